@@ -1,0 +1,759 @@
+/*
+ * bls381_oracle.c -- CPU restatement of the reference's pairing path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle for the HIP
+ * library (python-bls_amd/csrc); only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The shipped product never links,
+ * imports or falls back to anything in oracle/.
+ *
+ * It follows the REFERENCE'S OWN ALGORITHM step for step (zebra-lucky/python-bls
+ * v0.1.10, bls_py/fields_t.py): untwisted affine line functions evaluated in
+ * full Fq12 with one Fq12 inversion per step, affine twist-point arithmetic
+ * with 0^-1 := 0, and the final exponentiation as a 1268-bit square-and-multiply
+ * followed by two Frobenius corrections.  Each function cites the lines it
+ * restates.  The only liberty taken is the integer representation: Python ints
+ * with "% Q" become 6x64-bit Montgomery residues -- the residues are identical.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this file against
+ * the golden vectors in tests/golden/ that were produced by importing the
+ * reference itself (tests/golden/make_golden.py).
+ *
+ * Byte interface (same as include/blsgpu.h): Fq = 48-byte big-endian canonical
+ * residue; Fq12 = 12 x Fq in the reference's flat "ZT" order; G1 affine = x||y;
+ * G2 affine = x.c0||x.c1||y.c0||y.c1.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "oracle_consts.h"
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[6]; } fq;
+typedef struct { fq c0, c1; } fq2;
+typedef struct { fq2 c0, c1, c2; } fq6;
+typedef struct { fq6 c0, c1; } fq12;
+
+/* ------------------------------------------------------------------ Fq --- */
+static fq FQ_ZERO, FQ_ONE;            /* Montgomery 0 and 1 */
+
+static int fq_is_zero(const fq *a) {
+    uint64_t t = 0;
+    for (int i = 0; i < 6; i++) t |= a->l[i];
+    return t == 0;
+}
+static int fq_eq(const fq *a, const fq *b) { return memcmp(a, b, sizeof(fq)) == 0; }
+
+static int geq_q(const uint64_t *a) {
+    for (int i = 5; i >= 0; i--) {
+        if (a[i] > ORC_Q[i]) return 1;
+        if (a[i] < ORC_Q[i]) return 0;
+    }
+    return 1;
+}
+static void sub_q(uint64_t *a) {
+    u128 b = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 d = (u128)a[i] - ORC_Q[i] - (uint64_t)b;
+        a[i] = (uint64_t)d;
+        b = (d >> 64) & 1;
+    }
+}
+/* (a + b) % Q  -- fields_t.py inline "+ ... % Q" */
+static void fq_add(fq *r, const fq *a, const fq *b) {
+    u128 c = 0;
+    uint64_t t[6];
+    for (int i = 0; i < 6; i++) {
+        c += (u128)a->l[i] + b->l[i];
+        t[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    if (c || geq_q(t)) sub_q(t);
+    memcpy(r->l, t, sizeof t);
+}
+/* (a - b) % Q */
+static void fq_sub(fq *r, const fq *a, const fq *b) {
+    uint64_t t[6];
+    u128 br = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 d = (u128)a->l[i] - b->l[i] - (uint64_t)br;
+        t[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+    if (br) {
+        u128 c = 0;
+        for (int i = 0; i < 6; i++) {
+            c += (u128)t[i] + ORC_Q[i];
+            t[i] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    memcpy(r->l, t, sizeof t);
+}
+static void fq_neg(fq *r, const fq *a) { fq_sub(r, &FQ_ZERO, a); }
+
+/* a * b % Q  (Montgomery CIOS; operands and result carry the factor R) */
+static void fq_mul(fq *r, const fq *a, const fq *b) {
+    uint64_t t[8] = {0};
+    for (int i = 0; i < 6; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 6; j++) {
+            c += (u128)a->l[j] * b->l[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[6];
+        t[6] = (uint64_t)c;
+        t[7] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * ORC_QINV;
+        c = (u128)m * ORC_Q[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 6; j++) {
+            c += (u128)m * ORC_Q[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[6];
+        t[5] = (uint64_t)c;
+        t[6] = t[7] + (uint64_t)(c >> 64);
+    }
+    if (t[6] || geq_q(t)) sub_q(t);
+    memcpy(r->l, t, sizeof(uint64_t) * 6);
+}
+static void fq_sqr(fq *r, const fq *a) { fq_mul(r, a, a); }
+
+/* fq_pow, fields_t.py:58-68 (LSB-first square and multiply) */
+static void fq_pow_limbs(fq *r, const fq *a, const uint64_t *e, int nl) {
+    fq res = FQ_ONE, base = *a;
+    for (int i = 0; i < nl; i++)
+        for (int b = 0; b < 64; b++) {
+            if ((e[i] >> b) & 1) fq_mul(&res, &res, &base);
+            fq_sqr(&base, &base);
+        }
+    *r = res;
+}
+/* fq_invert, fields_t.py:47-55.  The reference runs extended Euclid, which
+ * returns 0 for input 0; a^(q-2) yields the same residue for every input,
+ * including 0 -> 0. */
+static void fq_inv(fq *r, const fq *a) { fq_pow_limbs(r, a, ORC_Q_MINUS_2, 6); }
+
+static void fq_from_bytes(fq *r, const uint8_t *be) {
+    fq t;
+    for (int i = 0; i < 6; i++) {
+        uint64_t w = 0;
+        for (int k = 0; k < 8; k++) w = (w << 8) | be[(5 - i) * 8 + k];
+        t.l[i] = w;
+    }
+    fq r2;
+    memcpy(r2.l, ORC_R2, sizeof r2.l);
+    fq_mul(r, &t, &r2);               /* also reduces a non-canonical input */
+}
+static void fq_to_bytes(uint8_t *be, const fq *a) {
+    fq one = {{1, 0, 0, 0, 0, 0}}, t;
+    fq_mul(&t, a, &one);
+    for (int i = 0; i < 6; i++)
+        for (int k = 0; k < 8; k++) be[(5 - i) * 8 + k] = (uint8_t)(t.l[i] >> (56 - 8 * k));
+}
+static void fq_mul_small(fq *r, const fq *a, unsigned k) {   /* a*k, k small */
+    fq acc = FQ_ZERO;
+    for (unsigned i = 0; i < k; i++) fq_add(&acc, &acc, a);
+    *r = acc;
+}
+
+/* ----------------------------------------------------------------- Fq2 --- */
+static fq2 FQ2_ZERO, FQ2_ONE, XI_INV; /* XI_INV = (tw1, tw2), fields_t.py:29-32 */
+
+static int fq2_is_zero(const fq2 *a) { return fq_is_zero(&a->c0) && fq_is_zero(&a->c1); }
+static int fq2_eq(const fq2 *a, const fq2 *b) { return fq_eq(&a->c0, &b->c0) && fq_eq(&a->c1, &b->c1); }
+static void fq2_add(fq2 *r, const fq2 *a, const fq2 *b) { fq_add(&r->c0, &a->c0, &b->c0); fq_add(&r->c1, &a->c1, &b->c1); }
+static void fq2_sub(fq2 *r, const fq2 *a, const fq2 *b) { fq_sub(&r->c0, &a->c0, &b->c0); fq_sub(&r->c1, &a->c1, &b->c1); }
+static void fq2_neg(fq2 *r, const fq2 *a) { fq_neg(&r->c0, &a->c0); fq_neg(&r->c1, &a->c1); }
+/* fq2_mul, fields_t.py:157-161: (am - bn, an + bm) */
+static void fq2_mul(fq2 *r, const fq2 *x, const fq2 *y) {
+    fq am, bn, an, bm;
+    fq_mul(&am, &x->c0, &y->c0);
+    fq_mul(&bn, &x->c1, &y->c1);
+    fq_mul(&an, &x->c0, &y->c1);
+    fq_mul(&bm, &x->c1, &y->c0);
+    fq_sub(&r->c0, &am, &bn);
+    fq_add(&r->c1, &an, &bm);
+}
+static void fq2_mul_small(fq2 *r, const fq2 *a, unsigned k) { fq_mul_small(&r->c0, &a->c0, k); fq_mul_small(&r->c1, &a->c1, k); }
+/* fq2_mul_by_nonresidue, fields_t.py:113-116: (a - b, a + b) */
+static void fq2_mul_xi(fq2 *r, const fq2 *a) {
+    fq t0, t1;
+    fq_sub(&t0, &a->c0, &a->c1);
+    fq_add(&t1, &a->c0, &a->c1);
+    r->c0 = t0; r->c1 = t1;
+}
+/* fq2_invert, fields_t.py:81-85 */
+static void fq2_inv(fq2 *r, const fq2 *x) {
+    fq aa, bb, f;
+    fq_sqr(&aa, &x->c0);
+    fq_sqr(&bb, &x->c1);
+    fq_add(&aa, &aa, &bb);
+    fq_inv(&f, &aa);
+    fq nb;
+    fq_neg(&nb, &x->c1);
+    fq_mul(&r->c0, &x->c0, &f);
+    fq_mul(&r->c1, &nb, &f);
+}
+/* fq2_pow, fields_t.py:92-101 */
+static void fq2_pow_limbs(fq2 *r, const fq2 *a, const uint64_t *e, int nl) {
+    fq2 res = FQ2_ONE, base = *a;
+    for (int i = 0; i < nl; i++)
+        for (int b = 0; b < 64; b++) {
+            if ((e[i] >> b) & 1) fq2_mul(&res, &res, &base);
+            fq2_mul(&base, &base, &base);
+        }
+    *r = res;
+}
+static void fq2_conj(fq2 *r, const fq2 *a) { r->c0 = a->c0; fq_neg(&r->c1, &a->c1); }
+
+/* ----------------------------------------------------------------- Fq6 --- */
+static fq6 FQ6_ZERO, FQ6_ONE;
+
+static void fq6_add(fq6 *r, const fq6 *a, const fq6 *b) { fq2_add(&r->c0, &a->c0, &b->c0); fq2_add(&r->c1, &a->c1, &b->c1); fq2_add(&r->c2, &a->c2, &b->c2); }
+static void fq6_sub(fq6 *r, const fq6 *a, const fq6 *b) { fq2_sub(&r->c0, &a->c0, &b->c0); fq2_sub(&r->c1, &a->c1, &b->c1); fq2_sub(&r->c2, &a->c2, &b->c2); }
+static void fq6_neg(fq6 *r, const fq6 *a) { fq2_neg(&r->c0, &a->c0); fq2_neg(&r->c1, &a->c1); fq2_neg(&r->c2, &a->c2); }
+/* fq6_mul, fields_t.py:293-318.  The reference expands the 36 integer products
+ * of (a0 + a1 v + a2 v^2)(b0 + b1 v + b2 v^2) with v^3 = xi = 1+u; grouped by
+ * Fq2 coefficient this is exactly
+ *   c0 = a0 b0 + xi (a1 b2 + a2 b1),  c1 = a0 b1 + a1 b0 + xi a2 b2,
+ *   c2 = a0 b2 + a1 b1 + a2 b0. */
+static void fq6_mul(fq6 *r, const fq6 *a, const fq6 *b) {
+    fq2 t, u, c0, c1, c2;
+    fq2_mul(&t, &a->c1, &b->c2); fq2_mul(&u, &a->c2, &b->c1); fq2_add(&t, &t, &u); fq2_mul_xi(&t, &t);
+    fq2_mul(&u, &a->c0, &b->c0); fq2_add(&c0, &u, &t);
+    fq2_mul(&t, &a->c2, &b->c2); fq2_mul_xi(&t, &t);
+    fq2_mul(&u, &a->c0, &b->c1); fq2_add(&t, &t, &u);
+    fq2_mul(&u, &a->c1, &b->c0); fq2_add(&c1, &t, &u);
+    fq2_mul(&t, &a->c0, &b->c2); fq2_mul(&u, &a->c1, &b->c1); fq2_add(&t, &t, &u);
+    fq2_mul(&u, &a->c2, &b->c0); fq2_add(&c2, &t, &u);
+    r->c0 = c0; r->c1 = c1; r->c2 = c2;
+}
+/* fq6_mul_by_nonresidue, fields_t.py:215-220: (xi*c2, c0, c1) */
+static void fq6_mul_v(fq6 *r, const fq6 *a) {
+    fq2 t;
+    fq2_mul_xi(&t, &a->c2);
+    fq2 c0 = a->c0, c1 = a->c1;
+    r->c0 = t; r->c1 = c0; r->c2 = c1;
+}
+/* fq6_invert, fields_t.py:170-184 */
+static void fq6_inv(fq6 *r, const fq6 *x) {
+    const fq2 *a = &x->c0, *b = &x->c1, *c = &x->c2;
+    fq2 g0, g1, g2, t, u, factor;
+    fq2_mul(&g0, a, a); fq2_mul_xi(&t, c); fq2_mul(&t, b, &t); fq2_sub(&g0, &g0, &t);
+    fq2_mul(&g1, c, c); fq2_mul_xi(&g1, &g1); fq2_mul(&t, a, b); fq2_sub(&g1, &g1, &t);
+    fq2_mul(&g2, b, b); fq2_mul(&t, a, c); fq2_sub(&g2, &g2, &t);
+    fq2_mul(&t, &g1, c); fq2_mul(&u, &g2, b); fq2_add(&t, &t, &u); fq2_mul_xi(&t, &t);
+    fq2_mul(&u, &g0, a); fq2_add(&t, &u, &t);
+    fq2_inv(&factor, &t);
+    fq2_mul(&r->c0, &g0, &factor);
+    fq2_mul(&r->c1, &g1, &factor);
+    fq2_mul(&r->c2, &g2, &factor);
+}
+static void fq6_mul_fq2(fq6 *r, const fq6 *a, const fq2 *m) { fq2_mul(&r->c0, &a->c0, m); fq2_mul(&r->c1, &a->c1, m); fq2_mul(&r->c2, &a->c2, m); }
+
+/* ---------------------------------------------------------------- Fq12 --- */
+static fq12 FQ12_ZERO, FQ12_ONE;
+/* Frobenius coefficients, fields_t.py:1133-1216: GAMMA[i] = xi^((q^i-1)/6);
+ * (6,i,1) = GAMMA[i]^2, (6,i,2) = GAMMA[i]^4, (12,i,1) = GAMMA[i]. */
+static fq2 GAMMA[12], GAMMA2[12], GAMMA4[12];
+
+static int fq12_eq(const fq12 *a, const fq12 *b) { return memcmp(a, b, sizeof(fq12)) == 0; }
+static void fq12_add(fq12 *r, const fq12 *a, const fq12 *b) { fq6_add(&r->c0, &a->c0, &b->c0); fq6_add(&r->c1, &a->c1, &b->c1); }
+static void fq12_sub(fq12 *r, const fq12 *a, const fq12 *b) { fq6_sub(&r->c0, &a->c0, &b->c0); fq6_sub(&r->c1, &a->c1, &b->c1); }
+static void fq12_neg(fq12 *r, const fq12 *a) { fq6_neg(&r->c0, &a->c0); fq6_neg(&r->c1, &a->c1); }
+/* fq12_mul, fields_t.py:503-554: the 144 products of (a0 + a1 w)(b0 + b1 w),
+ * w^2 = v, grouped by Fq6 coefficient: c0 = a0 b0 + v a1 b1, c1 = a0 b1 + a1 b0 */
+static void fq12_mul(fq12 *r, const fq12 *a, const fq12 *b) {
+    fq6 t, u, c0, c1;
+    fq6_mul(&t, &a->c1, &b->c1); fq6_mul_v(&t, &t);
+    fq6_mul(&u, &a->c0, &b->c0); fq6_add(&c0, &u, &t);
+    fq6_mul(&t, &a->c0, &b->c1); fq6_mul(&u, &a->c1, &b->c0); fq6_add(&c1, &t, &u);
+    r->c0 = c0; r->c1 = c1;
+}
+/* fq12_mul_fq, fields_t.py:448-452 */
+static void fq12_mul_fq(fq12 *r, const fq12 *a, const fq *m) {
+    const fq *s = (const fq *)a;
+    fq *d = (fq *)r;
+    for (int i = 0; i < 12; i++) fq_mul(&d[i], &s[i], m);
+}
+static void fq12_mul_small(fq12 *r, const fq12 *a, unsigned k) {
+    const fq *s = (const fq *)a;
+    fq *d = (fq *)r;
+    for (int i = 0; i < 12; i++) fq_mul_small(&d[i], &s[i], k);
+}
+/* fq12_invert, fields_t.py:328-337 */
+static void fq12_inv(fq12 *r, const fq12 *x) {
+    fq6 aa, bb, factor, nb;
+    fq6_mul(&aa, &x->c0, &x->c0);
+    fq6_mul(&bb, &x->c1, &x->c1);
+    fq6_mul_v(&bb, &bb);
+    fq6_sub(&aa, &aa, &bb);
+    fq6_inv(&factor, &aa);
+    fq6_neg(&nb, &x->c1);
+    fq6_mul(&r->c0, &x->c0, &factor);
+    fq6_mul(&r->c1, &nb, &factor);
+}
+/* fq12_pow, fields_t.py:344-352 */
+static void fq12_pow_limbs(fq12 *r, const fq12 *a, const uint64_t *e, int nl) {
+    fq12 ans = FQ12_ONE, base = *a;
+    int top = nl * 64;
+    while (top > 0 && !((e[(top - 1) / 64] >> ((top - 1) % 64)) & 1)) top--;
+    for (int i = 0; i < top; i++) {
+        if ((e[i / 64] >> (i % 64)) & 1) fq12_mul(&ans, &ans, &base);
+        fq12_mul(&base, &base, &base);
+    }
+    *r = ans;
+}
+/* fq2_qi_pow / fq6_qi_pow / fq12_qi_pow, fields_t.py:104-110, 203-212, 355-364 */
+static void fq2_qi_pow(fq2 *r, const fq2 *x, int i) {
+    if (i % 2 == 0) { *r = *x; return; }
+    fq2_conj(r, x);                   /* c1 * (-1) */
+}
+static void fq6_qi_pow(fq6 *r, const fq6 *x, int i) {
+    i %= 6;
+    if (i == 0) { *r = *x; return; }
+    fq2 t;
+    fq2_qi_pow(&r->c0, &x->c0, i);
+    fq2_qi_pow(&t, &x->c1, i); fq2_mul(&r->c1, &t, &GAMMA2[i]);
+    fq2_qi_pow(&t, &x->c2, i); fq2_mul(&r->c2, &t, &GAMMA4[i]);
+}
+static void fq12_qi_pow(fq12 *r, const fq12 *x, int i) {
+    i %= 12;
+    if (i == 0) { *r = *x; return; }
+    fq6 t;
+    fq6_qi_pow(&r->c0, &x->c0, i);
+    fq6_qi_pow(&t, &x->c1, i);
+    fq6_mul_fq2(&r->c1, &t, &GAMMA[i]);   /* frob_coeffs[12,i,1] = (gamma,0,0) */
+}
+/* fq_sub_fq12, fields_t.py:402-406: (a - m, -n, -o, ...) */
+static void fq_sub_fq12(fq12 *r, const fq *a, const fq12 *m) {
+    fq12_neg(r, m);
+    fq_add(&r->c0.c0.c0, &r->c0.c0.c0, a);
+}
+
+/* ------------------------------------------------ twist curve, affine --- */
+typedef struct { fq2 x, y; int inf; } g2aff;
+typedef struct { fq x, y; int inf; } g1aff;
+
+/* fq2_double_point, fields_t.py:641-646 */
+static void g2_double_affine(g2aff *r, const g2aff *p) {
+    fq2 left, s, t, xr, yr;
+    fq2_mul(&left, &p->x, &p->x); fq2_mul_small(&left, &left, 3);
+    fq2_mul_small(&t, &p->y, 2); fq2_inv(&t, &t);
+    fq2_mul(&s, &left, &t);
+    fq2_mul(&xr, &s, &s); fq2_mul_small(&t, &p->x, 2); fq2_sub(&xr, &xr, &t);
+    fq2_sub(&t, &p->x, &xr); fq2_mul(&yr, &s, &t); fq2_sub(&yr, &yr, &p->y);
+    r->x = xr; r->y = yr; r->inf = 0;
+}
+/* fq2_add_points, fields_t.py:673-686 */
+static void g2_add_affine(g2aff *r, const g2aff *a, const g2aff *b) {
+    if (a->inf) { *r = *b; return; }
+    if (b->inf) { *r = *a; return; }
+    if (fq2_eq(&a->x, &b->x) && fq2_eq(&a->y, &b->y)) { g2_double_affine(r, a); return; }
+    if (fq2_eq(&a->x, &b->x)) { r->x = FQ2_ZERO; r->y = FQ2_ZERO; r->inf = 1; return; }
+    fq2 s, t, xr, yr;
+    fq2_sub(&t, &b->x, &a->x); fq2_inv(&t, &t);
+    fq2_sub(&s, &b->y, &a->y); fq2_mul(&s, &s, &t);
+    fq2_mul(&xr, &s, &s); fq2_sub(&xr, &xr, &a->x); fq2_sub(&xr, &xr, &b->x);
+    fq2_sub(&t, &a->x, &xr); fq2_mul(&yr, &s, &t); fq2_sub(&yr, &yr, &a->y);
+    r->x = xr; r->y = yr; r->inf = 0;
+}
+/* fq2_untwist, fields_t.py:936-943: x*xi^-1 into flat slots 4,5 (c0.c2);
+ * y*xi^-1 into flat slots 8,9 (c1.c1) */
+static void untwist(fq12 *nx, fq12 *ny, const fq2 *x, const fq2 *y) {
+    *nx = FQ12_ZERO; *ny = FQ12_ZERO;
+    fq2_mul(&nx->c0.c2, &XI_INV, x);
+    fq2_mul(&ny->c1.c1, &XI_INV, y);
+}
+/* fq2_double_line_eval, fields_t.py:1035-1049 */
+static void double_line_eval(fq12 *res, const fq2 *rx, const fq2 *ry, const fq *px, const fq *py) {
+    fq12 r12x, r12y, slope, t, v;
+    untwist(&r12x, &r12y, rx, ry);
+    fq12_mul(&slope, &r12x, &r12x); fq12_mul_small(&slope, &slope, 3);
+    fq12_mul_small(&t, &r12y, 2); fq12_inv(&t, &t);
+    fq12_mul(&slope, &slope, &t);
+    fq12_mul(&t, &slope, &r12x); fq12_sub(&v, &r12y, &t);
+    fq12_mul_fq(&t, &slope, px); fq_sub_fq12(res, py, &t);
+    fq12_sub(res, res, &v);
+}
+/* fq2_add_line_eval, fields_t.py:1052-1078 */
+static void add_line_eval(fq12 *res, const fq2 *rx, const fq2 *ry, const fq2 *qx, const fq2 *qy,
+                          const fq *px, const fq *py) {
+    fq12 r12x, r12y, q12x, q12y, nqx, nqy, slope, t, u, v;
+    untwist(&r12x, &r12y, rx, ry);
+    untwist(&q12x, &q12y, qx, qy);
+    fq12_neg(&nqx, &q12x); fq12_neg(&nqy, &q12y);
+    if (fq12_eq(&r12x, &nqx) && fq12_eq(&r12y, &nqy)) {    /* vertical line, :1062-1065 */
+        fq_sub_fq12(res, px, &r12x);
+        return;
+    }
+    fq12_sub(&t, &q12x, &r12x); fq12_inv(&t, &t);
+    fq12_sub(&slope, &q12y, &r12y); fq12_mul(&slope, &slope, &t);
+    fq12_mul(&t, &q12y, &r12x); fq12_mul(&u, &r12y, &q12x); fq12_sub(&v, &t, &u);
+    fq12_sub(&t, &r12x, &q12x); fq12_inv(&t, &t); fq12_mul(&v, &v, &t);
+    fq12_mul_fq(&t, &slope, px); fq_sub_fq12(res, py, &t);
+    fq12_sub(res, res, &v);
+}
+/* fq_miller_loop, fields_t.py:1091-1111.  As in the reference, P's infinity
+ * flag is never read and the line evaluations look at coordinates only; Q's
+ * flag reaches fq2_add_points (:1109), where a flagged Q leaves R unchanged
+ * (:676-677).  R's own flag is False from the first doubling on (:646). */
+static void miller_loop(fq12 *out, const g1aff *P, const g2aff *Qp) {
+    g2aff R = *Qp;
+    fq12 f = FQ12_ONE, l;
+    int nbits = 64;
+    while (!((ORC_NX >> (nbits - 1)) & 1)) nbits--;
+    for (int i = nbits - 2; i >= 0; i--) {
+        double_line_eval(&l, &R.x, &R.y, &P->x, &P->y);
+        fq12_mul(&f, &f, &f);           /* fq12_pow(f, 2) */
+        fq12_mul(&f, &f, &l);
+        g2_double_affine(&R, &R);
+        if ((ORC_NX >> i) & 1) {
+            add_line_eval(&l, &R.x, &R.y, &Qp->x, &Qp->y, &P->x, &P->y);
+            fq12_mul(&f, &f, &l);
+            g2_add_affine(&R, &R, Qp);
+        }
+    }
+    *out = f;
+}
+/* fq12_final_exp, fields_t.py:1124-1128 with FINAL_EXP_E of :44 */
+static void final_exp(fq12 *r, const fq12 *x) {
+    fq12 ans, t, u;
+    fq12_pow_limbs(&ans, x, ORC_FINAL_EXP_E, ORC_FINAL_EXP_LIMBS);
+    fq12_qi_pow(&t, &ans, 2); fq12_mul(&ans, &t, &ans);
+    fq12_qi_pow(&t, &ans, 6); fq12_inv(&u, &ans); fq12_mul(&ans, &t, &u);
+    *r = ans;
+}
+
+/* ---------------------------------------------- Jacobian group law ------ */
+typedef struct { fq x, y, z; int inf; } g1jac;
+typedef struct { fq2 x, y, z; int inf; } g2jac;
+
+/* fq_double_point_jacobian, fields_t.py:878-897 */
+static void g1_double_jac(g1jac *r, const g1jac *p) {
+    fq S, Ysq, Y4, M, Xp, Yp, Zp, t;
+    fq_sqr(&Ysq, &p->y);
+    fq_mul(&S, &p->x, &Ysq); fq_mul_small(&S, &S, 4);
+    fq_sqr(&Y4, &Ysq);
+    fq_sqr(&M, &p->x); fq_mul_small(&M, &M, 3);
+    fq_sqr(&Xp, &M); fq_mul_small(&t, &S, 2); fq_sub(&Xp, &Xp, &t);
+    fq_sub(&t, &S, &Xp); fq_mul(&Yp, &M, &t); fq_mul_small(&t, &Y4, 8); fq_sub(&Yp, &Yp, &t);
+    fq_mul(&Zp, &p->y, &p->z); fq_mul_small(&Zp, &Zp, 2);
+    r->x = Xp; r->y = Yp; r->z = Zp; r->inf = p->inf;
+}
+/* fq_add_points_jacobian, fields_t.py:762-797 */
+static void g1_add_jac(g1jac *r, const g1jac *a, const g1jac *b) {
+    if (a->inf) { *r = *b; return; }
+    if (b->inf) { *r = *a; return; }
+    fq z1s, z2s, u1, u2, s1, s2, t;
+    fq_sqr(&z2s, &b->z); fq_mul(&u1, &a->x, &z2s);
+    fq_sqr(&z1s, &a->z); fq_mul(&u2, &b->x, &z1s);
+    fq_mul(&t, &z2s, &b->z); fq_mul(&s1, &a->y, &t);
+    fq_mul(&t, &z1s, &a->z); fq_mul(&s2, &b->y, &t);
+    if (fq_eq(&u1, &u2)) {
+        if (!fq_eq(&s1, &s2)) { r->x = FQ_ONE; r->y = FQ_ONE; r->z = FQ_ZERO; r->inf = 1; return; }
+        g1_double_jac(r, a); r->inf = 0; return;
+    }
+    fq h, rr, hsq, hcu, xr, yr, zr;
+    fq_sub(&h, &u2, &u1); fq_sub(&rr, &s2, &s1);
+    fq_sqr(&hsq, &h); fq_mul(&hcu, &h, &hsq);
+    fq_sqr(&xr, &rr); fq_sub(&xr, &xr, &hcu);
+    fq_mul(&t, &u1, &hsq); fq_mul_small(&zr, &t, 2); fq_sub(&xr, &xr, &zr);
+    fq_sub(&t, &t, &xr); fq_mul(&yr, &rr, &t); fq_mul(&t, &s1, &hcu); fq_sub(&yr, &yr, &t);
+    fq_mul(&zr, &a->z, &b->z); fq_mul(&zr, &zr, &h);
+    r->x = xr; r->y = yr; r->z = zr; r->inf = 0;
+}
+/* fqx_double_point_jacobian over Fq2, fields_t.py:900-933 */
+static void g2_double_jac(g2jac *r, const g2jac *p) {
+    fq2 S, Ysq, Y4, M, Xp, Yp, Zp, t;
+    fq2_mul(&Ysq, &p->y, &p->y);
+    fq2_mul(&S, &p->x, &Ysq); fq2_mul_small(&S, &S, 4);
+    fq2_mul(&Y4, &Ysq, &Ysq);
+    fq2_mul(&M, &p->x, &p->x); fq2_mul_small(&M, &M, 3);
+    fq2_mul(&Xp, &M, &M); fq2_mul_small(&t, &S, 2); fq2_sub(&Xp, &Xp, &t);
+    fq2_sub(&t, &S, &Xp); fq2_mul(&Yp, &M, &t); fq2_mul_small(&t, &Y4, 8); fq2_sub(&Yp, &Yp, &t);
+    fq2_mul(&Zp, &p->y, &p->z); fq2_mul_small(&Zp, &Zp, 2);
+    r->x = Xp; r->y = Yp; r->z = Zp; r->inf = p->inf;
+}
+/* fq2_add_points_jacobian, fields_t.py:800-819 with :844-875 */
+static void g2_add_jac(g2jac *r, const g2jac *a, const g2jac *b) {
+    if (a->inf) { *r = *b; return; }
+    if (b->inf) { *r = *a; return; }
+    fq2 z1s, z2s, u1, u2, s1, s2, t;
+    fq2_mul(&z2s, &b->z, &b->z); fq2_mul(&u1, &a->x, &z2s);
+    fq2_mul(&z1s, &a->z, &a->z); fq2_mul(&u2, &b->x, &z1s);
+    fq2_mul(&t, &z2s, &b->z); fq2_mul(&s1, &a->y, &t);
+    fq2_mul(&t, &z1s, &a->z); fq2_mul(&s2, &b->y, &t);
+    if (fq2_eq(&u1, &u2)) {
+        if (!fq2_eq(&s1, &s2)) { r->x = FQ2_ONE; r->y = FQ2_ONE; r->z = FQ2_ZERO; r->inf = 1; return; }
+        g2_double_jac(r, a); r->inf = 0; return;
+    }
+    fq2 h, rr, hsq, hcu, xr, yr, zr;
+    fq2_sub(&h, &u2, &u1); fq2_sub(&rr, &s2, &s1);
+    fq2_mul(&hsq, &h, &h); fq2_mul(&hcu, &h, &hsq);
+    fq2_mul(&xr, &rr, &rr); fq2_sub(&xr, &xr, &hcu);
+    fq2_mul(&t, &u1, &hsq); fq2_mul_small(&zr, &t, 2); fq2_sub(&xr, &xr, &zr);
+    fq2_sub(&t, &t, &xr); fq2_mul(&yr, &rr, &t); fq2_mul(&t, &s1, &hcu); fq2_sub(&yr, &yr, &t);
+    fq2_mul(&zr, &a->z, &b->z); fq2_mul(&zr, &zr, &h);
+    r->x = xr; r->y = yr; r->z = zr; r->inf = 0;
+}
+/* fq_scalar_mult_jacobian / fq2_scalar_mult_jacobian, fields_t.py:705-740:
+ * LSB-first double-and-add; "c % Q == 0" -> infinity. Scalars here are < 2^256
+ * so c % Q == 0 iff c == 0. */
+static void g1_scalar_mul(g1jac *r, const uint8_t *k_be, size_t klen, const g1jac *p) {
+    g1jac res = {FQ_ONE, FQ_ONE, FQ_ZERO, 1}, add = *p;
+    int any = 0;
+    for (size_t i = 0; i < klen; i++) any |= k_be[i];
+    if (p->inf || !any) { *r = res; return; }
+    size_t top = 0;
+    while (top < klen && k_be[top] == 0) top++;
+    for (size_t i = klen; i-- > top;)
+        for (int b = 0; b < 8; b++) {
+            if (i == top && !(k_be[i] >> b)) break;
+            if ((k_be[i] >> b) & 1) g1_add_jac(&res, &res, &add);
+            g1_double_jac(&add, &add);
+        }
+    *r = res;
+}
+static void g2_scalar_mul(g2jac *r, const uint8_t *k_be, size_t klen, const g2jac *p) {
+    g2jac res = {FQ2_ONE, FQ2_ONE, FQ2_ZERO, 1}, add = *p;
+    int any = 0;
+    for (size_t i = 0; i < klen; i++) any |= k_be[i];
+    if (p->inf || !any) { *r = res; return; }
+    size_t top = 0;
+    while (top < klen && k_be[top] == 0) top++;
+    for (size_t i = klen; i-- > top;)
+        for (int b = 0; b < 8; b++) {
+            if (i == top && !(k_be[i] >> b)) break;
+            if ((k_be[i] >> b) & 1) g2_add_jac(&res, &res, &add);
+            g2_double_jac(&add, &add);
+        }
+    *r = res;
+}
+/* fq_to_affine / fq2_to_affine, fields_t.py:609-622 */
+static void g1_to_affine(g1aff *r, const g1jac *p) {
+    if (p->inf) { r->x = FQ_ZERO; r->y = FQ_ZERO; r->inf = 1; return; }
+    fq z2, z3, t;
+    fq_sqr(&z2, &p->z); fq_mul(&z3, &z2, &p->z);
+    fq_inv(&t, &z2); fq_mul(&r->x, &p->x, &t);
+    fq_inv(&t, &z3); fq_mul(&r->y, &p->y, &t);
+    r->inf = 0;
+}
+static void g2_to_affine(g2aff *r, const g2jac *p) {
+    if (p->inf) { r->x = FQ2_ZERO; r->y = FQ2_ZERO; r->inf = 1; return; }
+    fq2 z2, z3, t;
+    fq2_mul(&z2, &p->z, &p->z); fq2_mul(&z3, &z2, &p->z);
+    fq2_inv(&t, &z2); fq2_mul(&r->x, &p->x, &t);
+    fq2_inv(&t, &z3); fq2_mul(&r->y, &p->y, &t);
+    r->inf = 0;
+}
+
+/* ------------------------------------------------------------- init ----- */
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+
+static void init_consts(void) {
+    memset(&FQ_ZERO, 0, sizeof FQ_ZERO);
+    memcpy(FQ_ONE.l, ORC_R1, sizeof FQ_ONE.l);
+    FQ2_ZERO.c0 = FQ_ZERO; FQ2_ZERO.c1 = FQ_ZERO;
+    FQ2_ONE.c0 = FQ_ONE; FQ2_ONE.c1 = FQ_ZERO;
+    memset(&FQ6_ZERO, 0, sizeof FQ6_ZERO);
+    FQ6_ONE = FQ6_ZERO; FQ6_ONE.c0 = FQ2_ONE;
+    memset(&FQ12_ZERO, 0, sizeof FQ12_ZERO);
+    FQ12_ONE = FQ12_ZERO; FQ12_ONE.c0 = FQ6_ONE;
+    fq2 xi = {FQ_ONE, FQ_ONE};
+    fq2_inv(&XI_INV, &xi);
+    /* gamma_1 = xi^((q-1)/6); gamma_i = conj(gamma_{i-1}) * gamma_1  (x -> x^q on Fq2 is conjugation) */
+    GAMMA[0] = FQ2_ONE;
+    fq2_pow_limbs(&GAMMA[1], &xi, ORC_XI_EXP_Q1_6, 6);
+    for (int i = 2; i < 12; i++) {
+        fq2 c;
+        fq2_conj(&c, &GAMMA[i - 1]);
+        fq2_mul(&GAMMA[i], &c, &GAMMA[1]);
+    }
+    for (int i = 0; i < 12; i++) {
+        fq2_mul(&GAMMA2[i], &GAMMA[i], &GAMMA[i]);
+        fq2_mul(&GAMMA4[i], &GAMMA2[i], &GAMMA2[i]);
+    }
+}
+static void ensure_init(void) { pthread_once(&g_once, init_consts); }
+
+/* ----------------------------------------------------- byte codecs ------ */
+static void fq2_from_bytes(fq2 *r, const uint8_t *b) { fq_from_bytes(&r->c0, b); fq_from_bytes(&r->c1, b + 48); }
+static void fq2_to_bytes(uint8_t *b, const fq2 *a) { fq_to_bytes(b, &a->c0); fq_to_bytes(b + 48, &a->c1); }
+static void fq12_from_bytes(fq12 *r, const uint8_t *b) { fq *d = (fq *)r; for (int i = 0; i < 12; i++) fq_from_bytes(&d[i], b + 48 * i); }
+static void fq12_to_bytes(uint8_t *b, const fq12 *a) { const fq *s = (const fq *)a; for (int i = 0; i < 12; i++) fq_to_bytes(b + 48 * i, &s[i]); }
+static void g1_from_bytes(g1aff *p, const uint8_t *b) { fq_from_bytes(&p->x, b); fq_from_bytes(&p->y, b + 48); p->inf = 0; }
+static void g2_from_bytes(g2aff *p, const uint8_t *b) { fq2_from_bytes(&p->x, b); fq2_from_bytes(&p->y, b + 96); p->inf = 0; }
+
+/* ======================================================= exported API === */
+#define EXPORT __attribute__((visibility("default")))
+
+/* one Miller loop, pre-final-exponentiation value (fq_miller_loop) */
+EXPORT int oracle_miller_loop(const uint8_t g1[96], const uint8_t g2[192], int qinf, uint8_t out[576]) {
+    ensure_init();
+    g1aff P; g2aff Qp; fq12 f;
+    g1_from_bytes(&P, g1); g2_from_bytes(&Qp, g2);
+    Qp.inf = qinf ? 1 : 0;
+    miller_loop(&f, &P, &Qp);
+    fq12_to_bytes(out, &f);
+    return 0;
+}
+EXPORT int oracle_final_exp(const uint8_t in[576], uint8_t out[576]) {
+    ensure_init();
+    fq12 x, r;
+    fq12_from_bytes(&x, in);
+    final_exp(&r, &x);
+    fq12_to_bytes(out, &r);
+    return 0;
+}
+
+typedef struct { const uint8_t *g1, *g2, *inf; size_t lo, hi; fq12 prod; } mt_job;
+static void *mt_worker(void *arg) {
+    mt_job *j = (mt_job *)arg;
+    fq12 prod = FQ12_ONE, f;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        g1aff P; g2aff Qp;
+        g1_from_bytes(&P, j->g1 + 96 * i); g2_from_bytes(&Qp, j->g2 + 192 * i);
+        if (j->inf) Qp.inf = j->inf[2 * i + 1] ? 1 : 0;
+        miller_loop(&f, &P, &Qp);
+        fq12_mul(&prod, &prod, &f);
+    }
+    j->prod = prod;
+    return NULL;
+}
+/* fq_ate_pairing_multi, fields_t.py:1114-1121.  threads <= 1 is the reference's
+ * serial loop; threads > 1 splits the (commutative) product across pthreads. */
+EXPORT int oracle_pairing_multi_mt(const uint8_t *g1, const uint8_t *g2, const uint8_t *inf /* n x {pinf,qinf} or NULL */,
+                                   size_t n, int threads, uint8_t out[576]) {
+    ensure_init();
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+    mt_job *jobs = (mt_job *)calloc((size_t)threads, sizeof(mt_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -12; }
+    for (int t = 0; t < threads; t++) {
+        jobs[t].g1 = g1; jobs[t].g2 = g2; jobs[t].inf = inf;
+        jobs[t].lo = n * (size_t)t / (size_t)threads;
+        jobs[t].hi = n * (size_t)(t + 1) / (size_t)threads;
+    }
+    if (threads == 1) mt_worker(&jobs[0]);
+    else {
+        for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    }
+    fq12 prod = FQ12_ONE, r;
+    for (int t = 0; t < threads; t++) fq12_mul(&prod, &prod, &jobs[t].prod);
+    final_exp(&r, &prod);
+    fq12_to_bytes(out, &r);
+    free(jobs); free(th);
+    return 0;
+}
+EXPORT int oracle_pairing_multi(const uint8_t *g1, const uint8_t *g2, const uint8_t *inf, size_t n, uint8_t out[576]) {
+    return oracle_pairing_multi_mt(g1, g2, inf, n, 1, out);
+}
+
+/* field operations for the KAT tests: degree in {1,2,6,12}; op: 0 add, 1 sub,
+ * 2 mul, 3 neg, 4 inv.  b is ignored for unary ops. */
+EXPORT int oracle_field_op(int degree, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    ensure_init();
+    if (degree == 1) {
+        fq x, y, r;
+        fq_from_bytes(&x, a); if (op < 3) fq_from_bytes(&y, b);
+        switch (op) { case 0: fq_add(&r, &x, &y); break; case 1: fq_sub(&r, &x, &y); break;
+            case 2: fq_mul(&r, &x, &y); break; case 3: fq_neg(&r, &x); break; case 4: fq_inv(&r, &x); break; default: return -22; }
+        fq_to_bytes(out, &r); return 0;
+    }
+    if (degree == 2) {
+        fq2 x, y, r;
+        fq2_from_bytes(&x, a); if (op < 3) fq2_from_bytes(&y, b);
+        switch (op) { case 0: fq2_add(&r, &x, &y); break; case 1: fq2_sub(&r, &x, &y); break;
+            case 2: fq2_mul(&r, &x, &y); break; case 3: fq2_neg(&r, &x); break; case 4: fq2_inv(&r, &x); break; default: return -22; }
+        fq2_to_bytes(out, &r); return 0;
+    }
+    if (degree == 6) {
+        fq6 x, y, r;
+        for (int i = 0; i < 3; i++) { fq2_from_bytes(&((fq2 *)&x)[i], a + 96 * i); if (op < 3) fq2_from_bytes(&((fq2 *)&y)[i], b + 96 * i); }
+        switch (op) { case 0: fq6_add(&r, &x, &y); break; case 1: fq6_sub(&r, &x, &y); break;
+            case 2: fq6_mul(&r, &x, &y); break; case 3: fq6_neg(&r, &x); break; case 4: fq6_inv(&r, &x); break; default: return -22; }
+        for (int i = 0; i < 3; i++) fq2_to_bytes(out + 96 * i, &((fq2 *)&r)[i]);
+        return 0;
+    }
+    if (degree == 12) {
+        fq12 x, y, r;
+        fq12_from_bytes(&x, a); if (op < 3) fq12_from_bytes(&y, b);
+        switch (op) { case 0: fq12_add(&r, &x, &y); break; case 1: fq12_sub(&r, &x, &y); break;
+            case 2: fq12_mul(&r, &x, &y); break; case 3: fq12_neg(&r, &x); break; case 4: fq12_inv(&r, &x); break; default: return -22; }
+        fq12_to_bytes(out, &r); return 0;
+    }
+    return -22;
+}
+/* Frobenius x -> x^(q^i) for degree 2, 6, 12 */
+EXPORT int oracle_qi_pow(int degree, const uint8_t *a, int i, uint8_t *out) {
+    ensure_init();
+    if (degree == 2) { fq2 x, r; fq2_from_bytes(&x, a); fq2_qi_pow(&r, &x, i); fq2_to_bytes(out, &r); return 0; }
+    if (degree == 6) {
+        fq6 x, r;
+        for (int k = 0; k < 3; k++) fq2_from_bytes(&((fq2 *)&x)[k], a + 96 * k);
+        fq6_qi_pow(&r, &x, i);
+        for (int k = 0; k < 3; k++) fq2_to_bytes(out + 96 * k, &((fq2 *)&r)[k]);
+        return 0;
+    }
+    if (degree == 12) { fq12 x, r; fq12_from_bytes(&x, a); fq12_qi_pow(&r, &x, i); fq12_to_bytes(out, &r); return 0; }
+    return -22;
+}
+/* fq12_pow with a big-endian exponent of elen bytes */
+EXPORT int oracle_fq12_pow(const uint8_t in[576], const uint8_t *e_be, size_t elen, uint8_t out[576]) {
+    ensure_init();
+    size_t nl = (elen + 7) / 8;
+    if (nl == 0) nl = 1;
+    uint64_t *e = (uint64_t *)calloc(nl, sizeof(uint64_t));
+    if (!e) return -12;
+    for (size_t i = 0; i < elen; i++) e[i / 8] |= (uint64_t)e_be[elen - 1 - i] << (8 * (i % 8));
+    fq12 x, r;
+    fq12_from_bytes(&x, in);
+    fq12_pow_limbs(&r, &x, e, (int)nl);
+    fq12_to_bytes(out, &r);
+    free(e);
+    return 0;
+}
+
+/* sum_i k_i * P_i with the reference's double-and-add and Jacobian addition
+ * (the loop of bls.py:215-221 / threshold.py:131-135).  scalars: n x slen
+ * big-endian bytes, or NULL for a plain sum.  Output: affine bytes + inf flag
+ * (to_affine of infinity is (0,0), fields_t.py:609-611). */
+EXPORT int oracle_g1_msm(const uint8_t *pts, const uint8_t *scalars, size_t slen, size_t n, uint8_t out[96], uint8_t *out_inf) {
+    ensure_init();
+    g1jac acc = {FQ_ONE, FQ_ONE, FQ_ZERO, 1};
+    for (size_t i = 0; i < n; i++) {
+        g1aff a; g1_from_bytes(&a, pts + 96 * i);
+        g1jac p = {a.x, a.y, FQ_ONE, 0}, t;
+        if (fq_is_zero(&a.x) && fq_is_zero(&a.y)) p.inf = 1;   /* (0,0) encodes infinity */
+        if (scalars) g1_scalar_mul(&t, scalars + slen * i, slen, &p); else t = p;
+        g1_add_jac(&acc, &acc, &t);
+    }
+    g1aff r; g1_to_affine(&r, &acc);
+    fq_to_bytes(out, &r.x); fq_to_bytes(out + 48, &r.y);
+    if (out_inf) *out_inf = (uint8_t)r.inf;
+    return 0;
+}
+EXPORT int oracle_g2_msm(const uint8_t *pts, const uint8_t *scalars, size_t slen, size_t n, uint8_t out[192], uint8_t *out_inf) {
+    ensure_init();
+    g2jac acc = {FQ2_ONE, FQ2_ONE, FQ2_ZERO, 1};
+    for (size_t i = 0; i < n; i++) {
+        g2aff a; g2_from_bytes(&a, pts + 192 * i);
+        g2jac p = {a.x, a.y, FQ2_ONE, 0}, t;
+        if (fq2_is_zero(&a.x) && fq2_is_zero(&a.y)) p.inf = 1;
+        if (scalars) g2_scalar_mul(&t, scalars + slen * i, slen, &p); else t = p;
+        g2_add_jac(&acc, &acc, &t);
+    }
+    g2aff r; g2_to_affine(&r, &acc);
+    fq2_to_bytes(out, &r.x); fq2_to_bytes(out + 96, &r.y);
+    if (out_inf) *out_inf = (uint8_t)r.inf;
+    return 0;
+}
+EXPORT const char *oracle_version(void) { return "bls381-oracle/1 (restates python-bls v0.1.10 fields_t.py)"; }

@@ -1,0 +1,520 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference, read-only).  Nothing
+of the reference is copied: this script calls its public functions on
+deterministic inputs and records inputs + outputs as hex/JSON/binary data.
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py [--big]
+
+Byte conventions (the ones include/blsgpu.h uses):
+  Fq     48-byte big-endian canonical residue
+  Fq2    c0 || c1                       (96 B)
+  Fq12   12 x Fq in the reference's flat ZT order   (576 B)   fields.py:624-629
+  G1 aff x || y                         (96 B)
+  G2 aff x.c0 || x.c1 || y.c0 || y.c1   (192 B)
+"""
+import hashlib
+import json
+import os
+import sys
+import logging
+
+logging.disable(logging.CRITICAL)
+sys.dont_write_bytecode = True
+REF = os.environ.get("BLS_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+from bls_py import fields_t as ft                      # noqa: E402
+from bls_py import tdata                               # noqa: E402
+from bls_py.aggregation_info import AggregationInfo    # noqa: E402
+from bls_py.bls import BLS                             # noqa: E402
+from bls_py.ec import (default_ec, default_ec_twist, generator_Fq, generator_Fq2,  # noqa: E402
+                       hash_to_point_prehashed_Fq2, hash_to_point_Fq2,
+                       hash_to_point_Fq, sw_encode, AffinePoint)
+from bls_py.fields import Fq, Fq2, Fq12                # noqa: E402
+from bls_py.keys import PrivateKey, PublicKey          # noqa: E402
+from bls_py.pairing import ate_pairing_multi           # noqa: E402
+from bls_py.signature import Signature                 # noqa: E402
+from bls_py.threshold import Threshold                 # noqa: E402
+from bls_py.util import hash256, hash_pks              # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+Q = default_ec.q
+N_ORDER = default_ec.n
+
+
+def fq_hex(v):
+    return int(v).to_bytes(48, "big").hex()
+
+
+def tup_hex(t):
+    return "".join(fq_hex(v) for v in t)
+
+
+def g1_bytes(p):
+    """AffinePoint over Fq -> 96 bytes."""
+    return int(p.x).to_bytes(48, "big") + int(p.y).to_bytes(48, "big")
+
+
+def g2_bytes(p):
+    """AffinePoint over Fq2 -> 192 bytes."""
+    return b"".join(int(c).to_bytes(48, "big")
+                    for c in (p.x.ZT[0], p.x.ZT[1], p.y.ZT[0], p.y.ZT[1]))
+
+
+def g1_tuple(p):
+    return (p.x.Z, p.y.Z, p.infinity)
+
+
+def g2_tuple(p):
+    return (p.x.ZT, p.y.ZT, p.infinity)
+
+
+def prf_scalar(tag, seed, i):
+    """counter-mode PRF scalar in [1, n-1]."""
+    h = hashlib.sha256(tag + seed.to_bytes(4, "big") + i.to_bytes(4, "big"))
+    return int.from_bytes(h.digest(), "big") % (N_ORDER - 1) + 1
+
+
+def dump(name, obj):
+    path = os.path.join(HERE, name)
+    with open(path, "w") as f:
+        json.dump(obj, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("wrote", name, os.path.getsize(path), "bytes")
+
+
+# --------------------------------------------------------------------------
+def gen_fields():
+    out = {}
+    ops = {1: None}
+    qi = tdata.qint_list
+    out["operand_ints"] = [fq_hex(v) for v in qi]
+    # operands exactly as the reference's tdata builds them (tdata.py:73-97)
+    elems = {
+        1: [(qi[i],) for i in range(4)],
+        2: [tuple(qi[i + j] for j in range(0, 8, 4)) for i in range(4)],
+        6: [tuple(qi[i + j] for j in range(0, 24, 4)) for i in range(4)],
+        12: [tuple(qi[i + j] for j in range(0, 48, 4)) for i in range(4)],
+    }
+    # sanity: same operands as the reference objects
+    assert elems[2][1] == tdata.fq2_list[1].ZT
+    assert elems[6][2] == tdata.fq6_list[2].ZT
+    assert elems[12][3] == tdata.fq12_list[3].ZT
+
+    def f1(name):
+        return {
+            "add": lambda a, b: ((a[0] + b[0]) % Q,),
+            "sub": lambda a, b: ((a[0] - b[0]) % Q,),
+            "mul": lambda a, b: ((a[0] * b[0]) % Q,),
+            "neg": lambda a: ((-a[0]) % Q,),
+            "inv": lambda a: (ft.fq_invert(Q, a[0]),),
+        }[name]
+
+    table = {
+        1: {k: f1(k) for k in ("add", "sub", "mul", "neg", "inv")},
+        2: {"add": ft.fq2_add, "sub": ft.fq2_sub, "mul": ft.fq2_mul,
+            "neg": ft.fq2_neg, "inv": ft.fq2_invert},
+        6: {"add": ft.fq6_add, "sub": ft.fq6_sub, "mul": ft.fq6_mul,
+            "neg": ft.fq6_neg, "inv": ft.fq6_invert},
+        12: {"add": ft.fq12_add, "sub": ft.fq12_sub, "mul": ft.fq12_mul,
+             "neg": ft.fq12_neg, "inv": ft.fq12_invert},
+    }
+    classes = {1: tdata.fq_list, 2: tdata.fq2_list, 6: tdata.fq6_list,
+               12: tdata.fq12_list}
+    res_lists = {1: tdata.fq_res_list, 2: tdata.fq2_res_list,
+                 6: tdata.fq6_res_list, 12: tdata.fq12_res_list}
+    for d in (1, 2, 6, 12):
+        e = elems[d]
+        rec = {"operands": [tup_hex(x) for x in e]}
+        pairs = [(i, j) for i in range(4) for j in range(i + 1, 4)]
+        for op in ("add", "mul", "sub"):
+            rec[op] = [{"i": i, "j": j, "r": tup_hex(table[d][op](e[i], e[j]))}
+                       for i, j in pairs]
+        rec["neg"] = [tup_hex(table[d]["neg"](x)) for x in e]
+        rec["inv"] = [tup_hex(table[d]["inv"](x)) for x in e]
+        # cross-check the same-type results against the reference's own
+        # expected-value table: its tests use 6 add, 6 mul, 6 sub of the pairs
+        # above as the first 18 entries (tests.py:443-461 and siblings).
+        rl = res_lists[d]
+        k = 0
+        for op in ("add", "mul", "sub"):
+            for idx, (i, j) in enumerate(pairs):
+                got = table[d][op](e[i], e[j])
+                exp = rl[k]
+                exp_t = (exp.Z,) if d == 1 else exp.ZT
+                assert tuple(got) == tuple(exp_t), (d, op, i, j)
+                k += 1
+        out[str(d)] = rec
+    # Frobenius maps
+    out["fq2_qi_pow"] = [{"i": i, "r": tup_hex(ft.fq2_qi_pow(elems[2][0], i))}
+                         for i in range(0, 3)]
+    out["fq6_qi_pow"] = [{"i": i, "r": tup_hex(ft.fq6_qi_pow(elems[6][0], i))}
+                         for i in range(0, 7)]
+    out["fq12_qi_pow"] = [{"i": i, "r": tup_hex(ft.fq12_qi_pow(elems[12][0], i))}
+                          for i in range(0, 13)]
+    out["fq12_pow"] = [{"e": hex(e), "r": tup_hex(ft.fq12_pow(elems[12][1], e))}
+                       for e in (0, 1, 2, 3, 0xd201000000010000, N_ORDER)]
+    dump("fields.json", out)
+
+
+# --------------------------------------------------------------------------
+def multi(Ps, Qs):
+    return ft.fq_ate_pairing_multi(tuple(Ps), tuple(Qs))
+
+
+def pair_record(Ps, Qs, with_miller=False):
+    """Ps/Qs are tuples in the boundary's format (fields_t.py:1114-1121)."""
+    rec = {
+        "g1": [fq_hex(p[0]) + fq_hex(p[1]) for p in Ps],
+        "g2": [tup_hex(q[0]) + tup_hex(q[1]) for q in Qs],
+        "inf": [[bool(p[2]), bool(q[2])] for p, q in zip(Ps, Qs)],
+        "out": tup_hex(multi(Ps, Qs)),
+    }
+    if with_miller:
+        rec["miller"] = [tup_hex(ft.fq_miller_loop(p[0], p[1], p[2],
+                                                   q[0], q[1], q[2]))
+                         for p, q in zip(Ps, Qs)]
+    return rec
+
+
+def gen_pairing(big):
+    g1 = generator_Fq()
+    g2 = generator_Fq2()
+    out = {}
+    # single pairing of the generators, with the pre-final-exp Miller value
+    P = g1_tuple(g1)
+    Qp = g2_tuple(g2)
+    ml = ft.fq_miller_loop(P[0], P[1], P[2], Qp[0], Qp[1], Qp[2])
+    e11 = ft.fq12_final_exp(ml)
+    out["gen"] = {"g1": g1_bytes(g1).hex(), "g2": g2_bytes(g2).hex(),
+                  "miller": tup_hex(ml), "final_exp": tup_hex(e11),
+                  "sha256_miller": hashlib.sha256(bytes.fromhex(tup_hex(ml))).hexdigest(),
+                  "sha256_pairing": hashlib.sha256(bytes.fromhex(tup_hex(e11))).hexdigest()}
+    assert out["gen"]["sha256_pairing"] == \
+        "70f0561453673ff155a40ba3618727f8a411c492748d845280dd71dce099905a"
+    # final exponentiation on non-Miller inputs (arbitrary Fq12 elements)
+    qi = tdata.qint_list
+    fe_in = [tuple(qi[i + j] for j in range(0, 48, 4)) for i in range(2)]
+    out["final_exp"] = [{"in": tup_hex(x), "out": tup_hex(ft.fq12_final_exp(x))}
+                        for x in fe_in + [ml]]
+    # small multiples
+    Ps = [g1_tuple((i + 1) * g1) for i in range(4)]
+    Qs = [g2_tuple((i + 2) * g2) for i in range(4)]
+    out["small4"] = pair_record(Ps, Qs, with_miller=True)
+    assert tuple(ft.fq12_pow(e11, 40)) == tuple(multi(Ps, Qs))
+    # edge cases --------------------------------------------------------
+    zero1 = (0, 0, True)
+    zero2 = ((0, 0), (0, 0), True)
+    edge = {}
+    edge["empty"] = pair_record([], [])
+    edge["p_inf"] = pair_record([zero1], [Qp], with_miller=True)
+    edge["q_inf"] = pair_record([P], [zero2], with_miller=True)
+    # both zero: every line value is 0, so the product (and its final
+    # exponentiation) is the ZERO element, not one
+    edge["both_inf"] = pair_record([zero1], [zero2], with_miller=True)
+    # Q zero makes each line value equal P.y: py == 0 gives zero again
+    edge["q_inf_py_zero"] = pair_record([(5, 0, False)], [zero2], with_miller=True)
+    edge["both_inf_in_batch"] = pair_record([Ps[0], zero1], [Qs[0], zero2])
+    # flags are ignored by the reference: zero coords with inf=False
+    edge["p_zero_noflag"] = pair_record([(0, 0, False)], [Qp])
+    edge["q_zero_noflag"] = pair_record([P], [((0, 0), (0, 0), False)])
+    # ... and a valid point carrying inf=True is still paired
+    edge["flag_on_valid"] = pair_record([(P[0], P[1], True)],
+                                        [(Qp[0], Qp[1], True)])
+    edge["mixed"] = pair_record([Ps[0], zero1, Ps[1], Ps[2]],
+                                [Qs[0], Qs[1], zero2, Qs[2]])
+    edge["repeat"] = pair_record([Ps[1], Ps[1], Ps[1]], [Qs[2], Qs[2], Qs[2]])
+    negQ = g2_tuple((3 * g2).negate())
+    edge["q_and_negq"] = pair_record([Ps[1], Ps[1]], [g2_tuple(3 * g2), negQ])
+    negP = g1_tuple((2 * g1).negate())
+    edge["p_and_negp"] = pair_record([Ps[1], negP], [Qs[0], Qs[0]])
+    out["edge"] = edge
+    one = tup_hex(ft.FQ12_ONE_TUPLE)
+    for k in ("empty", "p_inf", "q_inf", "q_and_negq", "p_and_negp",
+              "p_zero_noflag", "q_zero_noflag"):
+        assert edge[k]["out"] == one, k
+    zero = tup_hex(ft.FQ12_ZERO_TUPLE)
+    for k in ("both_inf", "q_inf_py_zero", "both_inf_in_batch"):
+        assert edge[k]["out"] == zero, k
+    # PRF-seeded batches -------------------------------------------------
+    seeded = {}
+    sizes = [8, 65] + ([1025] if big else [])
+    nmax = max(sizes)
+    a = [prf_scalar(b"blsgpu/a", 1, i) for i in range(nmax)]
+    b = [prf_scalar(b"blsgpu/b", 1, i) for i in range(nmax)]
+    print("scalar-multiplying", nmax, "pairs ...")
+    Pp = [g1_tuple(a[i] * g1) for i in range(nmax)]
+    Qq = [g2_tuple(b[i] * g2) for i in range(nmax)]
+    blob1 = b"".join(bytes.fromhex(fq_hex(p[0]) + fq_hex(p[1])) for p in Pp)
+    blob2 = b"".join(bytes.fromhex(tup_hex(q[0]) + tup_hex(q[1])) for q in Qq)
+    with open(os.path.join(HERE, "pairs_seed1_g1.bin"), "wb") as f:
+        f.write(blob1)
+    with open(os.path.join(HERE, "pairs_seed1_g2.bin"), "wb") as f:
+        f.write(blob2)
+    for n in sizes:
+        print("reference multi-pairing n =", n)
+        res = multi(Pp[:n], Qq[:n])
+        s = sum(x * y for x, y in zip(a[:n], b[:n])) % N_ORDER
+        assert tuple(res) == tuple(ft.fq12_pow(e11, s))
+        seeded[str(n)] = {"n": n, "seed": 1, "out": tup_hex(res),
+                          "sum_ab_mod_n": hex(s),
+                          "sha256_g1": hashlib.sha256(blob1[:96 * n]).hexdigest(),
+                          "sha256_g2": hashlib.sha256(blob2[:192 * n]).hexdigest()}
+    seeded["scalars_a_first4"] = [hex(x) for x in a[:4]]
+    seeded["scalars_b_first4"] = [hex(x) for x in b[:4]]
+    out["seeded"] = seeded
+    dump("pairing.json", out)
+
+
+# --------------------------------------------------------------------------
+def sig_rec(sig):
+    return sig.serialize().hex()
+
+
+def gen_verify4():
+    """C1 of BASELINE.json: 4 signatures aggregated and verified (bls.py:153-201)."""
+    sks = [PrivateKey.from_seed(bytes([i + 1] * 5)) for i in range(4)]
+    msgs = [bytes([i, 100 + i]) for i in range(4)]
+    pks = [sk.get_public_key() for sk in sks]
+    sigs = [sk.sign(m) for sk, m in zip(sks, msgs)]
+    agg = BLS.aggregate_sigs(sigs)
+    ok = BLS.verify(agg)
+    # what verify hands to the pairing (bls.py:197-199)
+    info = agg.aggregation_info
+    mh = info.message_hashes
+    pkl = info.public_keys
+    g1neg = Fq(default_ec.n, -1) * generator_Fq()
+    Ps = [g1neg] + [(pk.value * info.tree[(h, pk)]).to_affine()
+                    for h, pk in zip(mh, pkl)]
+    Qs = [agg.value.to_affine()] + [hash_to_point_prehashed_Fq2(h) for h in mh]
+    res = ate_pairing_multi(Ps, Qs, default_ec)
+    assert (res == Fq12.one(Q)) and ok
+    # tampered: aggregate of the first three with the 4-signature info
+    bad = BLS.aggregate_sigs(sigs[:3])
+    bad.set_aggregation_info(info)
+    bad_ok = BLS.verify(bad)
+    assert not bad_ok
+    out = {
+        "seeds": [bytes([i + 1] * 5).hex() for i in range(4)],
+        "msgs": [m.hex() for m in msgs],
+        "sk": [sk.serialize().hex() for sk in sks],
+        "pk": [pk.serialize().hex() for pk in pks],
+        "sig": [sig_rec(s) for s in sigs],
+        "agg_sig": sig_rec(agg),
+        "agg_msg_hashes": [h.hex() for h in mh],
+        "agg_pks": [pk.serialize().hex() for pk in pkl],
+        "agg_exponents": [hex(info.tree[(h, pk)]) for h, pk in zip(mh, pkl)],
+        "pairing_g1": [g1_bytes(p).hex() for p in Ps],
+        "pairing_g2": [g2_bytes(q).hex() for q in Qs],
+        "pairing_out": tup_hex(res.ZT),
+        "verify": ok,
+        "tampered_sig": sig_rec(bad),
+        "tampered_verify": bad_ok,
+    }
+    dump("verify4.json", out)
+
+
+def gen_scheme():
+    """Scenario outputs of the scheme API on fixed seeds/messages."""
+    out = {}
+    seeds = [bytes([1, 2, 3, 4, 5]), bytes([1, 2, 3, 4, 5, 6])]
+    sk1, sk2 = [PrivateKey.from_seed(s) for s in seeds]
+    pk1, pk2 = sk1.get_public_key(), sk2.get_public_key()
+    m = bytes([7, 8, 9])
+    sig1, sig2 = sk1.sign(m), sk2.sign(m)
+    agg = BLS.aggregate_sigs([sig1, sig2])
+    agg_pk = BLS.aggregate_pub_keys([pk1, pk2], True)
+    agg_pk_ns = BLS.aggregate_pub_keys([pk1, pk2], False)
+    agg_sk = BLS.aggregate_priv_keys([sk1, sk2], [pk1, pk2], True)
+    v = {"seeds": [s.hex() for s in seeds], "msg": m.hex(),
+         "sk": [sk1.serialize().hex(), sk2.serialize().hex()],
+         "pk": [pk1.serialize().hex(), pk2.serialize().hex()],
+         "fingerprint": [pk1.get_fingerprint(), pk2.get_fingerprint()],
+         "sig": [sig_rec(sig1), sig_rec(sig2)],
+         "agg_sig": sig_rec(agg), "agg_pk_secure": agg_pk.serialize().hex(),
+         "agg_pk_simple": agg_pk_ns.serialize().hex(),
+         "agg_sk": agg_sk.serialize().hex(),
+         "verify_sig1": BLS.verify(sig1), "verify_agg": BLS.verify(agg)}
+    agg.set_aggregation_info(AggregationInfo.from_msg(agg_pk, m))
+    v["verify_agg_under_agg_pk"] = BLS.verify(agg)
+    s1b = sk1.sign(m)
+    s1b.set_aggregation_info(sig2.aggregation_info)
+    v["verify_swapped_info"] = BLS.verify(s1b)
+    sig3 = sk1.sign(bytes([1, 2, 3]))
+    sig4 = sk1.sign(bytes([1, 2, 3, 4]))
+    sig5 = sk2.sign(bytes([1, 2]))
+    agg2 = BLS.aggregate_sigs([sig3, sig4, sig5])
+    v["agg2_msgs"] = ["010203", "01020304", "0102"]
+    v["agg2_signers"] = [0, 0, 1]
+    v["agg2_sig"] = sig_rec(agg2)
+    v["verify_agg2"] = BLS.verify(agg2)
+    out["vectors"] = v
+    # nested aggregation with colliding messages + divide_by
+    m1, m2, m3, m4 = bytes([1, 2, 3, 40]), bytes([5, 6, 70, 201]), \
+        bytes([9, 10, 11, 12, 13]), bytes([15, 63, 244, 92, 0, 1])
+    s1, s2, s3, s4, s5, s6 = sk1.sign(m1), sk2.sign(m2), sk2.sign(m1), \
+        sk1.sign(m3), sk1.sign(m1), sk1.sign(m4)
+    sL = BLS.aggregate_sigs([s1, s2])
+    sR = BLS.aggregate_sigs([s3, s4, s5])
+    sF = BLS.aggregate_sigs([sL, sR, s6])
+    quo = sF.divide_by([s2, s5, s6])
+    n = {"msgs": [x.hex() for x in (m1, m2, m3, m4)],
+         "sig_L": sig_rec(sL), "sig_R": sig_rec(sR), "sig_final": sig_rec(sF),
+         "verify_L": BLS.verify(sL), "verify_R": BLS.verify(sR),
+         "verify_final": BLS.verify(sF),
+         "final_tree": [[h.hex(), pk.serialize().hex(), hex(sF.aggregation_info.tree[(h, pk)])]
+                        for h, pk in zip(sF.aggregation_info.message_hashes,
+                                         sF.aggregation_info.public_keys)],
+         "quotient": sig_rec(quo), "verify_quotient": BLS.verify(quo)}
+    out["nested"] = n
+    # (de)serialisation round trips
+    ser = []
+    for i in range(6):
+        sk = PrivateKey.from_seed(bytes([i, 50, 6, 244, 24, 199, 1, 25]))
+        pk = sk.get_public_key()
+        msg = bytes([100, 2, 254, 88, 90, 45, 23, i])
+        sg = sk.sign(msg)
+        pk_aff = pk.value.to_affine()
+        sg_aff = sg.value.to_affine()
+        assert PublicKey.from_bytes(pk.serialize()).value.to_affine() == pk_aff
+        assert Signature.from_bytes(sg.serialize()).value.to_affine() == sg_aff
+        ser.append({"seed": bytes([i, 50, 6, 244, 24, 199, 1, 25]).hex(),
+                    "msg": msg.hex(), "sk": sk.serialize().hex(),
+                    "pk": pk.serialize().hex(), "pk_affine": g1_bytes(pk_aff).hex(),
+                    "sig": sg.serialize().hex(), "sig_affine": g2_bytes(sg_aff).hex()})
+    out["serialization"] = ser
+    dump("scheme.json", out)
+
+
+def gen_hash_to_curve():
+    out = {}
+    h2 = []
+    for msg in (b"", b"chia", bytes([7, 8, 9]), bytes(range(32)), b"\xff" * 32):
+        hm = hash256(msg)
+        p = hash_to_point_prehashed_Fq2(hm)
+        assert p == hash_to_point_Fq2(msg)
+        h2.append({"msg": msg.hex(), "msg_hash": hm.hex(), "point": g2_bytes(p).hex()})
+    out["hash_to_g2"] = h2
+    p = hash_to_point_Fq(b"")
+    out["hash_to_g1_empty"] = {"point": g1_bytes(p).hex(), "ser": p.serialize().hex()}
+    sw = []
+    for t in (1, 2, 3, Q - 1, tdata.qint_list[0] % Q):
+        r = sw_encode(Fq(Q, t))
+        if not isinstance(r, AffinePoint):
+            r = r.to_affine()
+        sw.append({"t": fq_hex(t), "point": g1_bytes(r).hex()})
+    out["sw_encode_fq"] = sw
+    sw2 = []
+    for t in ((1, 0), (0, 1), (5, 7), (tdata.qint_list[1] % Q, tdata.qint_list[2] % Q)):
+        r = sw_encode(Fq2(Q, *t), default_ec_twist, Fq2)
+        if not isinstance(r, AffinePoint):
+            r = r.to_affine()
+        sw2.append({"t": tup_hex(t), "point": g2_bytes(r).hex()})
+    out["sw_encode_fq2"] = sw2
+    dump("hash_to_curve.json", out)
+
+
+def gen_threshold(big):
+    """Deterministic Joint-Feldman-free variant: one polynomial per group from
+    the PRF, shares = P(j); unit signatures combined with Lagrange weights
+    (threshold.py:56-88, 127-136)."""
+    out = {}
+    cases = [(3, 5, 1)] + ([(67, 100, 2)] if big else [])
+    for T, N, seed in cases:
+        coeffs = [prf_scalar(b"blsgpu/poly", seed, i) for i in range(T)]
+        shares = [sum(c * pow(x, i, N_ORDER) for i, c in enumerate(coeffs)) % N_ORDER
+                  for x in range(1, N + 1)]
+        # PRF-chosen T-subset of players 1..N
+        order = sorted(range(1, N + 1),
+                       key=lambda j: hashlib.sha256(b"blsgpu/subset" + seed.to_bytes(4, "big")
+                                                    + j.to_bytes(4, "big")).digest())
+        players = sorted(order[:T])
+        msg = b"threshold message " + bytes([seed])
+        master = PrivateKey(coeffs[0])
+        sig_master = master.sign(msg)
+        unit = [PrivateKey(shares[p - 1]).sign(msg) for p in players]
+        lambs = Threshold.lagrange_coeffs_at_zero(players)
+        comb = Threshold.aggregate_unit_sigs(unit, players, T)
+        assert comb == sig_master
+        comb.set_aggregation_info(AggregationInfo.from_msg(master.get_public_key(), msg))
+        ok = BLS.verify(comb)
+        assert ok
+        out["%d_of_%d" % (T, N)] = {
+            "T": T, "N": N, "seed": seed, "msg": msg.hex(),
+            "poly": [hex(c) for c in coeffs],
+            "players": players,
+            "shares": [hex(shares[p - 1]) for p in players],
+            "lambdas": [hex(int(l)) for l in lambs],
+            "unit_sigs": [sig_rec(s) for s in unit],
+            "unit_sigs_affine": [g2_bytes(s.value.to_affine()).hex() for s in unit],
+            "combined": sig_rec(comb),
+            "combined_affine": g2_bytes(comb.value.to_affine()).hex(),
+            "master_pk": master.get_public_key().serialize().hex(),
+            "verify": ok,
+        }
+    dump("threshold.json", out)
+
+
+def gen_msm(big):
+    """aggregate_pub_keys (bls.py:203-223) on PRF-seeded keys."""
+    out = {}
+    g1 = generator_Fq()
+    sizes = [2, 16] + ([1024] if big else [])
+    for n in sizes:
+        sks = [prf_scalar(b"blsgpu/a", 1, i) for i in range(n)]
+        pks = [PublicKey.from_g1((sk * g1).to_jacobian()) for sk in sks]
+        pk_in = [g1_bytes(pk.value.to_affine()) for pk in pks]
+        lst = list(pks)
+        sec = BLS.aggregate_pub_keys(lst, True)
+        sorted_ser = [pk.serialize().hex() for pk in lst]   # sorted in place
+        ts = hash_pks(n, lst)
+        lst2 = list(pks)
+        simple = BLS.aggregate_pub_keys(lst2, False)
+        rec = {"n": n,
+               "secure": sec.serialize().hex(),
+               "secure_affine": g1_bytes(sec.value.to_affine()).hex(),
+               "simple": simple.serialize().hex(),
+               "simple_affine": g1_bytes(simple.value.to_affine()).hex(),
+               "sha256_inputs": hashlib.sha256(b"".join(pk_in)).hexdigest(),
+               "sha256_sorted_ser": hashlib.sha256("".join(sorted_ser).encode()).hexdigest(),
+               "sha256_scalars": hashlib.sha256(b"".join(t.to_bytes(32, "big") for t in ts)).hexdigest()}
+        if n <= 16:
+            rec["pk_affine"] = [b.hex() for b in pk_in]
+            rec["sorted_ser"] = sorted_ser
+            rec["scalars"] = [hex(t) for t in ts]
+        out[str(n)] = rec
+    dump("msm.json", out)
+
+
+def gen_points():
+    """Group-law vectors in the boundary's Jacobian tuple form; parity is on
+    the affine image (fields_t.py:762-933, 705-741)."""
+    g1, g2 = generator_Fq(), generator_Fq2()
+    out = {"g1": [], "g2": []}
+    ks = [1, 2, 3, 5, N_ORDER - 1, prf_scalar(b"blsgpu/a", 1, 0), prf_scalar(b"blsgpu/b", 1, 3)]
+    for k in ks:
+        out["g1"].append({"k": hex(k), "p": g1_bytes(k * g1).hex()})
+        out["g2"].append({"k": hex(k), "p": g2_bytes(k * g2).hex()})
+    a, b = prf_scalar(b"blsgpu/a", 1, 1), prf_scalar(b"blsgpu/a", 1, 2)
+    out["g1_add"] = {"a": g1_bytes(a * g1).hex(), "b": g1_bytes(b * g1).hex(),
+                     "sum": g1_bytes(a * g1 + b * g1).hex(),
+                     "dbl": g1_bytes((a * g1) + (a * g1)).hex()}
+    out["g2_add"] = {"a": g2_bytes(a * g2).hex(), "b": g2_bytes(b * g2).hex(),
+                     "sum": g2_bytes(a * g2 + b * g2).hex(),
+                     "dbl": g2_bytes((a * g2) + (a * g2)).hex()}
+    dump("points.json", out)
+
+
+if __name__ == "__main__":
+    big = "--big" in sys.argv
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    gens = {"fields": gen_fields, "pairing": lambda: gen_pairing(big),
+            "verify4": gen_verify4, "scheme": gen_scheme,
+            "hash": gen_hash_to_curve, "threshold": lambda: gen_threshold(big),
+            "msm": lambda: gen_msm(big), "points": gen_points}
+    for name, fn in gens.items():
+        if not only or name in only:
+            print("==", name)
+            fn()
