@@ -1,0 +1,372 @@
+"""Schedule compiler for the field-arithmetic VM that the HIP kernels interpret.
+
+The GPU hot path (python-bls_amd/csrc/blsgpu_kernels.hip) does not hard-code the
+pairing formulas.  One wavefront ("team") owns one pairing; its Fq values live
+in an LDS scratchpad of 48-byte slots, and the 64 lanes execute *rounds*:
+
+  MUL round   every active lane:  dst <- A * B            (Montgomery product)
+  LIN round   every active lane:  dst <- sum of +/- slots (micro-ops ADD/SUB/DBL)
+  INV round   every active lane:  dst <- A^-1             (0 -> 0, like the
+                                                           reference's fq_invert)
+
+This module traces straight-line formulas written over `E` expressions into a
+DAG, list-schedules the DAG into rounds (<= 64 lanes each), allocates LDS slots
+by live range and emits the per-lane operand tables.  The same tables are
+executed by `sim.py` with Python integers, so the whole schedule is checked on
+the CPU against the oracle before it ever reaches a GPU.
+"""
+from collections import defaultdict
+
+LANES = 64
+
+# slot reference = (selector << 11) | offset
+SEL_TEAM, SEL_CONST, SEL_R0, SEL_R1, SEL_R2, SEL_R3 = 0, 1, 2, 3, 4, 5
+OFF_BITS = 11
+OFF_MASK = (1 << OFF_BITS) - 1
+NOSLOT = 0x3FFF
+
+UOP_ADD, UOP_SUB, UOP_DBL, UOP_NOP = 0, 1, 2, 3
+
+
+def ref(sel, off):
+    assert 0 <= off <= OFF_MASK and 0 <= sel < 8
+    return (sel << OFF_BITS) | off
+
+
+class V:
+    """A materialised Fq value (one slot)."""
+    __slots__ = ("id", "kind", "a", "b", "terms", "fixed", "name")
+
+    def __init__(self, id, kind, a=None, b=None, terms=None, fixed=None, name=None):
+        self.id, self.kind, self.a, self.b = id, kind, a, b
+        self.terms, self.fixed, self.name = terms, fixed, name
+
+    def __repr__(self):
+        return "V%d:%s" % (self.id, self.kind)
+
+
+class E:
+    """Lazy integer-linear combination of materialised values."""
+    __slots__ = ("b", "t")
+
+    def __init__(self, b, t):
+        self.b, self.t = b, {v: c for v, c in t.items() if c != 0}
+
+    def is_zero(self):
+        return not self.t
+
+    def __add__(self, o):
+        if isinstance(o, int) and o == 0:
+            return self
+        t = dict(self.t)
+        for v, c in o.t.items():
+            t[v] = t.get(v, 0) + c
+        return E(self.b, t)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        t = dict(self.t)
+        for v, c in o.t.items():
+            t[v] = t.get(v, 0) - c
+        return E(self.b, t)
+
+    def __neg__(self):
+        return E(self.b, {v: -c for v, c in self.t.items()})
+
+    def __mul__(self, o):
+        if isinstance(o, int):
+            return E(self.b, {v: c * o for v, c in self.t.items()})
+        return self.b.mul(self, o)
+
+    __rmul__ = __mul__
+
+    def mat(self):
+        """Force materialisation; returns an E with a single unit term."""
+        if self.is_zero():
+            return self
+        v = self.b.materialise(self)
+        return E(self.b, {v: 1})
+
+    def inv(self):
+        return self.b.inv(self)
+
+
+class Builder:
+    """Traces one segment."""
+
+    def __init__(self, name):
+        self.name = name
+        self.vals = []
+        self.outputs = []      # (V, fixed_ref)
+        self._lin_cache = {}
+        self._mul_cache = {}
+
+    def _new(self, kind, **kw):
+        v = V(len(self.vals), kind, **kw)
+        self.vals.append(v)
+        return v
+
+    def inp(self, fixed, name=None):
+        """A value that is live on entry in a fixed slot reference."""
+        return E(self, {self._new("in", fixed=fixed, name=name): 1})
+
+    def zero(self):
+        return E(self, {})
+
+    def materialise(self, e):
+        assert not e.is_zero(), "cannot materialise the constant 0 (use a const slot)"
+        items = tuple(sorted(((v.id, c) for v, c in e.t.items())))
+        if len(items) == 1 and items[0][1] == 1:
+            return next(iter(e.t))
+        if items in self._lin_cache:
+            return self._lin_cache[items]
+        v = self._new("lin", terms=[(c, v) for v, c in sorted(e.t.items(), key=lambda x: x[0].id)])
+        self._lin_cache[items] = v
+        return v
+
+    def mul(self, x, y):
+        if x.is_zero() or y.is_zero():
+            return self.zero()
+        a, b = self.materialise(x), self.materialise(y)
+        key = (min(a.id, b.id), max(a.id, b.id))
+        if key not in self._mul_cache:
+            self._mul_cache[key] = self._new("mul", a=a, b=b)
+        return E(self, {self._mul_cache[key]: 1})
+
+    def inv(self, x):
+        a = self.materialise(x)
+        return E(self, {self._new("inv", a=a): 1})
+
+    def out(self, e, fixed):
+        """Declare that expression e must be left in the fixed slot reference."""
+        assert not e.is_zero(), "segment outputs must be non-constant-zero (copy from ZERO const instead)"
+        v = self.materialise(e)
+        self.outputs.append((v, fixed))
+
+
+# ---------------------------------------------------------------------------
+def lower_lin(terms):
+    """[(coef, V)] -> list of (uop, V|None) evaluating sum(coef * V) with
+    acc starting at 0: bit-plane Horner over the binary expansions."""
+    maxbits = max(abs(c).bit_length() for c, _ in terms)
+    uops = []
+    for bit in range(maxbits - 1, -1, -1):
+        if uops:
+            uops.append((UOP_DBL, None))
+        for c, v in terms:
+            if (abs(c) >> bit) & 1:
+                uops.append((UOP_ADD if c > 0 else UOP_SUB, v))
+    # drop a leading DBL-free prefix problem: acc starts at 0 so DBL of 0 is harmless
+    return uops
+
+
+class Round:
+    def __init__(self, kind):
+        self.kind = kind       # 'mul' | 'lin' | 'inv'
+        self.ops = []          # list of V (one per lane)
+
+
+class Segment:
+    """A scheduled, slot-allocated segment ready for emission / simulation."""
+
+    def __init__(self, name):
+        self.name = name
+        self.rounds = []       # list of dict(kind, K, lanes=[...])
+        self.ntemp = 0
+        self.stats = {}
+
+
+def schedule(b, temp_base=0, lanes=LANES, verbose=False):
+    """List-schedule builder b into rounds and allocate slots.
+
+    Returns a Segment.  Temps are allocated in the TEAM region from temp_base.
+    """
+    vals = b.vals
+    live_out = {v.id for v, _ in b.outputs}
+    # prune dead values
+    needed = set()
+    stack = [v for v, _ in b.outputs]
+    while stack:
+        v = stack.pop()
+        if v.id in needed:
+            continue
+        needed.add(v.id)
+        if v.kind in ("mul",):
+            stack += [v.a, v.b]
+        elif v.kind == "inv":
+            stack.append(v.a)
+        elif v.kind == "lin":
+            stack += [t for _, t in v.terms]
+    ops = [v for v in vals if v.id in needed and v.kind != "in"]
+
+    def srcs(v):
+        if v.kind == "mul":
+            return [v.a, v.b]
+        if v.kind == "inv":
+            return [v.a]
+        return [t for _, t in v.terms]
+
+    users = defaultdict(list)
+    for v in ops:
+        for s in srcs(v):
+            users[s.id].append(v)
+    # critical-path priority (cost: mul 10, inv 60, lin 1+terms/4)
+    cost = {}
+    for v in ops:
+        cost[v.id] = 10 if v.kind == "mul" else (60 if v.kind == "inv" else 1 + len(v.terms) // 4)
+    prio = {}
+    for v in reversed(ops):
+        prio[v.id] = cost[v.id] + max([prio[u.id] for u in users[v.id]], default=0)
+
+    # ---- levelled list scheduling ------------------------------------------
+    # "heavy" ops (mul, inv) define levels: asap[v] = number of heavy ops on
+    # the longest input->v path.  A heavy op may run at any level in
+    # [asap, alap] without lengthening the schedule; ops with slack are used
+    # to fill lanes of rounds that must run anyway.
+    heavy = lambda v: v.kind in ("mul", "inv")
+    asap = {v.id: 0 for v in vals if v.kind == "in"}
+    for v in ops:
+        asap[v.id] = max([asap[s.id] for s in srcs(v)], default=0) + (1 if heavy(v) else 0)
+    depth = max([asap[v.id] for v in ops], default=0)
+    alap = {}
+    for v in reversed(ops):
+        lim = depth
+        for u in users[v.id]:
+            lim = min(lim, alap[u.id] - (1 if heavy(u) else 0))
+        alap[v.id] = lim
+    done = {v.id for v in vals if v.kind == "in"}
+    pending = list(ops)
+    rounds = []
+    round_of = {}
+
+    def emit(kind, chunk):
+        r = Round(kind)
+        r.ops = chunk
+        for v in chunk:
+            round_of[v.id] = len(rounds)
+            done.add(v.id)
+            pending.remove(v)
+        rounds.append(r)
+
+    level = 0
+    while pending:
+        # LIN phase: all ready linear ops, sub-level by sub-level
+        while True:
+            rl = [v for v in pending if v.kind == "lin" and all(s.id in done for s in srcs(v))]
+            if not rl:
+                break
+            rl.sort(key=lambda v: -prio[v.id])
+            for i in range(0, len(rl), lanes):
+                emit("lin", rl[i:i + lanes])
+        if not pending:
+            break
+        level += 1
+        for kind in ("inv", "mul"):
+            rh = [v for v in pending if v.kind == kind and all(s.id in done for s in srcs(v))]
+            must = [v for v in rh if alap[v.id] <= level]
+            if not must:
+                continue
+            cap = lanes * ((len(must) + lanes - 1) // lanes)
+            opt = sorted([v for v in rh if alap[v.id] > level], key=lambda v: (alap[v.id], -prio[v.id]))
+            chosen = must + opt[:cap - len(must)]
+            chosen.sort(key=lambda v: -prio[v.id])
+            for i in range(0, len(chosen), lanes):
+                emit(kind, chosen[i:i + lanes])
+        assert level <= depth + 2 * len(ops), "scheduler failed to progress"
+    # ---- live ranges -----------------------------------------------------
+    last_use = {}
+    for v in ops:
+        for s in srcs(v):
+            last_use[s.id] = max(last_use.get(s.id, -1), round_of[v.id])
+    nrounds = len(rounds)
+    # ---- slot assignment ---------------------------------------------------
+    slot = {}
+    for v in vals:
+        if v.kind == "in":
+            slot[v.id] = v.fixed
+    out_fixed = {}
+    for v, fx in b.outputs:
+        out_fixed.setdefault(v.id, []).append(fx)
+    # when does a fixed (input) slot become dead?  after the last use of the
+    # input value that lives there (or never used -> -1)
+    fixed_busy_until = {}
+    for v in vals:
+        if v.kind == "in" and v.id in needed:
+            fixed_busy_until[v.fixed] = last_use.get(v.id, -1)
+    free = []
+    ntemp = 0
+    copies = []                # (src_ref, dst_ref) needed at the end
+    release_at = defaultdict(list)
+    fixed_claimed = {}
+    for ri, r in enumerate(rounds):
+        for v in r.ops:
+            want = out_fixed.get(v.id, [])
+            chosen = None
+            for fx in want:
+                # may write straight into its output slot if whatever lives
+                # there is dead by now (read-before-write inside a round is safe)
+                if fixed_busy_until.get(fx, -1) <= ri and fx not in fixed_claimed:
+                    chosen = fx
+                    fixed_claimed[fx] = v.id
+                    break
+            if chosen is None:
+                if free:
+                    off = free.pop()
+                else:
+                    off = ntemp
+                    ntemp += 1
+                chosen = ref(SEL_TEAM, temp_base + off)
+                lu = last_use.get(v.id, ri)
+                if v.id in live_out:
+                    lu = nrounds      # must survive until the final copy
+                else:
+                    release_at[lu].append(off)
+            slot[v.id] = chosen
+            for fx in want:
+                if fx != chosen:
+                    copies.append((v, fx))
+        # slots whose last reader is this round can be recycled from the next
+        for off in release_at.pop(ri, []):
+            free.append(off)
+    # outputs that are plain inputs (pass-through to another slot)
+    for v, fx in b.outputs:
+        if v.kind == "in" and v.fixed != fx:
+            copies.append((v, fx))
+    seg = Segment(b.name)
+    for r in rounds:
+        lanes_out = []
+        if r.kind == "mul":
+            for v in r.ops:
+                lanes_out.append((slot[v.a.id], slot[v.b.id], slot[v.id]))
+            seg.rounds.append({"kind": "mul", "K": 0, "lanes": lanes_out})
+        elif r.kind == "inv":
+            for v in r.ops:
+                lanes_out.append((slot[v.a.id], slot[v.id]))
+            seg.rounds.append({"kind": "inv", "K": 0, "lanes": lanes_out})
+        else:
+            K = 0
+            for v in r.ops:
+                u = [(op, (slot[s.id] if s is not None else NOSLOT)) for op, s in lower_lin(v.terms)]
+                K = max(K, len(u))
+                lanes_out.append((u, slot[v.id]))
+            seg.rounds.append({"kind": "lin", "K": K, "lanes": lanes_out})
+    # final copy rounds (dst <- src as a 1-uop LIN); a chain of copies whose
+    # destination is another copy's source must be ordered: do them in one
+    # round, which is safe because every lane reads before any lane writes.
+    if copies:
+        assert len(copies) <= lanes, "too many output copies"
+        seg.rounds.append({"kind": "lin", "K": 1,
+                           "lanes": [([(UOP_ADD, slot[v.id])], fx) for v, fx in copies]})
+    seg.ntemp = ntemp
+    nm = sum(len(r["lanes"]) for r in seg.rounds if r["kind"] == "mul")
+    rm = sum(1 for r in seg.rounds if r["kind"] == "mul")
+    nl = sum(len(r["lanes"]) for r in seg.rounds if r["kind"] == "lin")
+    rl = sum(1 for r in seg.rounds if r["kind"] == "lin")
+    uops = sum(r["K"] for r in seg.rounds if r["kind"] == "lin")
+    seg.stats = {"mul_ops": nm, "mul_rounds": rm, "lin_ops": nl, "lin_rounds": rl,
+                 "lin_uop_depth": uops, "inv_rounds": sum(1 for r in seg.rounds if r["kind"] == "inv"),
+                 "ntemp": ntemp, "copies": len(copies)}
+    if verbose:
+        print("%-14s %s" % (b.name, seg.stats))
+    return seg

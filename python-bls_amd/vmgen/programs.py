@@ -1,0 +1,390 @@
+"""The VM programs of the pairing hot path: segments, memory map, scripts.
+
+Algorithm (what the GPU runs) versus the reference (what it must equal):
+
+* Miller loop over |x| = 0xd201000000010000, MSB-1 .. 0, NO final conjugation
+  -- exactly the loop of fields_t.py:1091-1111 -- but with the twist point T in
+  homogeneous projective coordinates and the line l(P) scaled by elements that
+  the final exponentiation kills (Fq2 factors and w^3):
+      tangent:  l = (Y^2 - 3b'Z^2) + (-3 X^2 px) v + (2YZ py) v w
+      chord  :  l = (th xq - la yq) + (-th px) v + (la py) v w,
+                th = Y - yq Z, la = X - xq Z
+  so that f <- f^2 * l is a 13-Fq2-product sparse multiplication.
+* Final exponentiation to the SAME power (q^12-1)/n as fields_t.py:1124-1128,
+  split as easy part (q^6-1)(q^2+1) then E = (q^4-q^2+1)/n with the exact
+  identity  E = ((x-1)^2/3)(x+q)(x^2+q^2-1) + 1  (x = -|x|), using cyclotomic
+  squarings.  The result is the identical field element, hence identical bytes.
+"""
+from . import tower as tw
+from .core import (Builder, SEL_CONST, SEL_R0, SEL_R1, SEL_R2, SEL_TEAM, ref,
+                   schedule)
+from .sim import Q, R, to_m
+
+NX = 0xd201000000010000                   # |x|  (fields_t.py:25)
+
+# ------------------------------------------------------------- memory map --
+# team region (one per wavefront / pairing), in 48-byte slots
+PX, PY = 0, 1
+QX0, QX1, QY0, QY1 = 2, 3, 4, 5
+TX, TY, TZ = 6, 8, 10                     # Fq2 each
+F = 12                                    # Fq12 accumulator (12 slots)
+LD = 24                                   # pending tangent line  l0,l1,l4 (6)
+LA = 30                                   # pending chord line    l0,l1,l4 (6)
+NPX3 = 36                                 # -3*px
+REG0 = 40                                 # Fq12 registers R[k] = REG0 + 12 k
+NREG = 6
+TEMP0 = REG0 + 12 * NREG                  # 112
+
+# constant region (shared by the workgroup)
+C_ZERO, C_ONE, C_R2, C_RAW1 = 0, 1, 2, 3
+C_GAM = 4                                 # gamma_i^j, i=1..3, j=1..5: Fq2 each
+NCONST = C_GAM + 3 * 5 * 2
+
+
+def _fq2_pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = ((r[0] * a[0] - r[1] * a[1]) % Q, (r[0] * a[1] + r[1] * a[0]) % Q)
+        a = ((a[0] * a[0] - a[1] * a[1]) % Q, (2 * a[0] * a[1]) % Q)
+        e >>= 1
+    return r
+
+
+def gamma(i, j):
+    """xi^(j (q^i - 1)/6) in Fq2 (plain domain)."""
+    return _fq2_pow((1, 1), j * (Q ** i - 1) // 6)
+
+
+def const_table():
+    """Montgomery contents of the constant region."""
+    c = [0] * NCONST
+    c[C_ZERO] = 0
+    c[C_ONE] = to_m(1)
+    c[C_R2] = to_m(R % Q)          # content R^2: raw x -> x R
+    c[C_RAW1] = 1                  # content 1: x R -> x
+    for i in (1, 2, 3):
+        for j in range(1, 6):
+            g = gamma(i, j)
+            k = C_GAM + ((i - 1) * 5 + (j - 1)) * 2
+            c[k], c[k + 1] = to_m(g[0]), to_m(g[1])
+    return c
+
+
+def T(off):
+    return ref(SEL_TEAM, off)
+
+
+def C(off):
+    return ref(SEL_CONST, off)
+
+
+def in2(b, off, name=None):
+    return (b.inp(T(off), name), b.inp(T(off + 1)))
+
+
+def out2(b, e, off):
+    b.out(e[0], T(off))
+    b.out(e[1], T(off + 1))
+
+
+def in12(b, sel, base=0):
+    return tw.unflat12([b.inp(ref(sel, base + i)) for i in range(12)])
+
+
+def out12(b, x, sel, base=0):
+    for i, e in enumerate(tw.flat12(x)):
+        b.out(e, ref(sel, base + i))
+
+
+# ------------------------------------------------------------ Miller loop --
+def xi3b_times(c):
+    """3 b' c with b' = 4 xi:  12 xi c   (linear)"""
+    return tw.f2_scale(tw.f2_mul_xi(c), 12)
+
+
+def t_double(cfg, Tp, px3n, py):
+    """Tangent step.  Tp = (X, Y, Z) Fq2 each.  Returns (T2, line).
+    Homogeneous doubling on y^2 = x^3 + b' scaled by 4 to avoid halving:
+      X3 = 2 XY (B - F), Y3 = (B + F)^2 - 12 E^2, Z3 = 4 B H
+      B = Y^2, C = Z^2, E = 3b'C, F = 3E, H = 2YZ
+    line: l0 = B - E, l1 = X^2 * (-3 px), l4 = H * py"""
+    X, Y, Z = Tp
+    A = cfg.mul2(X, Y)
+    B = cfg.sqr2(Y)
+    Cc = cfg.sqr2(Z)
+    XX = cfg.sqr2(X)
+    YZ = cfg.mul2(Y, Z)
+    E = xi3b_times(Cc)
+    Fv = tw.f2_scale(E, 3)
+    H = tw.f2_scale(YZ, 2)
+    X3 = tw.f2_scale(cfg.mul2(A, tw.f2_sub(B, Fv)), 2)
+    G = tw.f2_add(B, Fv)
+    Y3 = tw.f2_sub(cfg.sqr2(G), tw.f2_scale(cfg.sqr2(E), 12))
+    Z3 = tw.f2_scale(cfg.mul2(B, H), 4)
+    l0 = tw.f2_sub(B, E)
+    l1 = tw.f2_mul_fq(XX, px3n)
+    l4 = tw.f2_mul_fq(H, py)
+    return (X3, Y3, Z3), (l0, l1, l4)
+
+
+def t_add(cfg, Tp, Qa, px, py):
+    """Chord step T + Q (Q affine).  Mixed addition:
+      th = Y - yq Z, la = X - xq Z, C = th^2, D = la^2, E = la D, Fz = Z C,
+      G = X D, H = E + Fz - 2G, X3 = la H, Y3 = th (G - H) - E Y, Z3 = Z E
+    line: l0 = th xq - la yq, l1 = -th px, l4 = la py"""
+    X, Y, Z = Tp
+    xq, yq = Qa
+    th = tw.f2_mat(tw.f2_sub(Y, cfg.mul2(yq, Z)))
+    la = tw.f2_mat(tw.f2_sub(X, cfg.mul2(xq, Z)))
+    Cc = cfg.sqr2(th)
+    D = cfg.sqr2(la)
+    E = cfg.mul2(la, D)
+    Fz = cfg.mul2(Z, Cc)
+    G = cfg.mul2(X, D)
+    H = tw.f2_mat(tw.f2_sub(tw.f2_add(E, Fz), tw.f2_scale(G, 2)))
+    X3 = cfg.mul2(la, H)
+    Y3 = tw.f2_sub(cfg.mul2(th, tw.f2_sub(G, H)), cfg.mul2(E, Y))
+    Z3 = cfg.mul2(Z, E)
+    l0 = tw.f2_sub(cfg.mul2(th, xq), cfg.mul2(la, yq))
+    l1 = tw.f2_neg(tw.f2_mul_fq(th, px))
+    l4 = tw.f2_mul_fq(la, py)
+    return (X3, Y3, Z3), (l0, l1, l4)
+
+
+def emit_tstep(b, cfg, Tp, Qa, px, py, px3n, with_add):
+    T2, ld = t_double(cfg, Tp, px3n, py)
+    la = None
+    if with_add:
+        T2 = tuple(tw.f2_mat(c) for c in T2)
+        T2, la = t_add(cfg, T2, Qa, px, py)
+    out2(b, T2[0], TX), out2(b, T2[1], TY), out2(b, T2[2], TZ)
+    for i, c in enumerate(ld):
+        out2(b, c, LD + 2 * i)
+    if la is not None:
+        for i, c in enumerate(la):
+            out2(b, c, LA + 2 * i)
+
+
+def seg_init(cfg, first_add):
+    """Raw inputs -> Montgomery; T = Q, F = 1; first tangent(+chord) step."""
+    b = Builder("init")
+    r2 = b.inp(C(C_R2))
+    one = b.inp(C(C_ONE))
+    px = (b.inp(T(PX)) * r2).mat()
+    py = (b.inp(T(PY)) * r2).mat()
+    q = [(b.inp(T(QX0 + i)) * r2).mat() for i in range(4)]
+    b.out(px, T(PX)), b.out(py, T(PY))
+    for i in range(4):
+        b.out(q[i], T(QX0 + i))
+    px3n = (px * -3).mat()
+    b.out(px3n, T(NPX3))
+    b.out(one, T(F))
+    zero = b.inp(C(C_ZERO))
+    for i in range(1, 12):
+        b.out(zero, T(F + i))
+    Tp = ((q[0], q[1]), (q[2], q[3]), (one, b.zero()))
+    Qa = ((q[0], q[1]), (q[2], q[3]))
+    # Z = (1, 0): products with the zero imaginary part vanish at trace time
+    T2, ld = t_double(cfg, Tp, px3n, py)
+    la = None
+    if first_add:
+        T2 = tuple(tw.f2_mat(c) for c in T2)
+        T2, la = t_add(cfg, T2, Qa, px, py)
+    _out_t(b, T2, ld, la, zero)
+    return b
+
+
+def _out2z(b, e, off, zero):
+    b.out(e[0] if not e[0].is_zero() else zero, T(off))
+    b.out(e[1] if not e[1].is_zero() else zero, T(off + 1))
+
+
+def _out_t(b, T2, ld, la, zero):
+    _out2z(b, T2[0], TX, zero), _out2z(b, T2[1], TY, zero), _out2z(b, T2[2], TZ, zero)
+    for i, c in enumerate(ld):
+        _out2z(b, c, LD + 2 * i, zero)
+    if la is not None:
+        for i, c in enumerate(la):
+            _out2z(b, c, LA + 2 * i, zero)
+
+
+def seg_body(cfg, cur_add, nxt):
+    """One pipelined Miller iteration:
+         f <- f^2 * LD (* LA if cur_add)          [lines of the current step]
+         (T, LD, LA) <- next step of the T chain  [nxt: 0 tangent, 1 tangent+chord,
+                                                   2 nothing (last iteration)]"""
+    b = Builder("body_%d%d" % (cur_add, nxt))
+    f = in12(b, SEL_TEAM, F)
+    ld = [in2(b, LD + 2 * i) for i in range(3)]
+    f = tw.f12_sqr(cfg, f)
+    f = tw.f12_mul_by_014(cfg, f, *ld)
+    if cur_add:
+        la = [in2(b, LA + 2 * i) for i in range(3)]
+        f = tw.f12_mul_by_014(cfg, f, *la)
+    out12(b, f, SEL_TEAM, F)
+    if nxt != 2:
+        zero = b.inp(C(C_ZERO))
+        Tp = (in2(b, TX), in2(b, TY), in2(b, TZ))
+        Qa = (in2(b, QX0), in2(b, QY0))
+        px, py, px3n = b.inp(T(PX)), b.inp(T(PY)), b.inp(T(NPX3))
+        T2, ldn = t_double(cfg, Tp, px3n, py)
+        lan = None
+        if nxt == 1:
+            T2 = tuple(tw.f2_mat(c) for c in T2)
+            T2, lan = t_add(cfg, T2, Qa, px, py)
+        _out_t(b, T2, ldn, lan, zero)
+    return b
+
+
+def miller_script():
+    """[(segment name)] for the whole loop.  Step p (p = 62 .. 0) multiplies by
+    the chord line iff bit p of |x| is set (fields_t.py:1104)."""
+    bits = [(NX >> p) & 1 for p in range(62, -1, -1)]
+    script = ["init"]
+    for k, bit in enumerate(bits):
+        nxt = 2 if k + 1 == len(bits) else bits[k + 1]
+        script.append("body_%d%d" % (bit, nxt))
+    return script, bits[0]
+
+
+# ------------------------------------------- Fq12 register machine pieces --
+def seg_mul_ip(cfg):
+    b = Builder("mul_ip")                 # R0 <- R0 * R1
+    x, y = in12(b, SEL_R0), in12(b, SEL_R1)
+    out12(b, tw.f12_mul(cfg, x, y), SEL_R0)
+    return b
+
+
+def seg_mul3(cfg):
+    b = Builder("mul3")                   # R0 <- R1 * R2   (R0 distinct from R1, R2)
+    x, y = in12(b, SEL_R1), in12(b, SEL_R2)
+    out12(b, tw.f12_mul(cfg, x, y), SEL_R0)
+    return b
+
+
+def seg_cyc_sqr_ip(cfg):
+    b = Builder("cyc_sqr_ip")             # R0 <- R0^2 (cyclotomic subgroup only)
+    x = in12(b, SEL_R0)
+    out12(b, tw.f12_cyclo_sqr(cfg, x), SEL_R0)
+    return b
+
+
+def seg_copy():
+    b = Builder("copy")                   # R0 <- R1
+    x = in12(b, SEL_R1)
+    out12(b, x, SEL_R0)
+    return b
+
+
+def seg_conj():
+    b = Builder("conj")                   # R0 <- conj(R1)
+    x = in12(b, SEL_R1)
+    out12(b, tw.f12_conj(x), SEL_R0)
+    return b
+
+
+def seg_frob(cfg, i):
+    b = Builder("frob%d" % i)             # R0 <- R1^(q^i)
+    x = in12(b, SEL_R1)
+
+    def gam(j):
+        k = C_GAM + ((i - 1) * 5 + (j - 1)) * 2
+        return (b.inp(C(k)), b.inp(C(k + 1)))
+    zero = b.inp(C(C_ZERO))
+    y = tw.f12_frob(cfg, x, i, gam)
+    for n, e in enumerate(tw.flat12(y)):
+        b.out(e if not e.is_zero() else zero, ref(SEL_R0, n))
+    return b
+
+
+def seg_inv12(cfg):
+    b = Builder("inv12")                  # R0 <- R1^-1   (0 -> 0)
+    x = in12(b, SEL_R1)
+    out12(b, tw.f12_inv(cfg, x), SEL_R0)
+    return b
+
+
+def seg_from_mont():
+    b = Builder("from_mont")              # R0 <- canonical (non-Montgomery) R1
+    raw1 = b.inp(C(C_RAW1))
+    for i in range(12):
+        b.out(b.inp(ref(SEL_R1, i)) * raw1, ref(SEL_R0, i))
+    return b
+
+
+def seg_to_mont():
+    b = Builder("to_mont")                # R0 <- Montgomery form of raw R1
+    r2 = b.inp(C(C_R2))
+    for i in range(12):
+        b.out(b.inp(ref(SEL_R1, i)) * r2, ref(SEL_R0, i))
+    return b
+
+
+# ---------------------------------------------------- final exponentiation --
+def final_exp_script():
+    """Register-machine script: list of (segment, r0, r1, r2) with register
+    numbers; input and output in register 0.  Registers 1..5 are scratch.
+
+    easy:  t = conj(f) * f^-1 ;  t = frob2(t) * t
+    hard:  y = t^E,  E = ((x-1)^2/3)(x+q)(x^2+q^2-1) + 1,  x = -|x|:
+       a = t^e1 ; e1 = (|x|+1)/3                [(x-1)/3 = -e1]
+       a = a^(|x|+1) = a^|x| * a                [now t^((x-1)^2/3)]
+       b = conj(a^|x|) * frob1(a)               [a^(x+q)]
+       c = (b^|x|)^|x| * frob2(b) * conj(b)     [b^(x^2+q^2-1)]
+       y = c * t
+    """
+    S = []
+    e1 = (NX + 1) // 3
+    assert (NX + 1) % 3 == 0
+
+    def op(name, r0=0, r1=0, r2=0):
+        S.append((name, r0, r1, r2))
+
+    def pow_to(dst, src, e, tmp):
+        """dst <- src^e by left-to-right square-and-multiply (src preserved;
+        dst != src)."""
+        op("copy", dst, src)
+        for bit in range(e.bit_length() - 2, -1, -1):
+            op("cyc_sqr_ip", dst)
+            if (e >> bit) & 1:
+                op("mul_ip", dst, src)
+    # easy part
+    op("inv12", 1, 0)           # r1 = f^-1
+    op("conj", 2, 0)            # r2 = conj(f)
+    op("mul_ip", 2, 1)          # r2 = f^(q^6-1)
+    op("frob2", 1, 2)           # r1 = r2^(q^2)
+    op("mul_ip", 1, 2)          # r1 = t   (cyclotomic from here on)
+    # hard part
+    pow_to(2, 1, e1, None)      # r2 = t^e1
+    pow_to(3, 2, NX, None)      # r3 = r2^|x|
+    op("mul_ip", 3, 2)          # r3 = a = t^((x-1)^2/3)
+    pow_to(2, 3, NX, None)      # r2 = a^|x|
+    op("conj", 4, 2)            # r4 = a^x
+    op("frob1", 2, 3)           # r2 = a^q
+    op("mul_ip", 2, 4)          # r2 = b = a^(x+q)
+    pow_to(3, 2, NX, None)      # r3 = b^|x|
+    pow_to(4, 3, NX, None)      # r4 = b^(x^2)
+    op("frob2", 3, 2)           # r3 = b^(q^2)
+    op("mul_ip", 4, 3)
+    op("conj", 3, 2)            # r3 = b^-1
+    op("mul_ip", 4, 3)          # r4 = c
+    op("mul_ip", 4, 1)          # r4 = c * t
+    op("copy", 0, 4)
+    return S
+
+
+# ------------------------------------------------------------- build all ----
+def build_all(cfg=None, verbose=False):
+    cfg = cfg or tw.Cfg()
+    script, first_add = miller_script()
+    builders = [seg_init(cfg, first_add)]
+    for name in sorted(set(script[1:])):
+        builders.append(seg_body(cfg, int(name[5]), int(name[6])))
+    builders += [seg_mul_ip(cfg), seg_mul3(cfg), seg_cyc_sqr_ip(cfg), seg_copy(), seg_conj(),
+                 seg_frob(cfg, 1), seg_frob(cfg, 2), seg_frob(cfg, 3), seg_inv12(cfg),
+                 seg_from_mont(), seg_to_mont()]
+    segs = {}
+    for b in builders:
+        segs[b.name] = schedule(b, temp_base=TEMP0, verbose=verbose)
+    return segs
