@@ -1,0 +1,79 @@
+/*
+ * blsgpu.h -- C ABI of the MI355X (gfx950) BLS12-381 multi-pairing engine.
+ *
+ * Drop-in boundary: this library replaces the reference's only native
+ * component for the aggregate-verify path, the Cython/GMP module
+ * bls_py.fields_t_c (extmod/bls_py/fields_t_c.pyx), whose functions shadow the
+ * pure-Python ones of bls_py/fields_t.py at import (fields_t.py:1218-1265).
+ * Each entry point names the reference function it stands in for.
+ *
+ * Byte conventions = the reference's own serialisation:
+ *   Fq    48-byte big-endian canonical residue           (fields.py:87-88)
+ *   Fq12  12 x Fq in flat "ZT" order, 576 bytes          (fields.py:624-629, 273-278)
+ *   G1    affine x || y, 96 bytes    -- the (x, y) of fq_ate_pairing_multi's Ps
+ *   G2    affine x.c0 || x.c1 || y.c0 || y.c1, 192 bytes -- the ((x0,x1),(y0,y1)) of Qs
+ * Infinity is the reference's coordinate encoding (0,0) (fields_t.py:609-622).
+ *
+ * All functions return 0 on success or a negative errno-style code;
+ * blsgpu_last_error() describes the last failure on the calling thread.
+ * Buffers are caller-allocated; nothing owned by the library crosses the ABI
+ * except the opaque context.  A context may be used from one thread at a time.
+ */
+#ifndef BLSGPU_H
+#define BLSGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLSGPU_FQ_BYTES 48
+#define BLSGPU_G1_BYTES 96
+#define BLSGPU_G2_BYTES 192
+#define BLSGPU_FQ12_BYTES 576
+#define BLSGPU_PARTIAL_WORDS 144   /* one Fq12 in Montgomery limb form, uint32 */
+
+typedef struct blsgpu_ctx blsgpu_ctx;
+
+/* Library / table identification string (static storage). */
+const char *blsgpu_version(void);
+const char *blsgpu_last_error(void);
+
+/* Create a context on HIP device `device` (uploads the schedule tables).
+ * Fails with -ENODEV (-19) when no gfx950-class GPU is usable: there is no CPU
+ * fallback in this library. */
+int blsgpu_ctx_create(int device, blsgpu_ctx **out);
+void blsgpu_ctx_destroy(blsgpu_ctx *ctx);
+/* Pre-size the per-context workspace for batches of up to max_pairs pairs. */
+int blsgpu_ctx_reserve(blsgpu_ctx *ctx, size_t max_pairs);
+
+/* fq_ate_pairing_multi(Ps, Qs) -- fields_t.py:1114-1121 / fields_t_c.pyx:2333-2391.
+ * Host buffers in, 576 result bytes out; synchronous.  n == 0 returns one. */
+int blsgpu_pairing_multi(blsgpu_ctx *ctx, const uint8_t *g1, const uint8_t *g2,
+                         size_t n, uint8_t out[BLSGPU_FQ12_BYTES]);
+
+/* Same computation on device-resident buffers, enqueued on `stream`
+ * (a hipStream_t, or NULL for the default stream); asynchronous.
+ * d_out receives 576 bytes. */
+int blsgpu_pairing_multi_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2,
+                             size_t n, void *d_out, void *stream);
+
+/* Sharded form (one rank per GPU).  Step 1: the product of the n Miller-loop
+ * values of this shard (fq_miller_loop, fields_t.py:1091-1111, folded with
+ * fq12_mul as in :1119-1120) as ONE partial of BLSGPU_PARTIAL_WORDS uint32.
+ * Step 2, after the partials of all ranks were gathered: their product and the
+ * final exponentiation (fq12_final_exp, fields_t.py:1124-1128) -> 576 bytes. */
+int blsgpu_miller_product_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2,
+                              size_t n, void *d_partial, void *stream);
+int blsgpu_final_exp_product_dev(blsgpu_ctx *ctx, const void *d_partials, size_t m,
+                                 void *d_out, void *stream);
+
+/* fq12_final_exp(t) on a host element (fields_t.py:1124-1128). */
+int blsgpu_final_exp(blsgpu_ctx *ctx, const uint8_t in[BLSGPU_FQ12_BYTES],
+                     uint8_t out[BLSGPU_FQ12_BYTES]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

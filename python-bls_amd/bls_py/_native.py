@@ -1,0 +1,127 @@
+"""ctypes binding of libblsgpu.so (include/blsgpu.h) -- the HIP engine.
+
+This is the product's only compute back-end for the pairing path.  There is no
+CPU fallback: when the library or a GPU is missing, `engine()` raises.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libblsgpu.so")
+
+SYMBOLS = (
+    "blsgpu_version", "blsgpu_last_error", "blsgpu_ctx_create", "blsgpu_ctx_destroy",
+    "blsgpu_ctx_reserve", "blsgpu_pairing_multi", "blsgpu_pairing_multi_dev",
+    "blsgpu_miller_product_dev", "blsgpu_final_exp_product_dev", "blsgpu_final_exp",
+)
+
+_lib = None
+_lock = threading.Lock()
+
+
+class BlsGpuError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libblsgpu.so and declare the prototypes (no GPU call is made)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        p = path or os.environ.get("BLSGPU_LIBRARY", _LIB_PATH)
+        if not os.path.exists(p):
+            raise BlsGpuError("libblsgpu.so not found at %s -- run __graft_entry__.build() "
+                              "(there is no CPU fallback)" % p)
+        L = ctypes.CDLL(p)
+        vp, sz, cp = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p
+        L.blsgpu_version.restype = cp
+        L.blsgpu_last_error.restype = cp
+        L.blsgpu_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.blsgpu_ctx_destroy.argtypes = [vp]
+        L.blsgpu_ctx_destroy.restype = None
+        L.blsgpu_ctx_reserve.argtypes = [vp, sz]
+        L.blsgpu_pairing_multi.argtypes = [vp, cp, cp, sz, cp]
+        L.blsgpu_pairing_multi_dev.argtypes = [vp, vp, vp, sz, vp, vp]
+        L.blsgpu_miller_product_dev.argtypes = [vp, vp, vp, sz, vp, vp]
+        L.blsgpu_final_exp_product_dev.argtypes = [vp, vp, sz, vp, vp]
+        L.blsgpu_final_exp.argtypes = [vp, cp, cp]
+        _lib = L
+        return L
+
+
+class Engine:
+    """One blsgpu context on one device."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.blsgpu_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise BlsGpuError("blsgpu_ctx_create(%d) failed (%d): %s"
+                              % (device, rc, self.lib.blsgpu_last_error().decode()))
+        self.h = h
+        self.device = device
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise BlsGpuError("%s failed (%d): %s" % (what, rc, self.lib.blsgpu_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.blsgpu_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def version(self):
+        return self.lib.blsgpu_version().decode()
+
+    def reserve(self, max_pairs):
+        self._check(self.lib.blsgpu_ctx_reserve(self.h, max_pairs), "blsgpu_ctx_reserve")
+
+    def pairing_multi(self, g1: bytes, g2: bytes, n: int) -> bytes:
+        if len(g1) != 96 * n or len(g2) != 192 * n:
+            raise ValueError("g1/g2 length does not match n")
+        out = ctypes.create_string_buffer(576)
+        self._check(self.lib.blsgpu_pairing_multi(self.h, g1, g2, n, out), "blsgpu_pairing_multi")
+        return out.raw
+
+    def final_exp(self, x: bytes) -> bytes:
+        if len(x) != 576:
+            raise ValueError("Fq12 must be 576 bytes")
+        out = ctypes.create_string_buffer(576)
+        self._check(self.lib.blsgpu_final_exp(self.h, x, out), "blsgpu_final_exp")
+        return out.raw
+
+    # device-pointer forms (integers: tensor.data_ptr(), stream.cuda_stream)
+    def pairing_multi_dev(self, d_g1, d_g2, n, d_out, stream=0):
+        self._check(self.lib.blsgpu_pairing_multi_dev(self.h, d_g1, d_g2, n, d_out, stream),
+                    "blsgpu_pairing_multi_dev")
+
+    def miller_product_dev(self, d_g1, d_g2, n, d_partial, stream=0):
+        self._check(self.lib.blsgpu_miller_product_dev(self.h, d_g1, d_g2, n, d_partial, stream),
+                    "blsgpu_miller_product_dev")
+
+    def final_exp_product_dev(self, d_partials, m, d_out, stream=0):
+        self._check(self.lib.blsgpu_final_exp_product_dev(self.h, d_partials, m, d_out, stream),
+                    "blsgpu_final_exp_product_dev")
+
+
+_engines = {}
+
+
+def engine(device=0):
+    """Process-wide engine for `device`; raises BlsGpuError if unavailable."""
+    with _lock:
+        e = _engines.get(device)
+    if e is None:
+        e = Engine(device)
+        with _lock:
+            _engines[device] = e
+    return e

@@ -1,0 +1,292 @@
+// blsgpu_api.hip -- host side of the C ABI declared in include/blsgpu.h.
+// Pure HIP runtime: no torch types, no CPU fallback.  If no GPU is usable the
+// context cannot be created and every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <errno.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/blsgpu.h"
+#include "blsgpu_kernels.hip"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(-EIO, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+constexpr int MILLER_WAVES = 4;        // teams (pairings) per workgroup in k_miller
+constexpr int REDUCE_WAVES = 8;        // teams per workgroup in k_reduce
+constexpr int REDUCE_PER_BLOCK = 64;   // partials folded by one k_reduce block
+
+}  // namespace
+
+struct blsgpu_ctx {
+    int device = 0;
+    blsgpu::VmTables tabs{};
+    void* d_tables = nullptr;          // one allocation holding every table
+    uint32_t* d_part[2] = {nullptr, nullptr};
+    size_t part_cap = 0;               // capacity of each partial buffer, in partials
+    void* d_io = nullptr;              // staging for the host-buffer entry points
+    size_t io_cap = 0;
+    uint32_t* d_out = nullptr;         // 576-byte result staging
+};
+
+static size_t n_blocks_miller(size_t n) { return (n + MILLER_WAVES - 1) / MILLER_WAVES; }
+
+static int ensure_workspace(blsgpu_ctx* c, size_t max_pairs) {
+    size_t need = n_blocks_miller(max_pairs) + 1;
+    if (need > c->part_cap) {
+        for (int i = 0; i < 2; i++) {
+            if (c->d_part[i]) (void)hipFree(c->d_part[i]);
+            c->d_part[i] = nullptr;
+        }
+        c->part_cap = 0;
+        for (int i = 0; i < 2; i++) HIP_TRY(hipMalloc((void**)&c->d_part[i], need * 144 * sizeof(uint32_t)));
+        c->part_cap = need;
+    }
+    return 0;
+}
+
+#define BLSGPU_EXPORT __attribute__((visibility("default")))
+
+extern "C" {
+
+BLSGPU_EXPORT const char* blsgpu_version(void) { return "blsgpu/1 gfx950 vm-tables " BLSVM_TABLE_HASH; }
+BLSGPU_EXPORT const char* blsgpu_last_error(void) { return g_err.c_str(); }
+
+BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
+    if (!out) return fail(-EINVAL, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(-ENODEV, std::string("no HIP device available (") + hipGetErrorString(e) +
+                                 "); blsgpu has no CPU fallback");
+    if (device < 0 || device >= count) return fail(-EINVAL, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    blsgpu_ctx* c = new blsgpu_ctx();
+    c->device = device;
+    // pack all tables into one device allocation (16-byte aligned pieces)
+    auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
+    size_t o_segs = 0;
+    size_t o_rounds = o_segs + al(sizeof(BLSVM_SEGS));
+    size_t o_data = o_rounds + al(sizeof(BLSVM_ROUNDS));
+    size_t o_ms = o_data + al(sizeof(BLSVM_DATA));
+    size_t o_fs = o_ms + al(sizeof(BLSVM_MILLER_SCRIPT));
+    size_t o_c = o_fs + al(sizeof(BLSVM_FEXP_SCRIPT));
+    size_t total = o_c + al(sizeof(BLSVM_CONSTS));
+    if (hipMalloc(&c->d_tables, total) != hipSuccess) {
+        delete c;
+        return fail(-ENOMEM, "hipMalloc(tables) failed");
+    }
+    char* base = (char*)c->d_tables;
+    struct { size_t off; const void* src; size_t len; } parts[] = {
+        {o_segs, BLSVM_SEGS, sizeof(BLSVM_SEGS)},       {o_rounds, BLSVM_ROUNDS, sizeof(BLSVM_ROUNDS)},
+        {o_data, BLSVM_DATA, sizeof(BLSVM_DATA)},       {o_ms, BLSVM_MILLER_SCRIPT, sizeof(BLSVM_MILLER_SCRIPT)},
+        {o_fs, BLSVM_FEXP_SCRIPT, sizeof(BLSVM_FEXP_SCRIPT)}, {o_c, BLSVM_CONSTS, sizeof(BLSVM_CONSTS)}};
+    for (auto& p : parts) {
+        if (hipMemcpy(base + p.off, p.src, p.len, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(c->d_tables);
+            delete c;
+            return fail(-EIO, "hipMemcpy(tables) failed");
+        }
+    }
+    c->tabs.segs = (const uint2*)(base + o_segs);
+    c->tabs.rounds = (const uint2*)(base + o_rounds);
+    c->tabs.data = (const uint16_t*)(base + o_data);
+    c->tabs.mscript = (const uint16_t*)(base + o_ms);
+    c->tabs.fscript = (const uint16_t*)(base + o_fs);
+    c->tabs.consts = (const uint32_t*)(base + o_c);
+    if (hipMalloc((void**)&c->d_out, BLSGPU_FQ12_BYTES) != hipSuccess) {
+        (void)hipFree(c->d_tables);
+        delete c;
+        return fail(-ENOMEM, "hipMalloc(out) failed");
+    }
+    // the kernels need more than the default 64 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_miller, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              MILLER_WAVES * blsgpu::TEAM_BYTES);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              REDUCE_WAVES * blsgpu::TEAM_BYTES);
+    int rc = ensure_workspace(c, 4096);
+    if (rc) {
+        blsgpu_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+BLSGPU_EXPORT void blsgpu_ctx_destroy(blsgpu_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    for (int i = 0; i < 2; i++)
+        if (c->d_part[i]) (void)hipFree(c->d_part[i]);
+    if (c->d_io) (void)hipFree(c->d_io);
+    if (c->d_out) (void)hipFree(c->d_out);
+    delete c;
+}
+
+BLSGPU_EXPORT int blsgpu_ctx_reserve(blsgpu_ctx* c, size_t max_pairs) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    return ensure_workspace(c, max_pairs);
+}
+
+// fold m partials (in d_in) down to one; the last launch optionally applies the
+// final exponentiation and writes bytes to d_out_bytes.  d_in is not modified
+// unless it is one of the context's ping-pong buffers.
+static int reduce_chain(blsgpu_ctx* c, const uint32_t* d_in, size_t m, bool do_final, uint32_t* d_out_partial,
+                        void* d_out_bytes, hipStream_t st) {
+    const uint32_t* src = d_in;
+    int pp = (d_in == c->d_part[0]) ? 1 : 0;
+    size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
+    while (true) {
+        size_t blocks = (m + REDUCE_PER_BLOCK - 1) / REDUCE_PER_BLOCK;
+        if (blocks == 0) blocks = 1;
+        bool last = blocks == 1;
+        uint32_t* dst = last ? d_out_partial : c->d_part[pp];
+        if (!last && blocks > c->part_cap) return fail(-ENOMEM, "workspace too small; call blsgpu_ctx_reserve");
+        hipLaunchKernelGGL(blsgpu::k_reduce, dim3((unsigned)blocks), dim3(REDUCE_WAVES * 64), lds, st, c->tabs, src,
+                           (uint32_t)m, (uint32_t)REDUCE_PER_BLOCK, dst, (uint32_t)(last && do_final ? 1 : 0),
+                           (uint32_t*)d_out_bytes);
+        HIP_TRY(hipGetLastError());
+        if (last) break;
+        src = dst;
+        m = blocks;
+        pp ^= 1;
+    }
+    return 0;
+}
+
+static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t n, uint32_t* d_partials,
+                         hipStream_t st) {
+    size_t blocks = n_blocks_miller(n);
+    size_t lds = (size_t)MILLER_WAVES * blsgpu::TEAM_BYTES;
+    hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)blocks), dim3(MILLER_WAVES * 64), lds, st, c->tabs,
+                       (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, d_partials);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+BLSGPU_EXPORT int blsgpu_miller_product_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t n, void* d_partial,
+                              void* stream) {
+    if (!c || !d_partial) return fail(-EINVAL, "NULL argument");
+    if (n > 0 && (!d_g1 || !d_g2)) return fail(-EINVAL, "NULL point buffer");
+    if (n > 0xFFFFFFF0ull) return fail(-EINVAL, "n too large");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (n_blocks_miller(n) + 1 > c->part_cap) {
+        int rc = ensure_workspace(c, n);
+        if (rc) return rc;
+    }
+    if (n > 0) {
+        int rc = launch_miller(c, d_g1, d_g2, n, c->d_part[0], st);
+        if (rc) return rc;
+    }
+    return reduce_chain(c, c->d_part[0], n_blocks_miller(n), false, (uint32_t*)d_partial, nullptr, st);
+}
+
+BLSGPU_EXPORT int blsgpu_final_exp_product_dev(blsgpu_ctx* c, const void* d_partials, size_t m, void* d_out, void* stream) {
+    if (!c || !d_out) return fail(-EINVAL, "NULL argument");
+    if (m > 0 && !d_partials) return fail(-EINVAL, "NULL partials");
+    HIP_TRY(hipSetDevice(c->device));
+    if ((m + REDUCE_PER_BLOCK - 1) / REDUCE_PER_BLOCK + 1 > c->part_cap) {
+        int rc = ensure_workspace(c, m * MILLER_WAVES);
+        if (rc) return rc;
+    }
+    return reduce_chain(c, (const uint32_t*)d_partials, m, true, nullptr, d_out, (hipStream_t)stream);
+}
+
+BLSGPU_EXPORT int blsgpu_pairing_multi_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t n, void* d_out,
+                             void* stream) {
+    if (!c || !d_out) return fail(-EINVAL, "NULL argument");
+    if (n > 0 && (!d_g1 || !d_g2)) return fail(-EINVAL, "NULL point buffer");
+    if (n > 0xFFFFFFF0ull) return fail(-EINVAL, "n too large");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (n_blocks_miller(n) + 1 > c->part_cap) {
+        int rc = ensure_workspace(c, n);
+        if (rc) return rc;
+    }
+    if (n > 0) {
+        int rc = launch_miller(c, d_g1, d_g2, n, c->d_part[0], st);
+        if (rc) return rc;
+    }
+    return reduce_chain(c, c->d_part[0], n_blocks_miller(n), true, nullptr, d_out, st);
+}
+
+BLSGPU_EXPORT int blsgpu_pairing_multi(blsgpu_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t out[576]) {
+    if (!c || !out) return fail(-EINVAL, "NULL argument");
+    if (n > 0 && (!g1 || !g2)) return fail(-EINVAL, "NULL point buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t need = n * (BLSGPU_G1_BYTES + BLSGPU_G2_BYTES);
+    if (need > c->io_cap) {
+        if (c->d_io) (void)hipFree(c->d_io);
+        c->d_io = nullptr;
+        c->io_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_io, need));
+        c->io_cap = need;
+    }
+    char* d1 = (char*)c->d_io;
+    char* d2 = d1 + n * BLSGPU_G1_BYTES;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(d1, g1, n * BLSGPU_G1_BYTES, hipMemcpyHostToDevice, 0));
+        HIP_TRY(hipMemcpyAsync(d2, g2, n * BLSGPU_G2_BYTES, hipMemcpyHostToDevice, 0));
+    }
+    int rc = blsgpu_pairing_multi_dev(c, d1, d2, n, c->d_out, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, c->d_out, BLSGPU_FQ12_BYTES, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// device kernel used by blsgpu_final_exp: bytes -> Montgomery partial
+namespace blsgpu {
+__global__ void k_bytes_to_partial(VmTables T, const uint32_t* __restrict__ in_bytes, uint32_t* __restrict__ out_partial) {
+    uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    team_init_consts(T, smem, lane);
+    for (uint32_t k = lane; k < 144; k += 64) {
+        uint32_t cidx = k / 12, w = k % 12;
+        smem[R1_DW + cidx * 12 + (11 - w)] = bswap32(in_bytes[k]);
+    }
+    wave_fence();
+    run_segment(T, BLSVM_SEG_TO_MONT_0_1, 0, lane);
+    for (uint32_t k = lane; k < 144; k += 64) out_partial[k] = smem[F_DW + k];
+}
+}  // namespace blsgpu
+
+BLSGPU_EXPORT int blsgpu_final_exp(blsgpu_ctx* c, const uint8_t in[576], uint8_t out[576]) {
+    if (!c || !in || !out) return fail(-EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->io_cap < 1024) {
+        if (c->d_io) (void)hipFree(c->d_io);
+        c->d_io = nullptr;
+        c->io_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_io, 4096));
+        c->io_cap = 4096;
+    }
+    HIP_TRY(hipMemcpy(c->d_io, in, 576, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(blsgpu::k_bytes_to_partial, dim3(1), dim3(64), blsgpu::TEAM_BYTES, 0, c->tabs,
+                       (const uint32_t*)c->d_io, c->d_part[1]);
+    HIP_TRY(hipGetLastError());
+    int rc = reduce_chain(c, c->d_part[1], 1, true, nullptr, c->d_out, 0);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, c->d_out, 576, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -19,18 +19,11 @@ from collections import defaultdict
 
 LANES = 64
 
-# slot reference = (selector << 11) | offset
-SEL_TEAM, SEL_CONST, SEL_R0, SEL_R1, SEL_R2, SEL_R3 = 0, 1, 2, 3, 4, 5
-OFF_BITS = 11
-OFF_MASK = (1 << OFF_BITS) - 1
-NOSLOT = 0x3FFF
+# A slot reference is simply the slot's index inside the team's scratchpad
+# (constants, named registers and temporaries all live there).
+NOSLOT = 0xFFFF
 
 UOP_ADD, UOP_SUB, UOP_DBL, UOP_NOP = 0, 1, 2, 3
-
-
-def ref(sel, off):
-    assert 0 <= off <= OFF_MASK and 0 <= sel < 8
-    return (sel << OFF_BITS) | off
 
 
 class V:
@@ -180,7 +173,7 @@ class Segment:
 def schedule(b, temp_base=0, lanes=LANES, verbose=False):
     """List-schedule builder b into rounds and allocate slots.
 
-    Returns a Segment.  Temps are allocated in the TEAM region from temp_base.
+    Returns a Segment.  Temporaries are allocated upwards from slot temp_base.
     """
     vals = b.vals
     live_out = {v.id for v, _ in b.outputs}
@@ -316,7 +309,7 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
                 else:
                     off = ntemp
                     ntemp += 1
-                chosen = ref(SEL_TEAM, temp_base + off)
+                chosen = temp_base + off
                 lu = last_use.get(v.id, ri)
                 if v.id in live_out:
                     lu = nrounds      # must survive until the final copy

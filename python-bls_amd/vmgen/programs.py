@@ -16,29 +16,33 @@ Algorithm (what the GPU runs) versus the reference (what it must equal):
   squarings.  The result is the identical field element, hence identical bytes.
 """
 from . import tower as tw
-from .core import (Builder, SEL_CONST, SEL_R0, SEL_R1, SEL_R2, SEL_TEAM, ref,
-                   schedule)
+from .core import Builder, schedule
 from .sim import Q, R, to_m
 
 NX = 0xd201000000010000                   # |x|  (fields_t.py:25)
 
 # ------------------------------------------------------------- memory map --
-# team region (one per wavefront / pairing), in 48-byte slots
-PX, PY = 0, 1
-QX0, QX1, QY0, QY1 = 2, 3, 4, 5
-TX, TY, TZ = 6, 8, 10                     # Fq2 each
-F = 12                                    # Fq12 accumulator (12 slots)
-LD = 24                                   # pending tangent line  l0,l1,l4 (6)
-LA = 30                                   # pending chord line    l0,l1,l4 (6)
-NPX3 = 36                                 # -3*px
-REG0 = 40                                 # Fq12 registers R[k] = REG0 + 12 k
-NREG = 6
-TEMP0 = REG0 + 12 * NREG                  # 112
-
-# constant region (shared by the workgroup)
+# One scratchpad per team (= wavefront = pairing), in 48-byte slots.
+# constants (copied in by the kernel at start-up)
 C_ZERO, C_ONE, C_R2, C_RAW1 = 0, 1, 2, 3
 C_GAM = 4                                 # gamma_i^j, i=1..3, j=1..5: Fq2 each
-NCONST = C_GAM + 3 * 5 * 2
+NCONST = C_GAM + 3 * 5 * 2                # 34
+# named values
+PX, PY = 34, 35
+QX0, QX1, QY0, QY1 = 36, 37, 38, 39
+TX, TY, TZ = 40, 42, 44                   # Fq2 each
+LD = 46                                   # pending tangent line  l0,l1,l4 (6)
+LA = 52                                   # pending chord line    l0,l1,l4 (6)
+NPX3 = 58                                 # -3*px
+REG0 = 60                                 # Fq12 registers R[k] = REG0 + 12 k
+NREG = 5
+F = REG0                                  # the Miller accumulator is register 0
+TEMP0 = REG0 + 12 * NREG                  # 120
+
+
+def reg(k):
+    assert 0 <= k < NREG
+    return REG0 + 12 * k
 
 
 def _fq2_pow(a, e):
@@ -72,11 +76,11 @@ def const_table():
 
 
 def T(off):
-    return ref(SEL_TEAM, off)
+    return off
 
 
 def C(off):
-    return ref(SEL_CONST, off)
+    return off
 
 
 def in2(b, off, name=None):
@@ -88,13 +92,13 @@ def out2(b, e, off):
     b.out(e[1], T(off + 1))
 
 
-def in12(b, sel, base=0):
-    return tw.unflat12([b.inp(ref(sel, base + i)) for i in range(12)])
+def in12(b, base):
+    return tw.unflat12([b.inp(base + i) for i in range(12)])
 
 
-def out12(b, x, sel, base=0):
+def out12(b, x, base, zero=None):
     for i, e in enumerate(tw.flat12(x)):
-        b.out(e, ref(sel, base + i))
+        b.out(e if not e.is_zero() else zero, base + i)
 
 
 # ------------------------------------------------------------ Miller loop --
@@ -152,20 +156,6 @@ def t_add(cfg, Tp, Qa, px, py):
     return (X3, Y3, Z3), (l0, l1, l4)
 
 
-def emit_tstep(b, cfg, Tp, Qa, px, py, px3n, with_add):
-    T2, ld = t_double(cfg, Tp, px3n, py)
-    la = None
-    if with_add:
-        T2 = tuple(tw.f2_mat(c) for c in T2)
-        T2, la = t_add(cfg, T2, Qa, px, py)
-    out2(b, T2[0], TX), out2(b, T2[1], TY), out2(b, T2[2], TZ)
-    for i, c in enumerate(ld):
-        out2(b, c, LD + 2 * i)
-    if la is not None:
-        for i, c in enumerate(la):
-            out2(b, c, LA + 2 * i)
-
-
 def seg_init(cfg, first_add):
     """Raw inputs -> Montgomery; T = Q, F = 1; first tangent(+chord) step."""
     b = Builder("init")
@@ -215,14 +205,14 @@ def seg_body(cfg, cur_add, nxt):
          (T, LD, LA) <- next step of the T chain  [nxt: 0 tangent, 1 tangent+chord,
                                                    2 nothing (last iteration)]"""
     b = Builder("body_%d%d" % (cur_add, nxt))
-    f = in12(b, SEL_TEAM, F)
+    f = in12(b, F)
     ld = [in2(b, LD + 2 * i) for i in range(3)]
     f = tw.f12_sqr(cfg, f)
     f = tw.f12_mul_by_014(cfg, f, *ld)
     if cur_add:
         la = [in2(b, LA + 2 * i) for i in range(3)]
         f = tw.f12_mul_by_014(cfg, f, *la)
-    out12(b, f, SEL_TEAM, F)
+    out12(b, f, F)
     if nxt != 2:
         zero = b.inp(C(C_ZERO))
         Tp = (in2(b, TX), in2(b, TY), in2(b, TZ))
@@ -249,142 +239,152 @@ def miller_script():
 
 
 # ------------------------------------------- Fq12 register machine pieces --
-def seg_mul_ip(cfg):
-    b = Builder("mul_ip")                 # R0 <- R0 * R1
-    x, y = in12(b, SEL_R0), in12(b, SEL_R1)
-    out12(b, tw.f12_mul(cfg, x, y), SEL_R0)
+# Segments are specialised per register tuple; names encode the operands.
+def seg_mul(cfg, d, a):
+    b = Builder("mul_%d_%d" % (d, a))     # R[d] <- R[d] * R[a]
+    x, y = in12(b, reg(d)), in12(b, reg(a))
+    out12(b, tw.f12_mul(cfg, x, y), reg(d))
     return b
 
 
-def seg_mul3(cfg):
-    b = Builder("mul3")                   # R0 <- R1 * R2   (R0 distinct from R1, R2)
-    x, y = in12(b, SEL_R1), in12(b, SEL_R2)
-    out12(b, tw.f12_mul(cfg, x, y), SEL_R0)
+def seg_cyc_sqr(cfg, d):
+    b = Builder("cyc_sqr_%d" % d)         # R[d] <- R[d]^2 (cyclotomic subgroup only)
+    out12(b, tw.f12_cyclo_sqr(cfg, in12(b, reg(d))), reg(d))
     return b
 
 
-def seg_cyc_sqr_ip(cfg):
-    b = Builder("cyc_sqr_ip")             # R0 <- R0^2 (cyclotomic subgroup only)
-    x = in12(b, SEL_R0)
-    out12(b, tw.f12_cyclo_sqr(cfg, x), SEL_R0)
+def seg_copy(d, a):
+    b = Builder("copy_%d_%d" % (d, a))    # R[d] <- R[a]
+    out12(b, in12(b, reg(a)), reg(d))
     return b
 
 
-def seg_copy():
-    b = Builder("copy")                   # R0 <- R1
-    x = in12(b, SEL_R1)
-    out12(b, x, SEL_R0)
+def seg_conj(d, a):
+    b = Builder("conj_%d_%d" % (d, a))    # R[d] <- conj(R[a])
+    out12(b, tw.f12_conj(in12(b, reg(a))), reg(d))
     return b
 
 
-def seg_conj():
-    b = Builder("conj")                   # R0 <- conj(R1)
-    x = in12(b, SEL_R1)
-    out12(b, tw.f12_conj(x), SEL_R0)
-    return b
-
-
-def seg_frob(cfg, i):
-    b = Builder("frob%d" % i)             # R0 <- R1^(q^i)
-    x = in12(b, SEL_R1)
+def seg_frob(cfg, i, d, a):
+    b = Builder("frob%d_%d_%d" % (i, d, a))   # R[d] <- R[a]^(q^i)
+    x = in12(b, reg(a))
 
     def gam(j):
         k = C_GAM + ((i - 1) * 5 + (j - 1)) * 2
         return (b.inp(C(k)), b.inp(C(k + 1)))
-    zero = b.inp(C(C_ZERO))
-    y = tw.f12_frob(cfg, x, i, gam)
-    for n, e in enumerate(tw.flat12(y)):
-        b.out(e if not e.is_zero() else zero, ref(SEL_R0, n))
+    out12(b, tw.f12_frob(cfg, x, i, gam), reg(d), zero=b.inp(C(C_ZERO)))
     return b
 
 
-def seg_inv12(cfg):
-    b = Builder("inv12")                  # R0 <- R1^-1   (0 -> 0)
-    x = in12(b, SEL_R1)
-    out12(b, tw.f12_inv(cfg, x), SEL_R0)
+def seg_inv12(cfg, d, a):
+    b = Builder("inv12_%d_%d" % (d, a))   # R[d] <- R[a]^-1   (0 -> 0)
+    out12(b, tw.f12_inv(cfg, in12(b, reg(a))), reg(d))
     return b
 
 
-def seg_from_mont():
-    b = Builder("from_mont")              # R0 <- canonical (non-Montgomery) R1
+def seg_from_mont(d, a):
+    b = Builder("from_mont_%d_%d" % (d, a))   # R[d] <- canonical (non-Montgomery) R[a]
     raw1 = b.inp(C(C_RAW1))
     for i in range(12):
-        b.out(b.inp(ref(SEL_R1, i)) * raw1, ref(SEL_R0, i))
+        b.out(b.inp(reg(a) + i) * raw1, reg(d) + i)
     return b
 
 
-def seg_to_mont():
-    b = Builder("to_mont")                # R0 <- Montgomery form of raw R1
+def seg_to_mont(d, a):
+    b = Builder("to_mont_%d_%d" % (d, a))     # R[d] <- Montgomery form of raw R[a]
     r2 = b.inp(C(C_R2))
     for i in range(12):
-        b.out(b.inp(ref(SEL_R1, i)) * r2, ref(SEL_R0, i))
+        b.out(b.inp(reg(a) + i) * r2, reg(d) + i)
     return b
+
+
+def seg_set_one(d):
+    b = Builder("set_one_%d" % d)         # R[d] <- 1
+    one, zero = b.inp(C(C_ONE)), b.inp(C(C_ZERO))
+    b.out(one, reg(d))
+    for i in range(1, 12):
+        b.out(zero, reg(d) + i)
+    return b
+
+
+SEG_FACTORY = {
+    "mul": lambda cfg, *r: seg_mul(cfg, *r),
+    "cyc_sqr": lambda cfg, *r: seg_cyc_sqr(cfg, *r),
+    "copy": lambda cfg, *r: seg_copy(*r),
+    "conj": lambda cfg, *r: seg_conj(*r),
+    "frob1": lambda cfg, *r: seg_frob(cfg, 1, *r),
+    "frob2": lambda cfg, *r: seg_frob(cfg, 2, *r),
+    "frob3": lambda cfg, *r: seg_frob(cfg, 3, *r),
+    "inv12": lambda cfg, *r: seg_inv12(cfg, *r),
+    "from_mont": lambda cfg, *r: seg_from_mont(*r),
+    "to_mont": lambda cfg, *r: seg_to_mont(*r),
+    "set_one": lambda cfg, *r: seg_set_one(*r),
+}
+
+
+def seg_by_name(cfg, name):
+    parts = name.split("_")
+    n = len(parts)
+    while n > 0 and parts[n - 1].isdigit():
+        n -= 1
+    return SEG_FACTORY["_".join(parts[:n])](cfg, *[int(p) for p in parts[n:]])
 
 
 # ---------------------------------------------------- final exponentiation --
 def final_exp_script():
-    """Register-machine script: list of (segment, r0, r1, r2) with register
-    numbers; input and output in register 0.  Registers 1..5 are scratch.
+    """Segment names, executed in order.  Input and output in register 0.
 
     easy:  t = conj(f) * f^-1 ;  t = frob2(t) * t
     hard:  y = t^E,  E = ((x-1)^2/3)(x+q)(x^2+q^2-1) + 1,  x = -|x|:
-       a = t^e1 ; e1 = (|x|+1)/3                [(x-1)/3 = -e1]
-       a = a^(|x|+1) = a^|x| * a                [now t^((x-1)^2/3)]
-       b = conj(a^|x|) * frob1(a)               [a^(x+q)]
-       c = (b^|x|)^|x| * frob2(b) * conj(b)     [b^(x^2+q^2-1)]
+       s = t^e1 ; e1 = (|x|+1)/3                [(x-1)/3 = -e1]
+       a = s^|x| * s                            [= t^((x-1)^2/3)]
+       b = conj(a^|x|) * frob1(a)               [= a^(x+q)]
+       c = (b^|x|)^|x| * frob2(b) * conj(b)     [= b^(x^2+q^2-1)]
        y = c * t
+    Register use: r0 accumulator, r1 power base / second operand, r2..r4 saves.
     """
     S = []
     e1 = (NX + 1) // 3
     assert (NX + 1) % 3 == 0
 
-    def op(name, r0=0, r1=0, r2=0):
-        S.append((name, r0, r1, r2))
-
-    def pow_to(dst, src, e, tmp):
-        """dst <- src^e by left-to-right square-and-multiply (src preserved;
-        dst != src)."""
-        op("copy", dst, src)
+    def pow_acc(e):
+        """r0 <- r0^e (cyclotomic), clobbers r1."""
+        S.append("copy_1_0")
         for bit in range(e.bit_length() - 2, -1, -1):
-            op("cyc_sqr_ip", dst)
+            S.append("cyc_sqr_0")
             if (e >> bit) & 1:
-                op("mul_ip", dst, src)
+                S.append("mul_0_1")
     # easy part
-    op("inv12", 1, 0)           # r1 = f^-1
-    op("conj", 2, 0)            # r2 = conj(f)
-    op("mul_ip", 2, 1)          # r2 = f^(q^6-1)
-    op("frob2", 1, 2)           # r1 = r2^(q^2)
-    op("mul_ip", 1, 2)          # r1 = t   (cyclotomic from here on)
+    S += ["inv12_2_0", "conj_1_0", "mul_1_2",      # r1 = f^(q^6-1)
+          "frob2_0_1", "mul_0_1",                  # r0 = t (cyclotomic from here on)
+          "copy_3_0"]                              # r3 = t
     # hard part
-    pow_to(2, 1, e1, None)      # r2 = t^e1
-    pow_to(3, 2, NX, None)      # r3 = r2^|x|
-    op("mul_ip", 3, 2)          # r3 = a = t^((x-1)^2/3)
-    pow_to(2, 3, NX, None)      # r2 = a^|x|
-    op("conj", 4, 2)            # r4 = a^x
-    op("frob1", 2, 3)           # r2 = a^q
-    op("mul_ip", 2, 4)          # r2 = b = a^(x+q)
-    pow_to(3, 2, NX, None)      # r3 = b^|x|
-    pow_to(4, 3, NX, None)      # r4 = b^(x^2)
-    op("frob2", 3, 2)           # r3 = b^(q^2)
-    op("mul_ip", 4, 3)
-    op("conj", 3, 2)            # r3 = b^-1
-    op("mul_ip", 4, 3)          # r4 = c
-    op("mul_ip", 4, 1)          # r4 = c * t
-    op("copy", 0, 4)
+    pow_acc(e1)                                    # r0 = s = t^e1, r1 = t
+    pow_acc(NX)                                    # r0 = s^|x|,   r1 = s
+    S += ["mul_0_1", "copy_4_0"]                   # r0 = r4 = a
+    pow_acc(NX)                                    # r0 = a^|x|
+    S += ["conj_0_0", "frob1_1_4", "mul_0_1",      # r0 = b = a^x * a^q
+          "copy_4_0"]                              # r4 = b
+    pow_acc(NX)
+    pow_acc(NX)                                    # r0 = b^(x^2)
+    S += ["frob2_1_4", "mul_0_1", "conj_1_4", "mul_0_1",   # r0 = c
+          "mul_0_3"]                               # r0 = c * t
     return S
 
 
 # ------------------------------------------------------------- build all ----
 def build_all(cfg=None, verbose=False):
+    """Returns (segments by name, miller script, final-exp script)."""
     cfg = cfg or tw.Cfg()
-    script, first_add = miller_script()
+    mscript, first_add = miller_script()
     builders = [seg_init(cfg, first_add)]
-    for name in sorted(set(script[1:])):
+    for name in sorted(set(mscript[1:])):
         builders.append(seg_body(cfg, int(name[5]), int(name[6])))
-    builders += [seg_mul_ip(cfg), seg_mul3(cfg), seg_cyc_sqr_ip(cfg), seg_copy(), seg_conj(),
-                 seg_frob(cfg, 1), seg_frob(cfg, 2), seg_frob(cfg, 3), seg_inv12(cfg),
-                 seg_from_mont(), seg_to_mont()]
+    fscript = final_exp_script()
+    extra = ["from_mont_1_0", "to_mont_0_1", "to_mont_1_1", "set_one_0", "mul_0_1", "copy_0_1"]
+    for name in sorted(set(fscript + extra)):
+        builders.append(seg_by_name(cfg, name))
     segs = {}
     for b in builders:
         segs[b.name] = schedule(b, temp_base=TEMP0, verbose=verbose)
-    return segs
+    return segs, mscript, fscript
