@@ -5,6 +5,7 @@ CPU fallback: when the library or a GPU is missing, `engine()` raises.
 """
 import ctypes
 import os
+import sys
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -31,6 +32,15 @@ def load_library(path=None):
         if _lib is not None:
             return _lib
         p = path or os.environ.get("BLSGPU_LIBRARY", _LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime.  If torch is going to be
+        # used in this process (device buffers, streams, RCCL) it has to be
+        # loaded first so that libblsgpu.so binds to the same runtime; loaded
+        # the other way round torch no longer sees the GPU.
+        if "torch" not in sys.modules and not os.environ.get("BLSGPU_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         if not os.path.exists(p):
             raise BlsGpuError("libblsgpu.so not found at %s -- run __graft_entry__.build() "
                               "(there is no CPU fallback)" % p)

@@ -1,0 +1,112 @@
+"""The scheduled VM programs, executed by the Python interpreter (vmgen.sim) in
+the GPU's own Montgomery domain, must reproduce the reference bit for bit.
+CPU only: this is what lets a schedule change be validated without a GPU."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from vmgen import emit, programs as P, sim
+
+
+@pytest.fixture(scope="module")
+def built():
+    segs, ms, fs = P.build_all()
+    nslots = P.TEMP0 + max(s.ntemp for s in segs.values())
+    return segs, ms, fs, nslots, P.const_table()
+
+
+def run_pairing(built, g1, g2):
+    segs, ms, fs, nslots, consts = built
+    m = sim.Machine(consts, nslots)
+    vals = [int.from_bytes(g1[i * 48:(i + 1) * 48], "big") for i in range(2)] + \
+           [int.from_bytes(g2[i * 48:(i + 1) * 48], "big") for i in range(4)]
+    for i, v in enumerate(vals):
+        m.team[P.PX + i] = v
+    for name in ms:
+        m.run(segs[name])
+    miller = [m.team[P.F + i] for i in range(12)]
+    for name in fs:
+        m.run(segs[name])
+    m.run(segs["from_mont_1_0"])
+    return miller, b"".join(m.team[P.reg(1) + i].to_bytes(48, "big") for i in range(12))
+
+
+def test_pairing_of_generators(built, golden):
+    g = golden("pairing.json")["gen"]
+    _, out = run_pairing(built, bytes.fromhex(g["g1"]), bytes.fromhex(g["g2"]))
+    assert out.hex() == g["final_exp"]
+
+
+def test_small_multiples_and_product(built, golden, oracle):
+    v = golden("pairing.json")["small4"]
+    segs, ms, fs, nslots, consts = built
+    acc = None
+    for a, b in zip(v["g1"], v["g2"]):
+        miller, out = run_pairing(built, bytes.fromhex(a), bytes.fromhex(b))
+        # single pairing equals the oracle's
+        assert out == oracle.pairing_multi(bytes.fromhex(a), bytes.fromhex(b), 1)
+        if acc is None:
+            acc = miller
+        else:                       # fold with the mul_0_1 segment
+            m = sim.Machine(consts, nslots)
+            for i in range(12):
+                m.team[P.reg(0) + i] = acc[i]
+                m.team[P.reg(1) + i] = miller[i]
+            m.run(segs["mul_0_1"])
+            acc = [m.team[P.reg(0) + i] for i in range(12)]
+    m = sim.Machine(consts, nslots)
+    for i in range(12):
+        m.team[P.reg(0) + i] = acc[i]
+    for name in fs:
+        m.run(segs[name])
+    m.run(segs["from_mont_1_0"])
+    out = b"".join(m.team[P.reg(1) + i].to_bytes(48, "big") for i in range(12))
+    assert out.hex() == v["out"]
+
+
+def test_final_exp_any_element(built, golden):
+    segs, ms, fs, nslots, consts = built
+    recs = golden("pairing.json")["final_exp"] + [{"in": "00" * 576, "out": "00" * 576}]
+    for rec in recs:
+        x = bytes.fromhex(rec["in"])
+        m = sim.Machine(consts, nslots)
+        for i in range(12):
+            m.team[P.reg(0) + i] = sim.to_m(int.from_bytes(x[i * 48:(i + 1) * 48], "big"))
+        for name in fs:
+            m.run(segs[name])
+        m.run(segs["from_mont_1_0"])
+        out = b"".join(m.team[P.reg(1) + i].to_bytes(48, "big") for i in range(12))
+        assert out.hex() == rec["out"]
+
+
+def test_hard_part_exponent_identity():
+    """E = (q^4-q^2+1)/n == ((x-1)^2/3)(x+q)(x^2+q^2-1) + 1 with x = -|x| (fields_t.py:44)."""
+    q, x = sim.Q, -P.NX
+    n = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    assert (q ** 4 - q ** 2 + 1) % n == 0 and (x - 1) % 3 == 0
+    assert (q ** 4 - q ** 2 + 1) // n == ((x - 1) ** 2 // 3) * (x + q) * (x * x + q * q - 1) + 1
+
+
+def test_schedule_invariants(built):
+    segs = built[0]
+    nslots = built[3]
+    for name, seg in segs.items():
+        for rnd in seg.rounds:
+            assert 0 < len(rnd["lanes"]) <= 64
+            dsts = [ln[-1] for ln in rnd["lanes"]]
+            assert len(set(dsts)) == len(dsts), "two lanes write one slot in " + name
+            for d in dsts:
+                assert P.NCONST <= d < nslots, "write outside the scratchpad or into constants"
+
+
+def test_committed_tables_are_current(tmp_path):
+    """csrc/vm_tables.h is generated; the committed copy must match the generator."""
+    path = os.path.join(ROOT, "python-bls_amd", "csrc", "vm_tables.h")
+    if not os.path.exists(path):
+        pytest.skip("tables not generated yet")
+    info = emit.generate(path=str(tmp_path / "t.h"))
+    with open(path) as f:
+        have = re.search(r'BLSVM_TABLE_HASH "([0-9a-f]+)"', f.read()).group(1)
+    assert have == info["hash"]
