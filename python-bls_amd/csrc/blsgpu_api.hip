@@ -81,12 +81,11 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     c->device = device;
     // pack all tables into one device allocation (16-byte aligned pieces)
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
-    size_t o_segs = 0;
-    size_t o_rounds = o_segs + al(sizeof(BLSVM_SEGS));
-    size_t o_data = o_rounds + al(sizeof(BLSVM_ROUNDS));
-    size_t o_ms = o_data + al(sizeof(BLSVM_DATA));
-    size_t o_fs = o_ms + al(sizeof(BLSVM_MILLER_SCRIPT));
-    size_t o_c = o_fs + al(sizeof(BLSVM_FEXP_SCRIPT));
+    size_t o_m = 0;
+    size_t o_f = o_m + al(sizeof(BLSVM_MILLER_FLAT));
+    size_t o_s = o_f + al(sizeof(BLSVM_FEXP_FLAT));
+    size_t o_data = o_s + al(sizeof(BLSVM_SEG_FLAT));
+    size_t o_c = o_data + al(sizeof(BLSVM_DATA));
     size_t total = o_c + al(sizeof(BLSVM_CONSTS));
     if (hipMalloc(&c->d_tables, total) != hipSuccess) {
         delete c;
@@ -94,9 +93,9 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     }
     char* base = (char*)c->d_tables;
     struct { size_t off; const void* src; size_t len; } parts[] = {
-        {o_segs, BLSVM_SEGS, sizeof(BLSVM_SEGS)},       {o_rounds, BLSVM_ROUNDS, sizeof(BLSVM_ROUNDS)},
-        {o_data, BLSVM_DATA, sizeof(BLSVM_DATA)},       {o_ms, BLSVM_MILLER_SCRIPT, sizeof(BLSVM_MILLER_SCRIPT)},
-        {o_fs, BLSVM_FEXP_SCRIPT, sizeof(BLSVM_FEXP_SCRIPT)}, {o_c, BLSVM_CONSTS, sizeof(BLSVM_CONSTS)}};
+        {o_m, BLSVM_MILLER_FLAT, sizeof(BLSVM_MILLER_FLAT)}, {o_f, BLSVM_FEXP_FLAT, sizeof(BLSVM_FEXP_FLAT)},
+        {o_s, BLSVM_SEG_FLAT, sizeof(BLSVM_SEG_FLAT)},       {o_data, BLSVM_DATA, sizeof(BLSVM_DATA)},
+        {o_c, BLSVM_CONSTS, sizeof(BLSVM_CONSTS)}};
     for (auto& p : parts) {
         if (hipMemcpy(base + p.off, p.src, p.len, hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(c->d_tables);
@@ -104,12 +103,18 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
             return fail(-EIO, "hipMemcpy(tables) failed");
         }
     }
-    c->tabs.segs = (const uint2*)(base + o_segs);
-    c->tabs.rounds = (const uint2*)(base + o_rounds);
+    c->tabs.mflat = (const uint2*)(base + o_m);
+    c->tabs.fflat = (const uint2*)(base + o_f);
+    c->tabs.segflat = (const uint2*)(base + o_s);
     c->tabs.data = (const uint16_t*)(base + o_data);
-    c->tabs.mscript = (const uint16_t*)(base + o_ms);
-    c->tabs.fscript = (const uint16_t*)(base + o_fs);
     c->tabs.consts = (const uint32_t*)(base + o_c);
+    c->tabs.stamps = nullptr;
+#ifdef BLSGPU_STAMPS
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, 128) == hipSuccess) { (void)hipMemset(p, 0, 128); c->tabs.stamps = (unsigned long long*)p; }
+    }
+#endif
     if (hipMalloc((void**)&c->d_out, BLSGPU_FQ12_BYTES) != hipSuccess) {
         (void)hipFree(c->d_tables);
         delete c;
@@ -255,7 +260,7 @@ BLSGPU_EXPORT int blsgpu_pairing_multi(blsgpu_ctx* c, const uint8_t* g1, const u
 
 // device kernel used by blsgpu_final_exp: bytes -> Montgomery partial
 namespace blsgpu {
-__global__ void k_bytes_to_partial(VmTables T, const uint32_t* __restrict__ in_bytes, uint32_t* __restrict__ out_partial) {
+__global__ void __launch_bounds__(64) k_bytes_to_partial(VmTables T, const uint32_t* __restrict__ in_bytes, uint32_t* __restrict__ out_partial) {
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     team_init_consts(T, smem, lane);
@@ -264,7 +269,7 @@ __global__ void k_bytes_to_partial(VmTables T, const uint32_t* __restrict__ in_b
         smem[R1_DW + cidx * 12 + (11 - w)] = bswap32(in_bytes[k]);
     }
     wave_fence();
-    run_segment(T, BLSVM_SEG_TO_MONT_0_1, 0, lane);
+    run_rounds(T, T.segflat + BLSVM_SEGF_TO_MONT_0_1_OFF, BLSVM_SEGF_TO_MONT_0_1_LEN, 0, lane);
     for (uint32_t k = lane; k < 144; k += 64) out_partial[k] = smem[F_DW + k];
 }
 }  // namespace blsgpu
@@ -288,5 +293,16 @@ BLSGPU_EXPORT int blsgpu_final_exp(blsgpu_ctx* c, const uint8_t in[576], uint8_t
     HIP_TRY(hipMemcpy(out, c->d_out, 576, hipMemcpyDeviceToHost));
     return 0;
 }
+
+#ifdef BLSGPU_STAMPS
+// diagnostic build: {cycles MUL, LIN, INV, rounds MUL, LIN, INV} of block 0 / wave 0, then reset
+BLSGPU_EXPORT int blsgpu_debug_stamps(blsgpu_ctx* c, unsigned long long out[9]) {
+    if (!c || !c->tabs.stamps) return fail(-EINVAL, "no stamps");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, c->tabs.stamps, 72, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->tabs.stamps, 0, 128));
+    return 0;
+}
+#endif
 
 }  // extern "C"

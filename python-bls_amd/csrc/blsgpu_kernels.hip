@@ -10,7 +10,11 @@
 // vm_tables.h (generated and CPU-verified by python-bls_amd/vmgen):
 //   MUL round: each active lane loads two slots, does one 12x12-limb Montgomery
 //              product (v_mad_u64_u32 chains) and stores one slot;
-//   LIN round: each active lane accumulates +/- slots (modular add chains);
+//   LIN round: each active lane accumulates coef * slot (or coef * ~slot for a
+//              negative term) limb by limb into 64-bit "fat" limbs -- independent
+//              v_mad_u64_u32, no carry chain, no VCC hazard -- and reduces once;
+//   values are kept "relaxed" (< 2q): products need no final subtraction and a
+//   linear combination is reduced with a single quotient estimate (fq32.h);
 //   INV round: field inversion (one lane, once per final exponentiation).
 // Lanes never diverge on data: all control flow below is wavefront-uniform.
 // Within a team LDS traffic is ordered by the hardware's in-order DS queue, so
@@ -25,14 +29,16 @@
 namespace blsgpu {
 
 struct VmTables {
-    const uint2* segs;        // {first_round, nrounds}
-    const uint2* rounds;      // {data_off, kind | K << 8 | nlanes << 16}
+    const uint2* mflat;       // Miller loop: flat round sequence {data_off, meta}
+    const uint2* fflat;       // final exponentiation
+    const uint2* segflat;     // directly called segments (BLSVM_SEGF_*)
     const uint16_t* data;
-    const uint16_t* mscript;
-    const uint16_t* fscript;
     const uint32_t* consts;   // BLSVM_NCONST x 12 limbs
+    unsigned long long* stamps;   // diagnostic builds only (-DBLSGPU_STAMPS), else unused
 };
 
+constexpr int LIN_CHUNKS = 8;                           // a LIN record holds <= 31 micro-ops
+static_assert(BLSVM_MAX_LIN_K <= 4 * LIN_CHUNKS - 1, "LIN record too long");
 constexpr int TEAM_DW = BLSVM_TEAM_SLOTS * 12;           // dwords per team
 constexpr int TEAM_BYTES = TEAM_DW * 4;
 constexpr int F_DW = BLSVM_SLOT_REG0 * 12;               // register 0 (accumulator)
@@ -58,63 +64,154 @@ __device__ __forceinline__ void lds_store12(const uint32_t* x, uint32_t idx16) {
     smem4[idx16 + 2] = make_uint4(x[8], x[9], x[10], x[11]);
 }
 
-// Run one scheduled segment on the team whose scratchpad starts at base16
-// (in 16-byte units).  seg must be wavefront-uniform.
-__device__ __noinline__ void run_segment(const VmTables& T, uint32_t seg, uint32_t base16, uint32_t lane) {
-    const uint32_t q[12] = BLS_Q_LIMBS;
-    seg = __builtin_amdgcn_readfirstlane(seg);
-    uint2 si = T.segs[seg];
-    uint32_t r0 = __builtin_amdgcn_readfirstlane(si.x), r1 = r0 + __builtin_amdgcn_readfirstlane(si.y);
-    for (uint32_t r = r0; r < r1; ++r) {
-        uint2 ri = T.rounds[r];
-        uint32_t off = __builtin_amdgcn_readfirstlane(ri.x);
-        uint32_t meta = __builtin_amdgcn_readfirstlane(ri.y);
-        uint32_t kind = meta & 0xffu, K = (meta >> 8) & 0xffu;
-        const uint16_t* d = T.data + off;
+// per-lane record length of a round, in u16 units (wave-uniform)
+__device__ __forceinline__ uint32_t rec_len(uint32_t meta) {
+    if ((meta & 3u) != 1u) return 4u;
+    return (((meta >> 8) & 0xFFu) + 1u + 3u) & ~3u;
+}
+
+// global-address-space views: a pointer taken out of the kernel-argument struct
+// is generic, and generic (flat) loads tie up the LDS wait counter
+typedef const __attribute__((address_space(1))) uint64_t* gptr_u2;     // 8-byte table entries
+typedef const __attribute__((address_space(1))) uint16_t* gptr_u16;
+__device__ __forceinline__ uint2 ld2(gptr_u2 p, uint32_t i) {
+    uint64_t v = p[i];
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
+// sequential reader of a lane's u16 record, 4 entries (8 bytes) per load,
+// with the next chunk requested one chunk ahead
+struct RecReader {
+    gptr_u2 p;
+    uint2 cur, nxt;
+    uint32_t pos, nchunks;
+    __device__ __forceinline__ void init(gptr_u2 rec, uint2 first, uint32_t len_u16) {
+        p = rec;
+        cur = first;
+        pos = 0;
+        nchunks = len_u16 >> 2;
+        nxt = (nchunks > 1) ? ld2(p, 1) : first;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        uint32_t sub = pos & 3u;                 // wave-uniform
+        uint32_t w = (sub & 2u) ? cur.y : cur.x;
+        uint32_t v = (sub & 1u) ? (w >> 16) : (w & 0xFFFFu);
+        ++pos;
+        if ((pos & 3u) == 0u) {
+            uint32_t c = pos >> 2;
+            cur = nxt;
+            if (c + 1 < nchunks) nxt = ld2(p, c + 1);
+        }
+        return v;
+    }
+};
+
+// Walk `n` rounds of a flat sequence on the team whose scratchpad starts at
+// base16 (16-byte units).  Round headers are read two rounds ahead and the
+// first 8 bytes of every lane record one round ahead, so that table latency
+// overlaps the arithmetic of the previous round.
+__device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __restrict__ seq_, uint32_t n, uint32_t base16, uint32_t lane) {
+    if (n == 0) return;
+    gptr_u2 seq = (gptr_u2)seq_;
+    gptr_u16 gdata = (gptr_u16)T.data;
+    uint2 h0 = ld2(seq, 0);
+    uint2 h1 = ld2(seq, n > 1 ? 1 : 0);
+    h0.x = __builtin_amdgcn_readfirstlane(h0.x); h0.y = __builtin_amdgcn_readfirstlane(h0.y);
+    h1.x = __builtin_amdgcn_readfirstlane(h1.x); h1.y = __builtin_amdgcn_readfirstlane(h1.y);
+    gptr_u2 rec = (gptr_u2)(gdata + h0.x + lane * rec_len(h0.y));
+    uint2 e = ld2(rec, 0);
+#ifdef BLSGPU_STAMPS
+    unsigned long long st_acc[3] = {0, 0, 0}, st_cnt[3] = {0, 0, 0}, st_lin[3] = {0, 0, 0};
+#endif
+    for (uint32_t i = 0; i < n; ++i) {
+#ifdef BLSGPU_STAMPS
+        unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        const uint32_t meta = h0.y;
+        gptr_u2 rec_cur = rec;
+        const uint2 e_cur = e;
+        // ---- prefetch for the following rounds
+        h0 = h1;
+        if (i + 2 < n) {
+            uint2 t = ld2(seq, i + 2);
+            h1.x = __builtin_amdgcn_readfirstlane(t.x); h1.y = __builtin_amdgcn_readfirstlane(t.y);
+        }
+        if (i + 1 < n) {
+            rec = (gptr_u2)(gdata + h0.x + lane * rec_len(h0.y));
+            e = ld2(rec, 0);
+        }
+        const uint32_t kind = meta & 3u;
         if (kind == 0u) {                                    // MUL
-            ushort4 e = reinterpret_cast<const ushort4*>(d)[lane];
+            uint32_t ra = e_cur.x & 0xFFFFu, rb = e_cur.x >> 16, rd = e_cur.y & 0xFFFFu;
             uint32_t A[12], B[12], D[12];
-            lds_load12(A, base16 + e.x);
-            lds_load12(B, base16 + e.y);
-            bls::fq_mul(D, A, B);
-            if (e.z != 0xFFFFu) lds_store12(D, base16 + e.z);
+            lds_load12(A, base16 + ra);
+            lds_load12(B, base16 + rb);
+            bls::fq_mul_relaxed(D, A, B);
+            if (rd != 0xFFFFu) lds_store12(D, base16 + rd);
         } else if (kind == 1u) {                             // LIN
-            uint32_t acc[12];
+            const uint32_t K = (meta >> 8) & 0xFFu;
+#ifdef BLSGPU_STAMPS
+            unsigned long long lt0 = __builtin_amdgcn_s_memtime();
+#endif
+            // the lane's whole record (<= LIN_CHUNKS x 4 u16) is requested up front;
+            // positions are compile-time so every value stays in a fixed register
+            uint2 ch[LIN_CHUNKS];
+            ch[0] = e_cur;
+            const uint32_t nch = rec_len(meta) >> 2;
+#pragma unroll
+            for (int c = 1; c < LIN_CHUNKS; c++) ch[c] = (c < (int)nch) ? ld2(rec_cur, c) : make_uint2(0u, 0u);
+            const uint32_t rd = ch[0].x & 0xFFFFu;
+            uint64_t acc[12];
 #pragma unroll
             for (int j = 0; j < 12; j++) acc[j] = 0;
-            for (uint32_t k = 0; k < K; ++k) {
-                uint32_t u = d[k * 64 + lane];
-                uint32_t op = u >> 14;
-                uint32_t S[12];
-                lds_load12(S, base16 + (u & 0x3FFFu));       // NOP / DBL reference slot 0 = ZERO
-                bool is_dbl = (op == 2u), is_sub = (op == 1u);
-                uint32_t N[12];
-                uint32_t br = 0;
+            // micro-op p sits at record position p + 1; operands are fetched one
+            // micro-op ahead into two alternating buffers
+            uint32_t S[2][12];
+#define BLSGPU_UOP(p) ((((p) + 1) & 1) ? ((((p) + 1) & 2) ? (ch[((p) + 1) >> 2].y >> 16) : (ch[((p) + 1) >> 2].x >> 16)) \
+                                       : ((((p) + 1) & 2) ? (ch[((p) + 1) >> 2].y & 0xFFFFu) : (ch[((p) + 1) >> 2].x & 0xFFFFu)))
+            if (K > 0) lds_load12(S[0], base16 + (BLSGPU_UOP(0) & 511u) * 3u);
 #pragma unroll
-                for (int j = 0; j < 12; j++) {
-                    uint32_t s = is_dbl ? acc[j] : S[j];
-                    uint64_t x = (uint64_t)q[j] - s - br;
-                    N[j] = (uint32_t)x;
-                    br = (uint32_t)(x >> 63);
-                    S[j] = s;
+            for (int p = 0; p < 4 * LIN_CHUNKS - 1; p++) {
+                if ((uint32_t)p < K) {
+                    if (p + 1 < 4 * LIN_CHUNKS - 1 && (uint32_t)(p + 1) < K)
+                        lds_load12(S[(p + 1) & 1], base16 + (BLSGPU_UOP(p + 1) & 511u) * 3u);
+                    const uint32_t u = BLSGPU_UOP(p);
+                    bls::fat_mac(acc, S[p & 1], (u >> 9) & 63u, (uint32_t)((int32_t)(u << 16) >> 31));
                 }
-#pragma unroll
-                for (int j = 0; j < 12; j++) S[j] = is_sub ? N[j] : S[j];
-                bls::fq_add_mod(acc, S);
             }
-            uint32_t dst = d[K * 64 + lane];
-            if (dst != 0xFFFFu) lds_store12(acc, base16 + dst);
+#undef BLSGPU_UOP
+#ifdef BLSGPU_STAMPS
+            asm volatile("" :: "v"(acc[0]), "v"(acc[11]));
+            unsigned long long lt1 = __builtin_amdgcn_s_memtime();
+#endif
+            uint32_t D[12];
+            bls::fat_reduce(D, acc);
+#ifdef BLSGPU_STAMPS
+            asm volatile("" :: "v"(D[0]), "v"(D[11]));
+            unsigned long long lt2 = __builtin_amdgcn_s_memtime();
+            st_lin[0] += lt1 - lt0; st_lin[1] += lt2 - lt1; st_lin[2] += K;
+#endif
+            if (rd != 0xFFFFu) lds_store12(D, base16 + rd);
         } else {                                             // INV
-            ushort4 e = reinterpret_cast<const ushort4*>(d)[lane];
-            if (e.z != 0xFFFFu) {
+            uint32_t ra = e_cur.x & 0xFFFFu, rd = e_cur.y & 0xFFFFu;
+            if (rd != 0xFFFFu) {
                 uint32_t A[12], D[12];
-                lds_load12(A, base16 + e.x);
+                lds_load12(A, base16 + ra);
                 bls::fq_inv(D, A);
-                lds_store12(D, base16 + e.z);
+                lds_store12(D, base16 + rd);
             }
         }
         wave_fence();
+#ifdef BLSGPU_STAMPS
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the round's LDS stores are issued
+        st_acc[kind] += __builtin_amdgcn_s_memtime() - st_t0;
+        st_cnt[kind] += 1;
+#endif
     }
+#ifdef BLSGPU_STAMPS
+    if (T.stamps && blockIdx.x == 0 && threadIdx.x == 0)
+        for (int k2 = 0; k2 < 3; k2++) { atomicAdd(&T.stamps[k2], st_acc[k2]); atomicAdd(&T.stamps[3 + k2], st_cnt[k2]); atomicAdd(&T.stamps[6 + k2], st_lin[k2]); }
+#endif
 }
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
@@ -142,7 +239,7 @@ __device__ __forceinline__ void wg_product_tree(const VmTables& T, uint32_t* sme
             const uint32_t* other = smem + (wave + s) * TEAM_DW + F_DW;
             for (uint32_t i = lane; i < 144; i += 64) team[R1_DW + i] = other[i];
             wave_fence();
-            run_segment(T, BLSVM_SEG_MUL_0_1, wave * (TEAM_BYTES / 16), lane);
+            run_rounds(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, wave * (TEAM_BYTES / 16), lane);
         }
     }
 }
@@ -192,7 +289,7 @@ __global__ void __launch_bounds__(256) k_miller(VmTables T, const uint32_t* __re
         } else if (p_zero) {
             team_set_acc(team, lane, true);
         } else {
-            for (uint32_t i = 0; i < BLSVM_MILLER_LEN; ++i) run_segment(T, T.mscript[i], base16, lane);
+            run_rounds(T, T.mflat, BLSVM_MILLER_FLAT_LEN, base16, lane);
         }
     } else {
         wave_fence();
@@ -231,7 +328,7 @@ __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __re
         uint32_t dst = first ? F_DW : R1_DW;
         for (uint32_t k = lane; k < 144; k += 64) team[dst + k] = src[k];
         wave_fence();
-        if (!first) run_segment(T, BLSVM_SEG_MUL_0_1, base16, lane);
+        if (!first) run_rounds(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, base16, lane);
         first = false;
     }
     if (first) team_set_acc(team, lane, true);
@@ -240,8 +337,15 @@ __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __re
     if (wave == 0) {
         wave_fence();
         if (do_final) {
-            for (uint32_t i = 0; i < BLSVM_FEXP_LEN; ++i) run_segment(T, T.fscript[i], base16, lane);
-            run_segment(T, BLSVM_SEG_FROM_MONT_1_0, base16, lane);
+            run_rounds(T, T.fflat, BLSVM_FEXP_FLAT_LEN, base16, lane);
+            run_rounds(T, T.segflat + BLSVM_SEGF_FROM_MONT_1_0_OFF, BLSVM_SEGF_FROM_MONT_1_0_LEN, base16, lane);
+            if (lane < 12) {                         // relaxed (< 2q) -> canonical residues
+                uint32_t X[12];
+                lds_load12(X, base16 + (BLSVM_SLOT_REG0 + 12 + lane) * 3);
+                bls::fq_canon(X);
+                lds_store12(X, base16 + (BLSVM_SLOT_REG0 + 12 + lane) * 3);
+            }
+            wave_fence();
             for (uint32_t k = lane; k < 144; k += 64) {
                 uint32_t c = k / 12, w = k % 12;
                 out_bytes[k] = bswap32(team[R1_DW + c * 12 + (11 - w)]);

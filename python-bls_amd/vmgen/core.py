@@ -5,7 +5,7 @@ pairing formulas.  One wavefront ("team") owns one pairing; its Fq values live
 in an LDS scratchpad of 48-byte slots, and the 64 lanes execute *rounds*:
 
   MUL round   every active lane:  dst <- A * B            (Montgomery product)
-  LIN round   every active lane:  dst <- sum of +/- slots (micro-ops ADD/SUB/DBL)
+  LIN round   every active lane:  dst <- sum of +/- coef * slot, coef = 1..63
   INV round   every active lane:  dst <- A^-1             (0 -> 0, like the
                                                            reference's fq_invert)
 
@@ -23,7 +23,6 @@ LANES = 64
 # (constants, named registers and temporaries all live there).
 NOSLOT = 0xFFFF
 
-UOP_ADD, UOP_SUB, UOP_DBL, UOP_NOP = 0, 1, 2, 3
 
 
 class V:
@@ -139,18 +138,34 @@ class Builder:
 
 
 # ---------------------------------------------------------------------------
+MAX_COEF = 63          # a micro-op adds coef * x, x = slot or its 384-bit complement
+MAX_LIN_MAG = 120      # sum of |coefficients| per linear combination
+K1_SLOT = None         # set by programs.py: slot holding -(2^384 - 1) mod q
+
+
 def lower_lin(terms):
-    """[(coef, V)] -> list of (uop, V|None) evaluating sum(coef * V) with
-    acc starting at 0: bit-plane Horner over the binary expansions."""
-    maxbits = max(abs(c).bit_length() for c, _ in terms)
+    """[(coef, V)] -> list of (neg, coef, V|"K1").
+
+    The GPU accumulates only non-negative quantities: a negative term -c*x is
+    added as c * (2^384 - 1 - x) (limb-wise complement) and the surplus
+    c * (2^384 - 1) is cancelled by one extra micro-op  N * K1,
+    K1 = -(2^384 - 1) mod q, N = sum of the negative coefficients."""
     uops = []
-    for bit in range(maxbits - 1, -1, -1):
-        if uops:
-            uops.append((UOP_DBL, None))
-        for c, v in terms:
-            if (abs(c) >> bit) & 1:
-                uops.append((UOP_ADD if c > 0 else UOP_SUB, v))
-    # drop a leading DBL-free prefix problem: acc starts at 0 so DBL of 0 is harmless
+    mag = nmag = 0
+    for c, v in terms:
+        m = abs(c)
+        mag += m
+        if c < 0:
+            nmag += m
+        while m > 0:
+            k = min(m, MAX_COEF)
+            uops.append((1 if c < 0 else 0, k, v))
+            m -= k
+    assert mag <= MAX_LIN_MAG, "linear combination too large (%d)" % mag
+    while nmag > 0:
+        k = min(nmag, MAX_COEF)
+        uops.append((0, k, "K1"))
+        nmag -= k
     return uops
 
 
@@ -340,7 +355,7 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
         else:
             K = 0
             for v in r.ops:
-                u = [(op, (slot[s.id] if s is not None else NOSLOT)) for op, s in lower_lin(v.terms)]
+                u = [(neg, cf, (K1_SLOT if s == "K1" else slot[s.id])) for neg, cf, s in lower_lin(v.terms)]
                 K = max(K, len(u))
                 lanes_out.append((u, slot[v.id]))
             seg.rounds.append({"kind": "lin", "K": K, "lanes": lanes_out})
@@ -350,7 +365,7 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
     if copies:
         assert len(copies) <= lanes, "too many output copies"
         seg.rounds.append({"kind": "lin", "K": 1,
-                           "lanes": [([(UOP_ADD, slot[v.id])], fx) for v, fx in copies]})
+                           "lanes": [([(0, 1, slot[v.id])], fx) for v, fx in copies]})
     seg.ntemp = ntemp
     nm = sum(len(r["lanes"]) for r in seg.rounds if r["kind"] == "mul")
     rm = sum(1 for r in seg.rounds if r["kind"] == "mul")

@@ -16,6 +16,7 @@ Algorithm (what the GPU runs) versus the reference (what it must equal):
   squarings.  The result is the identical field element, hence identical bytes.
 """
 from . import tower as tw
+from . import core
 from .core import Builder, schedule
 from .sim import Q, R, to_m
 
@@ -26,18 +27,22 @@ NX = 0xd201000000010000                   # |x|  (fields_t.py:25)
 # constants (copied in by the kernel at start-up)
 C_ZERO, C_ONE, C_R2, C_RAW1 = 0, 1, 2, 3
 C_GAM = 4                                 # gamma_i^j, i=1..3, j=1..5: Fq2 each
-NCONST = C_GAM + 3 * 5 * 2                # 34
+C_K1 = C_GAM + 3 * 5 * 2                  # -(2^384 - 1) mod q  (LIN complement surplus)
+NCONST = C_K1 + 1                         # 35
 # named values
-PX, PY = 34, 35
-QX0, QX1, QY0, QY1 = 36, 37, 38, 39
-TX, TY, TZ = 40, 42, 44                   # Fq2 each
-LD = 46                                   # pending tangent line  l0,l1,l4 (6)
-LA = 52                                   # pending chord line    l0,l1,l4 (6)
-NPX3 = 58                                 # -3*px
-REG0 = 60                                 # Fq12 registers R[k] = REG0 + 12 k
+PX, PY = 36, 37
+QX0, QX1, QY0, QY1 = 38, 39, 40, 41
+TX, TY, TZ = 42, 44, 46                   # Fq2 each
+LD = 48                                   # pending tangent line  l0,l1,l4 (6)
+LA = 54                                   # pending chord line    l0,l1,l4 (6)
+NPX3 = 60                                 # -3*px
+REG0 = 62                                 # Fq12 registers R[k] = REG0 + 12 k
 NREG = 5
 F = REG0                                  # the Miller accumulator is register 0
-TEMP0 = REG0 + 12 * NREG                  # 120
+TEMP0 = REG0 + 12 * NREG                  # 122
+
+
+core.K1_SLOT = C_K1
 
 
 def reg(k):
@@ -67,6 +72,7 @@ def const_table():
     c[C_ONE] = to_m(1)
     c[C_R2] = to_m(R % Q)          # content R^2: raw x -> x R
     c[C_RAW1] = 1                  # content 1: x R -> x
+    c[C_K1] = (-(R - 1)) % Q       # plain integer used by the LIN accumulation (not a field element)
     for i in (1, 2, 3):
         for j in range(1, 6):
             g = gamma(i, j)

@@ -1,10 +1,9 @@
 """Bit-exact Python interpreter for the VM tables (CPU check of the schedules).
 
 Works in the GPU's own value domain: every slot holds the Montgomery content
-x*R mod q (R = 2^384), MUL is a*b*R^-1 mod q, LIN micro-ops are modular
-add/sub/double, INV is the Montgomery inverse with 0 -> 0.
+x*R mod q (R = 2^384), MUL is a*b*R^-1 mod q, a LIN op is an exact sum of
+coef * slot (negative terms through the 384-bit complement) reduced mod q once, INV is the Montgomery inverse with 0 -> 0.
 """
-from .core import UOP_ADD, UOP_DBL, UOP_NOP, UOP_SUB
 
 Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 R = 1 << 384
@@ -56,17 +55,13 @@ class Machine:
             else:
                 self.uop_depth += rnd["K"]
                 for uops, d in rnd["lanes"]:
+                    # exactly the GPU's non-negative accumulation (core.lower_lin)
                     acc = 0
-                    for op, s in uops:
-                        if op == UOP_ADD:
-                            acc = (acc + self.rd(s)) % Q
-                        elif op == UOP_SUB:
-                            acc = (acc - self.rd(s)) % Q
-                        elif op == UOP_DBL:
-                            acc = (acc * 2) % Q
-                        else:
-                            assert op == UOP_NOP
-                    writes.append((d, acc))
+                    for neg, cf, s in uops:
+                        x = self.rd(s)
+                        acc += cf * ((R - 1 - x) if neg else x)
+                    assert 0 <= acc < (1 << 392)
+                    writes.append((d, acc % Q))
             # all lanes read before any lane writes
             for d, val in writes:
                 self.wr(d, val)
