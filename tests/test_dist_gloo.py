@@ -1,0 +1,82 @@
+"""World-size-2 check of the sharding logic (bls_py/dist.py) on CPU with gloo.
+The GPU engine is replaced by an oracle-backed stand-in with the same three
+methods, so only the rank/partition/exchange logic is under test here."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+class OracleShardBackend:
+    """partial = canonical 576-byte product of the shard's Miller values."""
+    ONE = (1).to_bytes(48, "big") + bytes(48 * 11)
+
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def miller_partial(self, g1, g2, n):
+        acc = self.ONE
+        for i in range(n):
+            ml = self.o.miller_loop(g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)])
+            acc = self.o.field_op(12, "mul", acc, ml)
+        return torch.frombuffer(bytearray(acc), dtype=torch.uint8).clone()
+
+    def all_gather(self, part, group=None):
+        world = dist.get_world_size(group)
+        outs = [torch.zeros(576, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(outs, part, group=group)
+        return outs, world
+
+    def final(self, gathered, world):
+        acc = self.ONE
+        for t in gathered:
+            acc = self.o.field_op(12, "mul", acc, bytes(t.numpy()))
+        return self.o.final_exp(acc)
+
+
+def _worker(rank, world, port, n, q):
+    for p in (os.path.join(ROOT, "python-bls_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    from bls_py.dist import pairing_multi_sharded
+    g1 = open(os.path.join(ROOT, "tests/golden/pairs_seed1_g1.bin"), "rb").read()[:96 * n]
+    g2 = open(os.path.join(ROOT, "tests/golden/pairs_seed1_g2.bin"), "rb").read()[:192 * n]
+    out = pairing_multi_sharded(OracleShardBackend(O), g1, g2, n, rank, world)
+    q.put((rank, out.hex()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_everything():
+    from bls_py.dist import shard_bounds
+    for n in (0, 1, 7, 1025, 65536):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def test_two_ranks_match_reference(golden, oracle):
+    n, world = 8, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = golden("pairing.json")["seeded"]["8"]["out"]
+    assert res[0] == res[1] == want
