@@ -1,0 +1,33 @@
+"""Where the host-side scheme code gets its heavy operations from.
+
+Default (and only shipped) provider: the HIP engine behind libblsgpu.so.
+`use(provider)` exists so that CPU-only unit tests of the HOST LOGIC can plug in
+a stand-in (tests/ inject the CPU oracle); the product never does that and has
+no fallback -- with no GPU the default provider raises BlsGpuError.
+"""
+_provider = None
+
+
+class HipProvider:
+    def __init__(self, device=0):
+        from . import _native
+        self._eng = _native.engine(device)
+
+    def pairing_multi(self, g1: bytes, g2: bytes, n: int) -> bytes:
+        return self._eng.pairing_multi(g1, g2, n)
+
+    def final_exp(self, x: bytes) -> bytes:
+        return self._eng.final_exp(x)
+
+
+def use(provider):
+    """Install a provider object with pairing_multi(g1, g2, n) / final_exp(x)."""
+    global _provider
+    _provider = provider
+
+
+def get():
+    global _provider
+    if _provider is None:
+        _provider = HipProvider()
+    return _provider

@@ -1,0 +1,121 @@
+"""Key types (keys.py:17-164 of the reference): PublicKey = G1 point with a
+48-byte compressed form, PrivateKey = scalar mod n."""
+from copy import deepcopy
+from random import SystemRandom
+
+from . import hostmath as H
+from .aggregation_info import AggregationInfo
+from .bls12381 import n as GROUP_ORDER
+from .ec import (JacobianPoint, default_ec, generator_Fq, hash_to_point_Fq2,
+                 hash_to_point_prehashed_Fq2)
+from .fields import Fq
+from .signature import Signature
+from .util import hash256, hmac256
+
+RNG = SystemRandom()
+
+
+class PublicKey:
+    PUBLIC_KEY_SIZE = 48
+
+    def __init__(self, value):
+        self.value = value
+        self._ser = None
+
+    @staticmethod
+    def from_bytes(buffer):
+        A = H.g1_decompress(bytes(buffer))
+        return PublicKey(JacobianPoint._from(H.F1, H.aff_to_jac(H.F1, A), default_ec))
+
+    @staticmethod
+    def from_g1(g1_el):
+        assert type(g1_el) is JacobianPoint
+        return PublicKey(g1_el)
+
+    def serialize(self):
+        if self._ser is None:
+            self._ser = self.value.serialize()
+        return self._ser
+
+    def get_fingerprint(self):
+        return int.from_bytes(hash256(self.serialize())[:4], "big")
+
+    def size(self):
+        return self.PUBLIC_KEY_SIZE
+
+    def __eq__(self, other):
+        return self.serialize() == other.serialize()
+
+    def __hash__(self):
+        return int.from_bytes(self.serialize(), "big")
+
+    def __lt__(self, other):
+        return self.serialize() < other.serialize()
+
+    def __repr__(self):
+        return "PublicKey(%s)" % self.serialize().hex()
+
+    def __deepcopy__(self, memo):
+        return PublicKey.from_g1(deepcopy(self.value, memo))
+
+
+class PrivateKey:
+    PRIVATE_KEY_SIZE = 32
+
+    def __init__(self, value):
+        self.value = int(value)
+
+    @staticmethod
+    def from_bytes(buffer):
+        return PrivateKey(int.from_bytes(buffer, "big"))
+
+    @staticmethod
+    def from_seed(seed):
+        return PrivateKey(int.from_bytes(hmac256(seed, b"BLS private key seed"), "big") % GROUP_ORDER)
+
+    @staticmethod
+    def new_threshold(T, N):
+        """Joint-Feldman dealing (keys.py:92-117): a random degree T-1 polynomial,
+        commitments g1*c_i and the N fragments P(1..N)."""
+        assert 1 <= T <= N
+        g1 = generator_Fq()
+        poly = [Fq(GROUP_ORDER, RNG.randint(1, GROUP_ORDER - 1)) for _ in range(T)]
+        commitments = [g1 * c for c in poly]
+        fragments = [sum(c * pow(x, i, GROUP_ORDER) for i, c in enumerate(poly)) for x in range(1, N + 1)]
+        return PrivateKey(poly[0]), commitments, fragments
+
+    def get_public_key(self):
+        return PublicKey.from_g1((self.value * generator_Fq()).to_jacobian())
+
+    def sign(self, m):
+        r = hash_to_point_Fq2(m).to_jacobian()
+        return Signature.from_g2(self.value * r, AggregationInfo.from_msg(self.get_public_key(), m))
+
+    def sign_prehashed(self, h):
+        r = hash_to_point_prehashed_Fq2(h).to_jacobian()
+        return Signature.from_g2(self.value * r, AggregationInfo.from_msg_hash(self.get_public_key(), h))
+
+    def sign_threshold(self, m, player, players):
+        from .threshold import Threshold
+        assert player in players
+        r = hash_to_point_Fq2(m).to_jacobian()
+        lam = Threshold.lagrange_coeffs_at_zero(players)[players.index(player)]
+        return Signature.from_g2(self.value * (r * lam))
+
+    def serialize(self):
+        return self.value.to_bytes(self.PRIVATE_KEY_SIZE, "big")
+
+    def size(self):
+        return self.PRIVATE_KEY_SIZE
+
+    def __lt__(self, other):
+        return self.value < other.value
+
+    def __eq__(self, other):
+        return self.value == other.value
+
+    def __hash__(self):
+        return self.value
+
+    def __repr__(self):
+        return "PrivateKey(%s)" % hex(self.value)

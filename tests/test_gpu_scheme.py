@@ -1,0 +1,84 @@
+"""The reference's scheme-level scenarios with the pairing on the GPU (default
+provider = HIP engine through the C ABI).  Needs an MI355X."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_provider(engine):
+    from bls_py import backend
+    backend.use(None)          # default HIP provider
+    assert type(backend.get()).__name__ == "HipProvider"
+    yield
+
+
+def test_verify_4_signatures_C1(golden):
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    v = golden("verify4.json")
+    sks = [PrivateKey.from_seed(bytes.fromhex(s)) for s in v["seeds"]]
+    sigs = [sk.sign(bytes.fromhex(m)) for sk, m in zip(sks, v["msgs"])]
+    agg = BLS.aggregate_sigs(sigs)
+    assert agg.serialize().hex() == v["agg_sig"]
+    assert BLS.verify(agg) is True
+    bad = BLS.aggregate_sigs(sigs[:3])
+    bad.set_aggregation_info(agg.aggregation_info)
+    assert BLS.verify(bad) is False
+
+
+def test_reference_vectors(golden):
+    from bls_py.aggregation_info import AggregationInfo
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey, PublicKey
+    from bls_py.signature import Signature
+    v = golden("scheme.json")["vectors"]
+    sk1, sk2 = [PrivateKey.from_seed(bytes.fromhex(x)) for x in v["seeds"]]
+    m = bytes.fromhex(v["msg"])
+    sig1, sig2 = sk1.sign(m), sk2.sign(m)
+    agg = BLS.aggregate_sigs([sig1, sig2])
+    assert BLS.verify(sig1) and BLS.verify(agg)
+    agg_pk = BLS.aggregate_pub_keys([sk1.get_public_key(), sk2.get_public_key()], True)
+    agg.set_aggregation_info(AggregationInfo.from_msg(agg_pk, m))
+    assert BLS.verify(agg)
+    sig1.set_aggregation_info(sig2.aggregation_info)
+    assert not BLS.verify(sig1)
+    # (de)serialise, re-attach the info, verify (tests.py:238-243)
+    sig = Signature.from_bytes(sk1.sign(b"round trip").serialize())
+    sig.set_aggregation_info(AggregationInfo.from_msg(PublicKey.from_bytes(sk1.get_public_key().serialize()), b"round trip"))
+    assert BLS.verify(sig)
+
+
+def test_sign_aggregate_verify_batch_C2():
+    """BASELINE configs[1] end to end at a reduced count (host hashing is pure
+    Python): n signatures -> aggregate -> verify = n + 1 pairings; one flipped
+    message must fail."""
+    import hashlib
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    n = 96
+    sks = [PrivateKey(int.from_bytes(hashlib.sha256(b"blsgpu/a" + (1).to_bytes(4, "big") + i.to_bytes(4, "big")).digest(), "big")
+                      % (0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001 - 1) + 1) for i in range(n)]
+    sigs = [sk.sign(i.to_bytes(4, "big")) for i, sk in enumerate(sks)]
+    agg = BLS.aggregate_sigs(sigs)
+    assert len(agg.aggregation_info.public_keys) == n
+    assert BLS.verify(agg) is True
+    sigs[7] = sks[7].sign(b"\xff\xff\xff\xff")
+    forged = BLS.aggregate_sigs_simple(sigs)
+    forged.set_aggregation_info(agg.aggregation_info)
+    assert BLS.verify(forged) is False
+
+
+def test_threshold_combine_and_verify_C4(golden):
+    from bls_py.aggregation_info import AggregationInfo
+    from bls_py.bls import BLS
+    from bls_py.keys import PublicKey
+    from bls_py.signature import Signature
+    from bls_py.threshold import Threshold
+    rec = golden("threshold.json")["67_of_100"]
+    unit = [Signature.from_bytes(bytes.fromhex(s)) for s in rec["unit_sigs"]]
+    comb = Threshold.aggregate_unit_sigs(unit, rec["players"], rec["T"])
+    assert comb.serialize().hex() == rec["combined"]
+    comb.set_aggregation_info(AggregationInfo.from_msg(PublicKey.from_bytes(bytes.fromhex(rec["master_pk"])),
+                                                       bytes.fromhex(rec["msg"])))
+    assert BLS.verify(comb) is True

@@ -1,0 +1,189 @@
+"""Host-side scheme logic (python-bls_amd/bls_py: keys, signatures, aggregation
+tree, threshold, hashing, (de)serialisation) against vectors produced by the
+reference.  CPU only: the pairing provider is replaced by the CPU oracle -- the
+product itself never does that (bls_py/backend.py)."""
+import pytest
+
+from conftest import cat
+
+
+@pytest.fixture(scope="module", autouse=True)
+def oracle_provider(oracle):
+    from bls_py import backend
+
+    class P:
+        def pairing_multi(self, g1, g2, n):
+            return oracle.pairing_multi(g1, g2, n, threads=8)
+
+        def final_exp(self, x):
+            return oracle.final_exp(x)
+    backend.use(P())
+    yield
+    backend.use(None)
+
+
+def test_hash_to_curve_and_sw_encode(golden):
+    from bls_py import hostmath as H, util
+    g = golden("hash_to_curve.json")
+    for rec in g["hash_to_g2"]:
+        assert util.hash256(bytes.fromhex(rec["msg"])).hex() == rec["msg_hash"]
+        p = H.hash_to_g2_prehashed(bytes.fromhex(rec["msg_hash"]), util.hash512)
+        assert H.g2_affine_bytes(p).hex() == rec["point"]
+    p = H.hash_to_g1_prehashed(util.hash256(b""), util.hash512)
+    assert H.g1_compress(p).hex() == g["hash_to_g1_empty"]["ser"]          # tests.py:80
+    for rec in g["sw_encode_fq"]:
+        assert H.g1_affine_bytes(H.sw_encode(H.F1, int(rec["t"], 16))).hex() == rec["point"]
+    for rec in g["sw_encode_fq2"]:
+        b = bytes.fromhex(rec["t"])
+        t = (int.from_bytes(b[:48], "big"), int.from_bytes(b[48:], "big"))
+        assert H.g2_affine_bytes(H.sw_encode(H.F2, t)).hex() == rec["point"]
+    assert H.sw_encode(H.F1, 0) is None                                    # tests.py:104
+
+
+def test_serialisation_round_trips(golden):
+    from bls_py.keys import PrivateKey, PublicKey
+    from bls_py.signature import Signature
+    from bls_py import hostmath as H
+    for rec in golden("scheme.json")["serialization"]:
+        sk = PrivateKey.from_seed(bytes.fromhex(rec["seed"]))
+        assert sk.serialize().hex() == rec["sk"]
+        pk = sk.get_public_key()
+        assert pk.serialize().hex() == rec["pk"] and pk.size() == 48
+        assert PublicKey.from_bytes(bytes.fromhex(rec["pk"])) == pk
+        assert H.g1_affine_bytes(PublicKey.from_bytes(bytes.fromhex(rec["pk"])).value.to_affine()._aff()).hex() == rec["pk_affine"]
+        sig = sk.sign(bytes.fromhex(rec["msg"]))
+        assert sig.serialize().hex() == rec["sig"] and sig.size() == 96
+        back = Signature.from_bytes(bytes.fromhex(rec["sig"]))
+        assert back == sig
+        assert H.g2_affine_bytes(back.value.to_affine()._aff()).hex() == rec["sig_affine"]
+
+
+def test_scheme_vectors(golden):
+    """tests.py:110-147 scenario: keys, signatures, aggregates, verify True/False."""
+    from bls_py.aggregation_info import AggregationInfo
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    v = golden("scheme.json")["vectors"]
+    sk1, sk2 = [PrivateKey.from_seed(bytes.fromhex(x)) for x in v["seeds"]]
+    pk1, pk2 = sk1.get_public_key(), sk2.get_public_key()
+    m = bytes.fromhex(v["msg"])
+    sig1, sig2 = sk1.sign(m), sk2.sign(m)
+    assert [sk1.serialize().hex(), sk2.serialize().hex()] == v["sk"]
+    assert [pk1.get_fingerprint(), pk2.get_fingerprint()] == v["fingerprint"]
+    assert [sig1.serialize().hex(), sig2.serialize().hex()] == v["sig"]
+    agg = BLS.aggregate_sigs([sig1, sig2])
+    assert agg.serialize().hex() == v["agg_sig"]
+    agg_pk = BLS.aggregate_pub_keys([pk1, pk2], True)
+    assert agg_pk.serialize().hex() == v["agg_pk_secure"]
+    assert BLS.aggregate_pub_keys([pk1, pk2], False).serialize().hex() == v["agg_pk_simple"]
+    agg_sk = BLS.aggregate_priv_keys([sk1, sk2], [pk1, pk2], True)
+    assert agg_sk.serialize().hex() == v["agg_sk"]
+    assert agg_sk.sign(m).serialize() == agg.serialize()
+    assert BLS.verify(sig1) is True and BLS.verify(agg) is True
+    agg.set_aggregation_info(AggregationInfo.from_msg(agg_pk, m))
+    assert BLS.verify(agg) is True
+    sig1.set_aggregation_info(sig2.aggregation_info)
+    assert BLS.verify(sig1) is False
+    sigs = [(sk1, sk2)[k].sign(bytes.fromhex(mm)) for k, mm in zip(v["agg2_signers"], v["agg2_msgs"])]
+    agg2 = BLS.aggregate_sigs(sigs)
+    assert agg2.serialize().hex() == v["agg2_sig"] and BLS.verify(agg2)
+
+
+def test_nested_aggregation_and_division(golden):
+    """tests.py:150-198 scenario."""
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    s = golden("scheme.json")
+    sk1, sk2 = [PrivateKey.from_seed(bytes.fromhex(x)) for x in s["vectors"]["seeds"]]
+    n = s["nested"]
+    m1, m2, m3, m4 = [bytes.fromhex(x) for x in n["msgs"]]
+    s1, s2, s3, s4, s5, s6 = sk1.sign(m1), sk2.sign(m2), sk2.sign(m1), sk1.sign(m3), sk1.sign(m1), sk1.sign(m4)
+    sL = BLS.aggregate_sigs([s1, s2])
+    sR = BLS.aggregate_sigs([s3, s4, s5])
+    sF = BLS.aggregate_sigs([sL, sR, s6])
+    assert [sL.serialize().hex(), sR.serialize().hex(), sF.serialize().hex()] == [n["sig_L"], n["sig_R"], n["sig_final"]]
+    info = sF.aggregation_info
+    tree = [[h.hex(), pk.serialize().hex(), hex(info.tree[(h, pk)])] for h, pk in zip(info.message_hashes, info.public_keys)]
+    assert tree == n["final_tree"]
+    assert BLS.verify(sL) and BLS.verify(sR) and BLS.verify(sF)
+    quo = sF.divide_by([s2, s5, s6])
+    assert quo.serialize().hex() == n["quotient"] and BLS.verify(quo) and BLS.verify(sF)
+    assert quo.divide_by([]) == quo
+    with pytest.raises(Exception):
+        quo.divide_by([s6])               # not a subset any more
+    sF.divide_by([s1])                    # fine
+    with pytest.raises(Exception):
+        sF.divide_by([sL])                # not unique
+
+
+def test_verify4_inputs_match_reference(golden):
+    """C1: the exact (Ps, Qs) byte strings BLS.verify sends to the pairing."""
+    from bls_py import backend
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    v = golden("verify4.json")
+    sks = [PrivateKey.from_seed(bytes.fromhex(s)) for s in v["seeds"]]
+    assert [sk.serialize().hex() for sk in sks] == v["sk"]
+    assert [sk.get_public_key().serialize().hex() for sk in sks] == v["pk"]
+    sigs = [sk.sign(bytes.fromhex(m)) for sk, m in zip(sks, v["msgs"])]
+    assert [s.serialize().hex() for s in sigs] == v["sig"]
+    agg = BLS.aggregate_sigs(sigs)
+    assert agg.serialize().hex() == v["agg_sig"]
+    seen = {}
+    inner = backend.get()
+
+    class Spy:
+        def pairing_multi(self, g1, g2, n):
+            seen["g1"], seen["g2"], seen["n"] = g1, g2, n
+            return inner.pairing_multi(g1, g2, n)
+    backend.use(Spy())
+    try:
+        assert BLS.verify(agg) is True
+    finally:
+        backend.use(inner)
+    assert seen["n"] == 5 and seen["g1"][:96] == bytes.fromhex(v["pairing_g1"][0])
+    assert seen["g2"][:192] == bytes.fromhex(v["pairing_g2"][0])
+    # the order of the per-message pairs follows dict insertion = sorted (mh, pk)
+    assert sorted(seen["g1"][96 * i:96 * (i + 1)].hex() for i in range(1, 5)) == sorted(v["pairing_g1"][1:])
+    bad = BLS.aggregate_sigs(sigs[:3])
+    bad.set_aggregation_info(agg.aggregation_info)
+    assert bad.serialize().hex() == v["tampered_sig"] and BLS.verify(bad) is False
+
+
+def test_threshold_vectors(golden):
+    from bls_py.keys import PrivateKey
+    from bls_py.signature import Signature
+    from bls_py.threshold import Threshold
+    rec = golden("threshold.json")["3_of_5"]
+    players = rec["players"]
+    lam = Threshold.lagrange_coeffs_at_zero(players)
+    assert [hex(int(x)) for x in lam] == rec["lambdas"]
+    shares = [int(s, 16) for s in rec["shares"]]
+    assert int(Threshold.interpolate_at_zero(players, shares)) == int(rec["poly"][0], 16)
+    msg = bytes.fromhex(rec["msg"])
+    unit = [PrivateKey(s).sign(msg) for s in shares]
+    assert [u.serialize().hex() for u in unit] == rec["unit_sigs"]
+    comb = Threshold.aggregate_unit_sigs(unit, players, rec["T"])
+    assert comb.serialize().hex() == rec["combined"]
+    big = golden("threshold.json")["67_of_100"]
+    lam = Threshold.lagrange_coeffs_at_zero(big["players"])
+    assert [hex(int(x)) for x in lam] == big["lambdas"]
+    sigs = [Signature.from_bytes(bytes.fromhex(s)) for s in big["unit_sigs"][:4]]
+    assert [s.serialize().hex() for s in sigs] == big["unit_sigs"][:4]
+
+
+def test_aggregate_pub_keys_vectors(golden):
+    from bls_py.bls import BLS
+    from bls_py.keys import PublicKey
+    from bls_py.ec import JacobianPoint
+    from bls_py import hostmath as H
+    rec = golden("msm.json")["16"]
+    pks = [PublicKey(JacobianPoint._from(H.F1, H.aff_to_jac(H.F1, H.g1_from_abi(bytes.fromhex(p)))))
+           for p in rec["pk_affine"]]
+    lst = list(pks)
+    sec = BLS.aggregate_pub_keys(lst, True)
+    assert [pk.serialize().hex() for pk in lst] == rec["sorted_ser"]        # sorted in place (bls.py:210)
+    assert sec.serialize().hex() == rec["secure"]
+    assert BLS.aggregate_pub_keys(list(pks), False).serialize().hex() == rec["simple"]
+    with pytest.raises(Exception):
+        BLS.aggregate_pub_keys([], True)
