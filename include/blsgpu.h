@@ -73,6 +73,15 @@ int blsgpu_final_exp_product_dev(blsgpu_ctx *ctx, const void *d_partials, size_t
 int blsgpu_final_exp(blsgpu_ctx *ctx, const uint8_t in[BLSGPU_FQ12_BYTES],
                      uint8_t out[BLSGPU_FQ12_BYTES]);
 
+/* Measurement aid (bench.py): when enabled, HIP events are recorded on the
+ * launch stream around every kernel this context launches (up to 1024 launches
+ * between reads).  blsgpu_timing_read waits for them and returns, per launch,
+ * the duration in ms and the kernel kind: 0 = k_miller (Miller loops + workgroup
+ * product), 1 = k_reduce (partial products), 2 = k_reduce with the final
+ * exponentiation.  Reading resets the ring. */
+int blsgpu_timing_enable(blsgpu_ctx *ctx, int enable);
+int blsgpu_timing_read(blsgpu_ctx *ctx, float *ms, int *kind, size_t cap, size_t *count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ SYMBOLS = (
     "blsgpu_version", "blsgpu_last_error", "blsgpu_ctx_create", "blsgpu_ctx_destroy",
     "blsgpu_ctx_reserve", "blsgpu_pairing_multi", "blsgpu_pairing_multi_dev",
     "blsgpu_miller_product_dev", "blsgpu_final_exp_product_dev", "blsgpu_final_exp",
+    "blsgpu_timing_enable", "blsgpu_timing_read",
 )
 
 _lib = None
@@ -57,6 +58,9 @@ def load_library(path=None):
         L.blsgpu_miller_product_dev.argtypes = [vp, vp, vp, sz, vp, vp]
         L.blsgpu_final_exp_product_dev.argtypes = [vp, vp, sz, vp, vp]
         L.blsgpu_final_exp.argtypes = [vp, cp, cp]
+        L.blsgpu_timing_enable.argtypes = [vp, ctypes.c_int]
+        L.blsgpu_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), sz,
+                                         ctypes.POINTER(sz)]
         _lib = L
         return L
 
@@ -108,6 +112,19 @@ class Engine:
         out = ctypes.create_string_buffer(576)
         self._check(self.lib.blsgpu_final_exp(self.h, x, out), "blsgpu_final_exp")
         return out.raw
+
+    def timing_enable(self, on=True):
+        self._check(self.lib.blsgpu_timing_enable(self.h, int(on)), "blsgpu_timing_enable")
+
+    def timing_read(self):
+        """[(kind, ms)] for every kernel launched since the last read; kinds:
+        0 k_miller, 1 k_reduce, 2 k_reduce + final exponentiation."""
+        cap = 1024
+        ms = (ctypes.c_float * cap)()
+        kind = (ctypes.c_int * cap)()
+        cnt = ctypes.c_size_t(0)
+        self._check(self.lib.blsgpu_timing_read(self.h, ms, kind, cap, ctypes.byref(cnt)), "blsgpu_timing_read")
+        return [(kind[i], ms[i]) for i in range(cnt.value)]
 
     # device-pointer forms (integers: tensor.data_ptr(), stream.cuda_stream)
     def pairing_multi_dev(self, d_g1, d_g2, n, d_out, stream=0):

@@ -42,7 +42,29 @@ struct blsgpu_ctx {
     void* d_io = nullptr;              // staging for the host-buffer entry points
     size_t io_cap = 0;
     uint32_t* d_out = nullptr;         // 576-byte result staging
+    // optional per-kernel timing (blsgpu_timing_enable): HIP events recorded on
+    // the launch stream around every kernel, ring of TIMING_SLOTS launches
+    bool timing = false;
+    static constexpr int TIMING_SLOTS = 1024;
+    hipEvent_t* ev0 = nullptr;
+    hipEvent_t* ev1 = nullptr;
+    int* ev_kind = nullptr;            // 0 k_miller, 1 k_reduce, 2 k_reduce with final exponentiation
+    size_t ev_count = 0;
 };
+
+namespace {
+struct KernelTimer {
+    blsgpu_ctx* c; hipStream_t st; int slot;
+    KernelTimer(blsgpu_ctx* c_, hipStream_t st_, int kind) : c(c_), st(st_), slot(-1) {
+        if (c->timing && c->ev_count < (size_t)blsgpu_ctx::TIMING_SLOTS) {
+            slot = (int)c->ev_count++;
+            c->ev_kind[slot] = kind;
+            (void)hipEventRecord(c->ev0[slot], st);
+        }
+    }
+    ~KernelTimer() { if (slot >= 0) (void)hipEventRecord(c->ev1[slot], st); }
+};
+}  // namespace
 
 static size_t n_blocks_miller(size_t n) { return (n + MILLER_WAVES - 1) / MILLER_WAVES; }
 
@@ -142,7 +164,39 @@ BLSGPU_EXPORT void blsgpu_ctx_destroy(blsgpu_ctx* c) {
         if (c->d_part[i]) (void)hipFree(c->d_part[i]);
     if (c->d_io) (void)hipFree(c->d_io);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->ev0) {
+        for (int i = 0; i < blsgpu_ctx::TIMING_SLOTS; i++) { (void)hipEventDestroy(c->ev0[i]); (void)hipEventDestroy(c->ev1[i]); }
+        delete[] c->ev0; delete[] c->ev1; delete[] c->ev_kind;
+    }
     delete c;
+}
+
+BLSGPU_EXPORT int blsgpu_timing_enable(blsgpu_ctx* c, int enable) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (enable && !c->ev0) {
+        c->ev0 = new hipEvent_t[blsgpu_ctx::TIMING_SLOTS];
+        c->ev1 = new hipEvent_t[blsgpu_ctx::TIMING_SLOTS];
+        c->ev_kind = new int[blsgpu_ctx::TIMING_SLOTS];
+        for (int i = 0; i < blsgpu_ctx::TIMING_SLOTS; i++) { HIP_TRY(hipEventCreate(&c->ev0[i])); HIP_TRY(hipEventCreate(&c->ev1[i])); }
+    }
+    c->timing = enable != 0;
+    c->ev_count = 0;
+    return 0;
+}
+
+BLSGPU_EXPORT int blsgpu_timing_read(blsgpu_ctx* c, float* ms, int* kind, size_t cap, size_t* count) {
+    if (!c || !count) return fail(-EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t n = c->ev_count < cap ? c->ev_count : cap;
+    for (size_t i = 0; i < n; i++) {
+        HIP_TRY(hipEventSynchronize(c->ev1[i]));
+        HIP_TRY(hipEventElapsedTime(&ms[i], c->ev0[i], c->ev1[i]));
+        kind[i] = c->ev_kind[i];
+    }
+    *count = n;
+    c->ev_count = 0;
+    return 0;
 }
 
 BLSGPU_EXPORT int blsgpu_ctx_reserve(blsgpu_ctx* c, size_t max_pairs) {
@@ -165,9 +219,12 @@ static int reduce_chain(blsgpu_ctx* c, const uint32_t* d_in, size_t m, bool do_f
         bool last = blocks == 1;
         uint32_t* dst = last ? d_out_partial : c->d_part[pp];
         if (!last && blocks > c->part_cap) return fail(-ENOMEM, "workspace too small; call blsgpu_ctx_reserve");
-        hipLaunchKernelGGL(blsgpu::k_reduce, dim3((unsigned)blocks), dim3(REDUCE_WAVES * 64), lds, st, c->tabs, src,
-                           (uint32_t)m, (uint32_t)REDUCE_PER_BLOCK, dst, (uint32_t)(last && do_final ? 1 : 0),
-                           (uint32_t*)d_out_bytes);
+        {
+            KernelTimer kt(c, st, (last && do_final) ? 2 : 1);
+            hipLaunchKernelGGL(blsgpu::k_reduce, dim3((unsigned)blocks), dim3(REDUCE_WAVES * 64), lds, st, c->tabs, src,
+                               (uint32_t)m, (uint32_t)REDUCE_PER_BLOCK, dst, (uint32_t)(last && do_final ? 1 : 0),
+                               (uint32_t*)d_out_bytes);
+        }
         HIP_TRY(hipGetLastError());
         if (last) break;
         src = dst;
@@ -181,8 +238,11 @@ static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size
                          hipStream_t st) {
     size_t blocks = n_blocks_miller(n);
     size_t lds = (size_t)MILLER_WAVES * blsgpu::TEAM_BYTES;
-    hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)blocks), dim3(MILLER_WAVES * 64), lds, st, c->tabs,
-                       (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, d_partials);
+    {
+        KernelTimer kt(c, st, 0);
+        hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)blocks), dim3(MILLER_WAVES * 64), lds, st, c->tabs,
+                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, d_partials);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
