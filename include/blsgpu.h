@@ -73,6 +73,24 @@ int blsgpu_final_exp_product_dev(blsgpu_ctx *ctx, const void *d_partials, size_t
 int blsgpu_final_exp(blsgpu_ctx *ctx, const uint8_t in[BLSGPU_FQ12_BYTES],
                      uint8_t out[BLSGPU_FQ12_BYTES]);
 
+/* Multi-scalar sums  out[g] = sum_{i<k} scalars[g*k+i] * pts[g*k+i]  for `groups`
+ * independent groups of k points: the loops of BLS.aggregate_pub_keys
+ * (bls.py:203-223, G1), BLS.aggregate_sigs* (bls.py:12-151, G2) and
+ * Threshold.aggregate_unit_sigs (threshold.py:127-136, G2), i.e. the reference's
+ * fq_/fq2_scalar_mult_jacobian + *_add_points_jacobian (fields_t.py:705-875).
+ * pts: affine big-endian coordinates (96 B per G1 point, 192 B per G2 point,
+ * (0,0) = infinity); scalars: 32 bytes big-endian each, or NULL for plain sums;
+ * out: affine bytes per group ((0,0) for infinity); out_inf (may be NULL): 1 if
+ * the group's sum is the point at infinity. */
+int blsgpu_g1_msm(blsgpu_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, size_t k,
+                  size_t groups, uint8_t *out, uint8_t *out_inf);
+int blsgpu_g2_msm(blsgpu_ctx *ctx, const uint8_t *pts, const uint8_t *scalars, size_t k,
+                  size_t groups, uint8_t *out, uint8_t *out_inf);
+int blsgpu_g1_msm_dev(blsgpu_ctx *ctx, const void *d_pts, const void *d_scalars, size_t k,
+                      size_t groups, void *d_out, void *d_out_inf, void *stream);
+int blsgpu_g2_msm_dev(blsgpu_ctx *ctx, const void *d_pts, const void *d_scalars, size_t k,
+                      size_t groups, void *d_out, void *d_out_inf, void *stream);
+
 /* Measurement aid (bench.py): when enabled, HIP events are recorded on the
  * launch stream around every kernel this context launches (up to 1024 launches
  * between reads).  blsgpu_timing_read waits for them and returns, per launch,

@@ -16,6 +16,7 @@ SYMBOLS = (
     "blsgpu_ctx_reserve", "blsgpu_pairing_multi", "blsgpu_pairing_multi_dev",
     "blsgpu_miller_product_dev", "blsgpu_final_exp_product_dev", "blsgpu_final_exp",
     "blsgpu_timing_enable", "blsgpu_timing_read",
+    "blsgpu_g1_msm", "blsgpu_g2_msm", "blsgpu_g1_msm_dev", "blsgpu_g2_msm_dev",
 )
 
 _lib = None
@@ -58,6 +59,10 @@ def load_library(path=None):
         L.blsgpu_miller_product_dev.argtypes = [vp, vp, vp, sz, vp, vp]
         L.blsgpu_final_exp_product_dev.argtypes = [vp, vp, sz, vp, vp]
         L.blsgpu_final_exp.argtypes = [vp, cp, cp]
+        for f in (L.blsgpu_g1_msm, L.blsgpu_g2_msm):
+            f.argtypes = [vp, cp, cp, sz, sz, cp, cp]
+        for f in (L.blsgpu_g1_msm_dev, L.blsgpu_g2_msm_dev):
+            f.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp]
         L.blsgpu_timing_enable.argtypes = [vp, ctypes.c_int]
         L.blsgpu_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), sz,
                                          ctypes.POINTER(sz)]
@@ -112,6 +117,28 @@ class Engine:
         out = ctypes.create_string_buffer(576)
         self._check(self.lib.blsgpu_final_exp(self.h, x, out), "blsgpu_final_exp")
         return out.raw
+
+    def _msm(self, fn, psz, pts, scalars, k, groups):
+        n = k * groups
+        if len(pts) != psz * n:
+            raise ValueError("point buffer length does not match k * groups")
+        sb = None
+        if scalars is not None:
+            sb = scalars if isinstance(scalars, (bytes, bytearray)) else b"".join(int(s).to_bytes(32, "big") for s in scalars)
+            if len(sb) != 32 * n:
+                raise ValueError("scalar buffer length does not match k * groups")
+            sb = bytes(sb)
+        out = ctypes.create_string_buffer(psz * groups)
+        inf = ctypes.create_string_buffer(max(1, groups))
+        self._check(fn(self.h, bytes(pts), sb, k, groups, out, inf), fn.__name__)
+        return out.raw, [bool(b) for b in inf.raw[:groups]]
+
+    def g1_msm(self, pts, scalars, k, groups=1):
+        """-> (groups x 96 affine bytes, [is_infinity])"""
+        return self._msm(self.lib.blsgpu_g1_msm, 96, pts, scalars, k, groups)
+
+    def g2_msm(self, pts, scalars, k, groups=1):
+        return self._msm(self.lib.blsgpu_g2_msm, 192, pts, scalars, k, groups)
 
     def timing_enable(self, on=True):
         self._check(self.lib.blsgpu_timing_enable(self.h, int(on)), "blsgpu_timing_enable")

@@ -11,6 +11,7 @@
 
 #include "../../include/blsgpu.h"
 #include "blsgpu_kernels.hip"
+#include "blsgpu_msm.hip"
 
 namespace {
 
@@ -42,6 +43,8 @@ struct blsgpu_ctx {
     void* d_io = nullptr;              // staging for the host-buffer entry points
     size_t io_cap = 0;
     uint32_t* d_out = nullptr;         // 576-byte result staging
+    uint32_t* d_msm_part = nullptr;    // MSM partials
+    size_t msm_part_cap = 0;           // in u32
     // optional per-kernel timing (blsgpu_timing_enable): HIP events recorded on
     // the launch stream around every kernel, ring of TIMING_SLOTS launches
     bool timing = false;
@@ -81,6 +84,83 @@ static int ensure_workspace(blsgpu_ctx* c, size_t max_pairs) {
     }
     return 0;
 }
+
+// ---------------------------------------------------------------- MSM -------
+namespace {
+constexpr int MSM_WAVES = 4;
+
+template <int DEG>
+int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, size_t groups, void* d_out,
+            void* d_out_inf, hipStream_t st) {
+    using C = blsgpu::MsmCfg<DEG>;
+    if (groups == 0) return 0;
+    if (k == 0) {                                   // empty sums: infinity
+        HIP_TRY(hipMemsetAsync(d_out, 0, groups * 96 * DEG, st));
+        if (d_out_inf) HIP_TRY(hipMemsetAsync(d_out_inf, 1, groups, st));
+        return 0;
+    }
+    if (k > 0x7FFFFFFFull || groups > 0x7FFFFFFFull || k * groups > 0xFFFFFFF0ull) return fail(-EINVAL, "msm too large");
+    // points per block: whole group when small, else chunks that give >= ~2k blocks
+    size_t per_pass = (size_t)MSM_WAVES * C::NP;
+    size_t chunk = k;
+    if (groups < 1024 && k > 4 * per_pass) {
+        size_t want_blocks = 2048 / groups + 1;
+        chunk = (k + want_blocks - 1) / want_blocks;
+        chunk = ((chunk + per_pass - 1) / per_pass) * per_pass;
+        if (chunk > k) chunk = k;
+    }
+    size_t bpg = (k + chunk - 1) / chunk;
+    size_t blocks = bpg * groups;
+    size_t need = blocks * 36 * DEG;
+    if (need > c->msm_part_cap) {
+        if (c->d_msm_part) (void)hipFree(c->d_msm_part);
+        c->d_msm_part = nullptr;
+        c->msm_part_cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_msm_part, need * sizeof(uint32_t)));
+        c->msm_part_cap = need;
+    }
+    size_t lds = (size_t)MSM_WAVES * blsgpu::TEAM_BYTES;
+    hipLaunchKernelGGL(blsgpu::k_msm<DEG>, dim3((unsigned)blocks), dim3(MSM_WAVES * 64), lds, st, c->tabs,
+                       (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, (uint32_t)bpg,
+                       c->d_msm_part);
+    HIP_TRY(hipGetLastError());
+    size_t fblocks = (groups + MSM_WAVES - 1) / MSM_WAVES;
+    hipLaunchKernelGGL(blsgpu::k_msm_finish<DEG>, dim3((unsigned)fblocks), dim3(MSM_WAVES * 64), lds, st, c->tabs,
+                       c->d_msm_part, (uint32_t)bpg, (uint32_t)groups, (uint32_t*)d_out, (uint8_t*)d_out_inf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int DEG>
+int msm_host(blsgpu_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t k, size_t groups, uint8_t* out,
+             uint8_t* out_inf) {
+    if (!c || !out) return fail(-EINVAL, "NULL argument");
+    size_t n = k * groups;
+    if (n && !pts) return fail(-EINVAL, "NULL point buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t pb = n * 96 * DEG, sb = scalars ? n * 32 : 0, ob = groups * 96 * DEG;
+    size_t need = pb + sb + ob + groups + 64;
+    if (need > c->io_cap) {
+        if (c->d_io) (void)hipFree(c->d_io);
+        c->d_io = nullptr;
+        c->io_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_io, need));
+        c->io_cap = need;
+    }
+    char* dp = (char*)c->d_io;
+    char* ds = dp + pb;
+    char* dout = ds + ((sb + 15) & ~size_t(15));
+    char* dinf = dout + ob;
+    if (pb) HIP_TRY(hipMemcpyAsync(dp, pts, pb, hipMemcpyHostToDevice, 0));
+    if (sb) HIP_TRY(hipMemcpyAsync(ds, scalars, sb, hipMemcpyHostToDevice, 0));
+    int rc = msm_dev<DEG>(c, dp, scalars ? ds : nullptr, k, groups, dout, dinf, 0);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost));
+    if (out_inf) HIP_TRY(hipMemcpy(out_inf, dinf, groups, hipMemcpyDeviceToHost));
+    return 0;
+}
+}  // namespace
+
 
 #define BLSGPU_EXPORT __attribute__((visibility("default")))
 
@@ -147,6 +227,10 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
                               MILLER_WAVES * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize,
                               REDUCE_WAVES * blsgpu::TEAM_BYTES);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_msm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * blsgpu::TEAM_BYTES);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_msm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * blsgpu::TEAM_BYTES);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_msm_finish<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * blsgpu::TEAM_BYTES);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_msm_finish<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * blsgpu::TEAM_BYTES);
     int rc = ensure_workspace(c, 4096);
     if (rc) {
         blsgpu_ctx_destroy(c);
@@ -164,6 +248,7 @@ BLSGPU_EXPORT void blsgpu_ctx_destroy(blsgpu_ctx* c) {
         if (c->d_part[i]) (void)hipFree(c->d_part[i]);
     if (c->d_io) (void)hipFree(c->d_io);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_msm_part) (void)hipFree(c->d_msm_part);
     if (c->ev0) {
         for (int i = 0; i < blsgpu_ctx::TIMING_SLOTS; i++) { (void)hipEventDestroy(c->ev0[i]); (void)hipEventDestroy(c->ev1[i]); }
         delete[] c->ev0; delete[] c->ev1; delete[] c->ev_kind;
@@ -352,6 +437,27 @@ BLSGPU_EXPORT int blsgpu_final_exp(blsgpu_ctx* c, const uint8_t in[576], uint8_t
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, c->d_out, 576, hipMemcpyDeviceToHost));
     return 0;
+}
+
+BLSGPU_EXPORT int blsgpu_g1_msm(blsgpu_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t k, size_t groups,
+                                uint8_t* out, uint8_t* out_inf) {
+    return msm_host<1>(c, pts, scalars, k, groups, out, out_inf);
+}
+BLSGPU_EXPORT int blsgpu_g2_msm(blsgpu_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t k, size_t groups,
+                                uint8_t* out, uint8_t* out_inf) {
+    return msm_host<2>(c, pts, scalars, k, groups, out, out_inf);
+}
+BLSGPU_EXPORT int blsgpu_g1_msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, size_t groups,
+                                    void* d_out, void* d_out_inf, void* stream) {
+    if (!c || !d_out) return fail(-EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return msm_dev<1>(c, d_pts, d_scalars, k, groups, d_out, d_out_inf, (hipStream_t)stream);
+}
+BLSGPU_EXPORT int blsgpu_g2_msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, size_t groups,
+                                    void* d_out, void* d_out_inf, void* stream) {
+    if (!c || !d_out) return fail(-EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return msm_dev<2>(c, d_pts, d_scalars, k, groups, d_out, d_out_inf, (hipStream_t)stream);
 }
 
 #ifdef BLSGPU_STAMPS

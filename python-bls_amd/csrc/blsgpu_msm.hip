@@ -1,0 +1,183 @@
+// blsgpu_msm.hip -- G1 / G2 scalar multiplication and multi-scalar sums on the
+// same wavefront-team VM as the pairing (included by blsgpu_api.hip).
+//
+// Replaces the reference's fq_scalar_mult_jacobian / fq2_scalar_mult_jacobian
+// + *_add_points_jacobian loops (fields_t.py:705-740, 762-875; native
+// fields_t_c.pyx:1368-1413) as used by BLS.aggregate_pub_keys (bls.py:203-223),
+// aggregate_sigs* (bls.py:12-151) and Threshold.aggregate_unit_sigs
+// (threshold.py:127-136).  Same LSB-first double-and-add; complete projective
+// formulas (vmgen/msm_programs.py); parity on the affine output.
+#pragma once
+
+namespace blsgpu {
+
+template <int DEG> struct MsmCfg;
+template <> struct MsmCfg<1> {
+    static constexpr int NP = BLSVM_MSM1_NP, IN = BLSVM_MSM1_IN, R = BLSVM_MSM1_R, A = BLSVM_MSM1_A,
+                         S = BLSVM_MSM1_S, PR0 = BLSVM_MSM1_PR0, PR1 = BLSVM_MSM1_PR1, OUT = BLSVM_MSM1_OUT;
+    static constexpr int LOAD_OFF = BLSVM_SEGF_G1_LOAD_OFF, LOAD_LEN = BLSVM_SEGF_G1_LOAD_LEN,
+                         STEP_OFF = BLSVM_SEGF_G1_STEP_OFF, STEP_LEN = BLSVM_SEGF_G1_STEP_LEN,
+                         FOLD_OFF = BLSVM_SEGF_G1_FOLD_OFF, FOLD_LEN = BLSVM_SEGF_G1_FOLD_LEN,
+                         PADD_OFF = BLSVM_SEGF_G1_PADD_OFF, PADD_LEN = BLSVM_SEGF_G1_PADD_LEN,
+                         AFF_OFF = BLSVM_SEGF_G1_AFFINE_OFF, AFF_LEN = BLSVM_SEGF_G1_AFFINE_LEN;
+};
+template <> struct MsmCfg<2> {
+    static constexpr int NP = BLSVM_MSM2_NP, IN = BLSVM_MSM2_IN, R = BLSVM_MSM2_R, A = BLSVM_MSM2_A,
+                         S = BLSVM_MSM2_S, PR0 = BLSVM_MSM2_PR0, PR1 = BLSVM_MSM2_PR1, OUT = BLSVM_MSM2_OUT;
+    static constexpr int LOAD_OFF = BLSVM_SEGF_G2_LOAD_OFF, LOAD_LEN = BLSVM_SEGF_G2_LOAD_LEN,
+                         STEP_OFF = BLSVM_SEGF_G2_STEP_OFF, STEP_LEN = BLSVM_SEGF_G2_STEP_LEN,
+                         FOLD_OFF = BLSVM_SEGF_G2_FOLD_OFF, FOLD_LEN = BLSVM_SEGF_G2_FOLD_LEN,
+                         PADD_OFF = BLSVM_SEGF_G2_PADD_OFF, PADD_LEN = BLSVM_SEGF_G2_PADD_LEN,
+                         AFF_OFF = BLSVM_SEGF_G2_AFFINE_OFF, AFF_LEN = BLSVM_SEGF_G2_AFFINE_LEN;
+};
+
+// dword k (0 .. 36*DEG-1) of the projective point at infinity (0 : 1 : 0), Montgomery
+template <int DEG>
+__device__ __forceinline__ uint32_t inf_dword(const uint32_t* team, uint32_t k) {
+    return (k >= 12u * DEG && k < 12u * DEG + 12u) ? team[BLSVM_SLOT_C_ONE * 12 + (k - 12u * DEG)] : 0u;
+}
+
+// Kernel A: block b handles points [lo, hi) of group g = b / bpg (chunk b % bpg of
+// `chunk` points); its teams walk them NP at a time; output: one projective
+// Montgomery partial (36*DEG u32) per block.
+//   pts:     affine big-endian coordinates, 96*DEG bytes per point ((0,0) = infinity)
+//   scalars: 32 bytes big-endian per point, or nullptr for all-ones (plain sums)
+template <int DEG>
+__global__ void __launch_bounds__(256) k_msm(VmTables T, const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars,
+                                             uint32_t k, uint32_t chunk, uint32_t bpg, uint32_t* __restrict__ partials) {
+    using C = MsmCfg<DEG>;
+    constexpr uint32_t PT_DW = 24 * DEG;            // dwords per affine input point
+    constexpr uint32_t PJ_DW = 36 * DEG;            // dwords per projective point
+    uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwaves = blockDim.x >> 6;
+    uint32_t* team = smem + wave * TEAM_DW;
+    const uint32_t base16 = wave * (TEAM_BYTES / 16);
+    const uint32_t g = blockIdx.x / bpg, cidx = blockIdx.x % bpg;
+    const uint32_t lo = g * k + cidx * chunk;
+    const uint32_t hi = min(g * k + k, lo + chunk);
+    team_init_consts(T, team, lane);
+    wave_fence();
+    for (uint32_t d = lane; d < C::NP * PJ_DW; d += 64) team[C::R * 12 + d] = inf_dword<DEG>(team, d % PJ_DW);
+    wave_fence();
+    for (uint32_t first = lo + wave * C::NP; first < hi; first += nwaves * C::NP) {
+        const uint32_t cnt = min((uint32_t)C::NP, hi - first);
+        // raw coordinates -> IN slots (limb order reversed, bytes swapped)
+        for (uint32_t d = lane; d < C::NP * PT_DW; d += 64) {
+            uint32_t p = d / PT_DW, o = d % PT_DW, e = o / 12, w = o % 12;
+            uint32_t v = (p < cnt) ? bswap32(pts[(size_t)(first + p) * PT_DW + o]) : 0u;
+            team[(C::IN + p * 2 * DEG + e) * 12 + (11 - w)] = v;
+        }
+        // this lane's scalar (lanes 0..NP-1), little-endian words
+        uint32_t sw[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t v = 0;
+            if (lane < cnt) v = scalars ? bswap32(scalars[(size_t)(first + lane) * 8 + (7 - j)]) : (j == 0 ? 1u : 0u);
+            sw[j] = v;
+        }
+        wave_fence();
+        run_rounds(T, T.segflat + C::LOAD_OFF, C::LOAD_LEN, base16, lane);
+        // (0,0) inputs are the point at infinity
+        uint32_t zero_in = 0;
+        if (lane < C::NP) {
+            uint32_t acc = 0;
+            for (uint32_t i = 0; i < 2u * DEG * 12u; i++) acc |= team[(C::IN + lane * 2 * DEG) * 12 + i];
+            zero_in = (acc == 0u);
+        }
+        const uint64_t zmask = __ballot(zero_in != 0);
+        for (uint32_t d = lane; d < C::NP * PJ_DW; d += 64) {
+            uint32_t p = d / PJ_DW;
+            if ((zmask >> p) & 1ull) team[C::A * 12 + d] = inf_dword<DEG>(team, d % PJ_DW);
+        }
+        // number of scalar bits to walk (wave-uniform)
+        uint32_t bl = 0;
+#pragma unroll
+        for (int j = 7; j >= 0; j--)
+            if (bl == 0 && sw[j] != 0) bl = 32u * j + (32u - __builtin_clz(sw[j]));
+        for (int off = 32; off > 0; off >>= 1) bl = max(bl, (uint32_t)__shfl_xor((int)bl, off));
+        bl = __builtin_amdgcn_readfirstlane(bl);
+        wave_fence();
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) {
+            const uint32_t word = sw[j];
+#pragma unroll 1
+            for (uint32_t b = 0; b < 32; b++) {
+                const uint32_t bit = 32u * j + b;
+                if (bit >= bl) break;
+                const uint64_t bits = __ballot(lane < (uint32_t)C::NP && ((word >> b) & 1u));
+                // S_p = bit ? A_p : infinity
+                for (uint32_t d = lane; d < C::NP * PJ_DW; d += 64) {
+                    uint32_t p = d / PJ_DW;
+                    team[C::S * 12 + d] = ((bits >> p) & 1ull) ? team[C::A * 12 + d] : inf_dword<DEG>(team, d % PJ_DW);
+                }
+                wave_fence();
+                run_rounds(T, T.segflat + C::STEP_OFF, C::STEP_LEN, base16, lane);
+            }
+            if (32u * (j + 1) >= bl) break;
+        }
+    }
+    wave_fence();
+    run_rounds(T, T.segflat + C::FOLD_OFF, C::FOLD_LEN, base16, lane);
+    // product tree over the teams of the workgroup
+    for (uint32_t s = 1; s < nwaves; s <<= 1) {
+        __syncthreads();
+        if ((wave % (2 * s)) == 0 && wave + s < nwaves) {
+            const uint32_t* other = smem + (wave + s) * TEAM_DW + C::PR0 * 12;
+            for (uint32_t i = lane; i < PJ_DW; i += 64) team[C::PR1 * 12 + i] = other[i];
+            wave_fence();
+            run_rounds(T, T.segflat + C::PADD_OFF, C::PADD_LEN, base16, lane);
+        }
+    }
+    if (wave == 0) {
+        wave_fence();
+        for (uint32_t i = lane; i < PJ_DW; i += 64) partials[(size_t)blockIdx.x * PJ_DW + i] = team[C::PR0 * 12 + i];
+    }
+}
+
+// Kernel B: one team per group: sum of the group's bpg partials, conversion to
+// affine canonical bytes (x || y, (0,0) for infinity) and an infinity flag.
+template <int DEG>
+__global__ void __launch_bounds__(256) k_msm_finish(VmTables T, const uint32_t* __restrict__ partials, uint32_t bpg,
+                                                    uint32_t groups, uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf) {
+    using C = MsmCfg<DEG>;
+    constexpr uint32_t PJ_DW = 36 * DEG;
+    constexpr uint32_t PT_DW = 24 * DEG;
+    uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwaves = blockDim.x >> 6;
+    uint32_t* team = smem + wave * TEAM_DW;
+    const uint32_t base16 = wave * (TEAM_BYTES / 16);
+    const uint32_t g = blockIdx.x * nwaves + wave;
+    if (g >= groups) return;                     // no workgroup barrier below
+    team_init_consts(T, team, lane);
+    wave_fence();
+    for (uint32_t i = 0; i < bpg; i++) {
+        const uint32_t* src = partials + ((size_t)g * bpg + i) * PJ_DW;
+        const uint32_t dst = (i == 0) ? C::PR0 : C::PR1;
+        for (uint32_t d = lane; d < PJ_DW; d += 64) team[dst * 12 + d] = src[d];
+        wave_fence();
+        if (i) run_rounds(T, T.segflat + C::PADD_OFF, C::PADD_LEN, base16, lane);
+    }
+    run_rounds(T, T.segflat + C::AFF_OFF, C::AFF_LEN, base16, lane);
+    if (lane < 2u * DEG) {
+        uint32_t X[12];
+        lds_load12(X, base16 + (C::OUT + lane) * 3);
+        bls::fq_canon(X);
+        lds_store12(X, base16 + (C::OUT + lane) * 3);
+    }
+    wave_fence();
+    uint32_t any = 0;
+    for (uint32_t d = lane; d < PT_DW; d += 64) {
+        uint32_t e = d / 12, w = d % 12;
+        uint32_t v = team[(C::OUT + e) * 12 + (11 - w)];
+        any |= v;
+        out[(size_t)g * PT_DW + d] = bswap32(v);
+    }
+    const uint64_t nz = __ballot(any != 0);
+    if (out_inf && lane == 0) out_inf[g] = (nz == 0) ? 1 : 0;
+}
+
+}  // namespace blsgpu

@@ -1,0 +1,109 @@
+"""G1 / G2 multi-scalar sums on the GPU (blsgpu_g1_msm / blsgpu_g2_msm through the
+C ABI) against reference vectors and the CPU oracle.  Bit-exact affine bytes."""
+import hashlib
+import random
+
+import pytest
+
+from conftest import cat
+
+pytestmark = pytest.mark.gpu
+N = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+
+def prf(tag, seed, i):
+    h = hashlib.sha256(tag + seed.to_bytes(4, "big") + i.to_bytes(4, "big")).digest()
+    return int.from_bytes(h, "big") % (N - 1) + 1
+
+
+def test_scalar_multiples_of_generators(engine, golden):
+    p = golden("points.json")
+    g1, g2 = bytes.fromhex(p["g1"][0]["p"]), bytes.fromhex(p["g2"][0]["p"])
+    ks = [int(r["k"], 16) for r in p["g1"]]
+    out, inf = engine.g1_msm(g1 * len(ks), ks, 1, len(ks))           # len(ks) groups of one point
+    assert out.hex() == "".join(r["p"] for r in p["g1"]) and not any(inf)
+    out, inf = engine.g2_msm(g2 * len(ks), ks, 1, len(ks))
+    assert out.hex() == "".join(r["p"] for r in p["g2"]) and not any(inf)
+    a = p["g1_add"]
+    assert engine.g1_msm(bytes.fromhex(a["a"] + a["b"]), None, 2)[0].hex() == a["sum"]
+    assert engine.g1_msm(bytes.fromhex(a["a"] + a["a"]), None, 2)[0].hex() == a["dbl"]      # doubling inside add
+    a = p["g2_add"]
+    assert engine.g2_msm(bytes.fromhex(a["a"] + a["b"]), None, 2)[0].hex() == a["sum"]
+    assert engine.g2_msm(bytes.fromhex(a["a"] + a["a"]), None, 2)[0].hex() == a["dbl"]
+
+
+def test_infinity_and_degenerate_cases(engine, golden):
+    p = golden("points.json")
+    P = bytes.fromhex(p["g1"][3]["p"])
+    negP = P[:48] + ((Q - int.from_bytes(P[48:], "big")) % Q).to_bytes(48, "big")
+    out, inf = engine.g1_msm(P + negP, None, 2)
+    assert out == bytes(96) and inf == [True]                         # P + (-P)
+    out, inf = engine.g1_msm(P + P, [5, N - 5], 2)
+    assert out == bytes(96) and inf == [True]
+    out, inf = engine.g1_msm(P + bytes(96), [7, 9], 2)                # (0,0) input = infinity
+    assert out == engine.g1_msm(P, [7], 1)[0] and inf == [False]
+    out, inf = engine.g1_msm(P * 3, [0, 0, 0], 3)                     # c == 0 -> infinity (fields_t.py:710)
+    assert out == bytes(96) and inf == [True]
+    out, inf = engine.g1_msm(b"", None, 0, 2)                         # empty sums
+    assert out == bytes(192) and inf == [True, True]
+    Q2 = bytes.fromhex(p["g2"][2]["p"])
+    out, inf = engine.g2_msm(Q2 + bytes(192), [3, 4], 2)
+    assert out == engine.g2_msm(Q2, [3], 1)[0]
+
+
+@pytest.mark.parametrize("k,groups", [(1, 1), (5, 3), (6, 1), (7, 2), (13, 5), (25, 2), (67, 1)])
+def test_random_sums_vs_oracle(engine, oracle, seeded_pairs, k, groups):
+    g1, g2 = seeded_pairs
+    rnd = random.Random(k * 100 + groups)
+    n = k * groups
+    pts1, pts2 = g1[96 * 10:96 * (10 + n)], g2[192 * 10:192 * (10 + n)]
+    sc = [rnd.randrange(N) if rnd.random() < 0.8 else rnd.randrange(1 << 40) for _ in range(n)]
+    out1, _ = engine.g1_msm(pts1, sc, k, groups)
+    out2, _ = engine.g2_msm(pts2, sc, k, groups)
+    for g in range(groups):
+        w1, _ = oracle.g1_msm(pts1[96 * k * g:96 * k * (g + 1)], sc[k * g:k * (g + 1)], k)
+        w2, _ = oracle.g2_msm(pts2[192 * k * g:192 * k * (g + 1)], sc[k * g:k * (g + 1)], k)
+        assert out1[96 * g:96 * (g + 1)] == w1
+        assert out2[192 * g:192 * (g + 1)] == w2
+
+
+def _compress_g1(pt):
+    b = bytearray(pt[:48])
+    if int.from_bytes(pt[48:], "big") > Q // 2:
+        b[0] |= 0x80
+    return bytes(b)
+
+
+@pytest.mark.parametrize("n", [16, 1024])
+def test_aggregate_pub_keys_vectors(engine, golden, n):
+    """bls.py:203-223 as a G1 MSM: keys a_i*G1 (PRF scalars), sorted by their
+    compressed bytes, t_i = hash_pks; both the secure and the plain sum."""
+    rec = golden("msm.json")[str(n)]
+    g = bytes.fromhex(golden("points.json")["g1"][0]["p"])
+    sks = [prf(b"blsgpu/a", 1, i) for i in range(n)]
+    pks, inf = engine.g1_msm(g * n, sks, 1, n)                       # n scalar multiplications
+    assert hashlib.sha256(pks).hexdigest() == rec["sha256_inputs"] and not any(inf)
+    pts = sorted((pks[96 * i:96 * (i + 1)] for i in range(n)), key=_compress_g1)
+    ser = [_compress_g1(p) for p in pts]
+    assert hashlib.sha256("".join(s.hex() for s in ser).encode()).hexdigest() == rec["sha256_sorted_ser"]
+    digest = hashlib.sha256(b"".join(ser)).digest()
+    ts = [int.from_bytes(hashlib.sha256(i.to_bytes(4, "big") + digest).digest(), "big") % N for i in range(n)]
+    assert hashlib.sha256(b"".join(t.to_bytes(32, "big") for t in ts)).hexdigest() == rec["sha256_scalars"]
+    out, _ = engine.g1_msm(b"".join(pts), ts, n)
+    assert out.hex() == rec["secure_affine"]
+    out, _ = engine.g1_msm(b"".join(pts), None, n)
+    assert out.hex() == rec["simple_affine"]
+
+
+def test_threshold_combine_batched(engine, golden):
+    """threshold.py:127-136: 67 unit signatures x Lagrange weights, as a batch of groups."""
+    rec = golden("threshold.json")["67_of_100"]
+    pts = cat(rec["unit_sigs_affine"])
+    lam = [int(x, 16) for x in rec["lambdas"]]
+    groups = 5
+    out, inf = engine.g2_msm(pts * groups, lam * groups, 67, groups)
+    assert out == bytes.fromhex(rec["combined_affine"]) * groups and not any(inf)
+    small = golden("threshold.json")["3_of_5"]
+    out, _ = engine.g2_msm(cat(small["unit_sigs_affine"]), [int(x, 16) for x in small["lambdas"]], 3)
+    assert out.hex() == small["combined_affine"]
