@@ -73,6 +73,18 @@ int blsgpu_final_exp_product_dev(blsgpu_ctx *ctx, const void *d_partials, size_t
 int blsgpu_final_exp(blsgpu_ctx *ctx, const uint8_t in[BLSGPU_FQ12_BYTES],
                      uint8_t out[BLSGPU_FQ12_BYTES]);
 
+/* m independent fq12_final_exp (fields_t.py:1124-1128), host buffers m x 576 bytes. */
+int blsgpu_final_exp_batch(blsgpu_ctx *ctx, const uint8_t *in, size_t m, uint8_t *out);
+
+/* `groups` independent fq_ate_pairing_multi calls of gsz pairs each, in one
+ * launch sequence (e.g. 10 000 threshold verifications of 2 pairs: BLS.verify,
+ * bls.py:153-201, once per group).  Pairs are stored group after group;
+ * out receives groups x 576 bytes. */
+int blsgpu_pairing_multi_batch(blsgpu_ctx *ctx, const uint8_t *g1, const uint8_t *g2, size_t gsz,
+                               size_t groups, uint8_t *out);
+int blsgpu_pairing_multi_batch_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2, size_t gsz,
+                                   size_t groups, void *d_out, void *stream);
+
 /* Multi-scalar sums  out[g] = sum_{i<k} scalars[g*k+i] * pts[g*k+i]  for `groups`
  * independent groups of k points: the loops of BLS.aggregate_pub_keys
  * (bls.py:203-223, G1), BLS.aggregate_sigs* (bls.py:12-151, G2) and

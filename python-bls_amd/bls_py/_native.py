@@ -17,6 +17,7 @@ SYMBOLS = (
     "blsgpu_miller_product_dev", "blsgpu_final_exp_product_dev", "blsgpu_final_exp",
     "blsgpu_timing_enable", "blsgpu_timing_read",
     "blsgpu_g1_msm", "blsgpu_g2_msm", "blsgpu_g1_msm_dev", "blsgpu_g2_msm_dev",
+    "blsgpu_final_exp_batch", "blsgpu_pairing_multi_batch", "blsgpu_pairing_multi_batch_dev",
 )
 
 _lib = None
@@ -63,6 +64,9 @@ def load_library(path=None):
             f.argtypes = [vp, cp, cp, sz, sz, cp, cp]
         for f in (L.blsgpu_g1_msm_dev, L.blsgpu_g2_msm_dev):
             f.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp]
+        L.blsgpu_final_exp_batch.argtypes = [vp, cp, sz, cp]
+        L.blsgpu_pairing_multi_batch.argtypes = [vp, cp, cp, sz, sz, cp]
+        L.blsgpu_pairing_multi_batch_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp]
         L.blsgpu_timing_enable.argtypes = [vp, ctypes.c_int]
         L.blsgpu_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), sz,
                                          ctypes.POINTER(sz)]
@@ -117,6 +121,21 @@ class Engine:
         out = ctypes.create_string_buffer(576)
         self._check(self.lib.blsgpu_final_exp(self.h, x, out), "blsgpu_final_exp")
         return out.raw
+
+    def final_exp_batch(self, xs: bytes) -> bytes:
+        if len(xs) % 576:
+            raise ValueError("need m x 576 bytes")
+        out = ctypes.create_string_buffer(max(1, len(xs)))
+        self._check(self.lib.blsgpu_final_exp_batch(self.h, xs, len(xs) // 576, out), "blsgpu_final_exp_batch")
+        return out.raw[:len(xs)]
+
+    def pairing_multi_batch(self, g1: bytes, g2: bytes, gsz: int, groups: int) -> bytes:
+        n = gsz * groups
+        if len(g1) != 96 * n or len(g2) != 192 * n:
+            raise ValueError("g1/g2 length does not match gsz * groups")
+        out = ctypes.create_string_buffer(max(1, 576 * groups))
+        self._check(self.lib.blsgpu_pairing_multi_batch(self.h, g1, g2, gsz, groups, out), "blsgpu_pairing_multi_batch")
+        return out.raw[:576 * groups]
 
     def _msm(self, fn, psz, pts, scalars, k, groups):
         n = k * groups

@@ -19,9 +19,16 @@ class HipProvider:
     def final_exp(self, x: bytes) -> bytes:
         return self._eng.final_exp(x)
 
+    def g1_msm(self, pts: bytes, scalars, k: int, groups: int = 1):
+        return self._eng.g1_msm(pts, scalars, k, groups)
+
+    def g2_msm(self, pts: bytes, scalars, k: int, groups: int = 1):
+        return self._eng.g2_msm(pts, scalars, k, groups)
+
 
 def use(provider):
-    """Install a provider object with pairing_multi(g1, g2, n) / final_exp(x)."""
+    """Install a provider object with pairing_multi(g1, g2, n), final_exp(x),
+    g1_msm / g2_msm(pts, scalars|None, k, groups) -> (bytes, [is_inf])."""
     global _provider
     _provider = provider
 

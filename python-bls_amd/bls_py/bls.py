@@ -2,7 +2,8 @@
 
 `verify` is the GPU hot path: it assembles Ps = [-G1] + per-message key sums and
 Qs = [signature] + H(m) exactly as bls.py:153-201 does and hands them to the
-multi-pairing engine.  Group sums here are host integer code for now."""
+multi-pairing engine.  The group sums (signature aggregation, per-message key
+folding, aggregate public keys) are GPU multi-scalar sums as well."""
 from . import hostmath as H
 from .aggregation_info import AggregationInfo
 from .bls12381 import n as GROUP_ORDER
@@ -15,22 +16,39 @@ from .signature import Signature
 from .util import hash_pks
 
 
-def _g2_zero():
-    return JacobianPoint._from(H.F2, None)
+from . import backend
 
 
-def _g1_zero():
-    return JacobianPoint._from(H.F1, None)
+def _g2_sum(points, scalars=None):
+    """sum_i scalars[i] * points[i] (JacobianPoint over Fq2) on the GPU."""
+    if not points:
+        return JacobianPoint._from(H.F2, None)
+    pts = b"".join(H.g2_affine_bytes(p.to_affine()._aff()) for p in points)
+    out, inf = backend.get().g2_msm(pts, scalars, len(points), 1)
+    return JacobianPoint._from(H.F2, None if inf[0] else H.aff_to_jac(H.F2, H.g2_from_abi(out)))
+
+
+def _g1_sums(groups_of_points, groups_of_scalars):
+    """One G1 multi-scalar sum per group (ragged groups are padded with infinity)."""
+    if not groups_of_points:
+        return []
+    k = max(len(g) for g in groups_of_points)
+    pts, sc = bytearray(), []
+    for g, s in zip(groups_of_points, groups_of_scalars):
+        for p in g:
+            pts += H.g1_affine_bytes(p.to_affine()._aff())
+        pts += bytes(96) * (k - len(g))
+        sc += [int(x) for x in s] + [0] * (k - len(g))
+    out, inf = backend.get().g1_msm(bytes(pts), sc, k, len(groups_of_points))
+    return [JacobianPoint._from(H.F1, None if inf[i] else H.aff_to_jac(H.F1, H.g1_from_abi(out[96 * i:96 * (i + 1)])))
+            for i in range(len(groups_of_points))]
 
 
 class BLS:
     @staticmethod
     def aggregate_sigs_simple(signatures):
         """Plain sum; NOT safe for signatures over one message (rogue keys)."""
-        acc = _g2_zero()
-        for sig in signatures:
-            acc = acc + sig.value
-        return Signature.from_g2(acc)
+        return Signature.from_g2(_g2_sum([sig.value for sig in signatures]))
 
     @staticmethod
     def aggregate_sigs_secure(signatures, public_keys, message_hashes):
@@ -38,10 +56,7 @@ class BLS:
             raise Exception("Invalid number of keys")
         ordered = sorted(zip(message_hashes, public_keys, signatures))
         ts = hash_pks(len(public_keys), public_keys)
-        acc = _g2_zero()
-        for t, (_, _, sig) in zip(ts, ordered):
-            acc = acc + sig.value * t
-        return Signature.from_g2(acc)
+        return Signature.from_g2(_g2_sum([sig.value for _, _, sig in ordered], ts))
 
     @staticmethod
     def aggregate_sigs(signatures):
@@ -61,12 +76,7 @@ class BLS:
         keys = sorted((mh, pk) for s in hit
                       for mh, pk in zip(s.aggregation_info.message_hashes, s.aggregation_info.public_keys))
         ts = hash_pks(len(hit), [pk for _, pk in keys])
-        acc = _g2_zero()
-        for t, sig in zip(ts, hit):
-            acc = acc + sig.value * t
-        for sig in rest:
-            acc = acc + sig.value
-        out = Signature.from_g2(acc)
+        out = Signature.from_g2(_g2_sum([s.value for s in hit] + [s.value for s in rest], ts + [1] * len(rest)))
         out.set_aggregation_info(AggregationInfo.merge_infos(infos))
         return out
 
@@ -76,17 +86,16 @@ class BLS:
         by_message = {}
         for mh, pk in zip(info.message_hashes, info.public_keys):
             by_message.setdefault(mh, []).append(pk)
-        Ps, Qs = [], []
+        key_groups, exp_groups, Qs = [], [], []
         for mh, keys in by_message.items():
-            total = _g1_zero()
-            for pk in set(keys):
-                try:
-                    exponent = info.tree[(mh, pk)]
-                except KeyError:
-                    return False
-                total = total + pk.value * exponent
-            Ps.append(total.to_affine())
+            uniq = list(set(keys))
+            try:
+                exp_groups.append([info.tree[(mh, pk)] for pk in uniq])
+            except KeyError:
+                return False
+            key_groups.append([pk.value for pk in uniq])
             Qs.append(hash_to_point_prehashed_Fq2(mh))
+        Ps = [t.to_affine() for t in _g1_sums(key_groups, exp_groups)]
         neg_g1 = generator_Fq() * (GROUP_ORDER - 1)
         res = ate_pairing_multi([neg_g1] + Ps, [signature.value.to_affine()] + Qs, default_ec)
         return res == Fq12.one(default_ec.q)
@@ -97,10 +106,7 @@ class BLS:
             raise Exception("Invalid number of keys")
         public_keys.sort()                 # in place, like the reference (bls.py:210)
         ts = hash_pks(len(public_keys), public_keys)
-        acc = _g1_zero()
-        for t, pk in zip(ts, public_keys):
-            acc = acc + (pk.value * t if secure else pk.value)
-        return PublicKey.from_g1(acc)
+        return PublicKey.from_g1(_g1_sums([[pk.value for pk in public_keys]], [ts if secure else [1] * len(public_keys)])[0])
 
     @staticmethod
     def aggregate_priv_keys(private_keys, public_keys, secure):

@@ -42,8 +42,6 @@ class Threshold:
     @staticmethod
     def aggregate_unit_sigs(signatures, players, T, ec=default_ec):
         """sum_i lambda_i * sig_i  (a |players|-point G2 multi-scalar multiplication)."""
+        from .bls import _g2_sum
         lam = Threshold.lagrange_coeffs_at_zero(players, ec)
-        acc = JacobianPoint._from(H.F2, None)
-        for l, sig in zip(lam, signatures):
-            acc = acc + sig.value * l
-        return Signature.from_g2(acc)
+        return Signature.from_g2(_g2_sum([sig.value for sig in signatures], [int(l) for l in lam]))

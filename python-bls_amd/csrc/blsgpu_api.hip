@@ -227,6 +227,10 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
                               MILLER_WAVES * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize,
                               REDUCE_WAVES * blsgpu::TEAM_BYTES);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_final_groups, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              REDUCE_WAVES * blsgpu::TEAM_BYTES);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_bytes_to_partials, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              REDUCE_WAVES * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_msm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_msm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_msm_finish<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * blsgpu::TEAM_BYTES);
@@ -403,39 +407,96 @@ BLSGPU_EXPORT int blsgpu_pairing_multi(blsgpu_ctx* c, const uint8_t* g1, const u
     return 0;
 }
 
-// device kernel used by blsgpu_final_exp: bytes -> Montgomery partial
-namespace blsgpu {
-__global__ void __launch_bounds__(64) k_bytes_to_partial(VmTables T, const uint32_t* __restrict__ in_bytes, uint32_t* __restrict__ out_partial) {
-    uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
-    const uint32_t lane = threadIdx.x & 63u;
-    team_init_consts(T, smem, lane);
-    for (uint32_t k = lane; k < 144; k += 64) {
-        uint32_t cidx = k / 12, w = k % 12;
-        smem[R1_DW + cidx * 12 + (11 - w)] = bswap32(in_bytes[k]);
-    }
-    wave_fence();
-    run_rounds(T, T.segflat + BLSVM_SEGF_TO_MONT_0_1_OFF, BLSVM_SEGF_TO_MONT_0_1_LEN, 0, lane);
-    for (uint32_t k = lane; k < 144; k += 64) out_partial[k] = smem[F_DW + k];
-}
-}  // namespace blsgpu
-
-BLSGPU_EXPORT int blsgpu_final_exp(blsgpu_ctx* c, const uint8_t in[576], uint8_t out[576]) {
-    if (!c || !in || !out) return fail(-EINVAL, "NULL argument");
+// m independent final exponentiations: fq12_final_exp on each 576-byte element
+BLSGPU_EXPORT int blsgpu_final_exp_batch(blsgpu_ctx* c, const uint8_t* in, size_t m, uint8_t* out) {
+    if (!c || (m && (!in || !out))) return fail(-EINVAL, "NULL argument");
+    if (m == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
-    if (c->io_cap < 1024) {
+    size_t need = m * 576 * 2 + 64;
+    if (need > c->io_cap) {
         if (c->d_io) (void)hipFree(c->d_io);
         c->d_io = nullptr;
         c->io_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_io, 4096));
-        c->io_cap = 4096;
+        HIP_TRY(hipMalloc(&c->d_io, need));
+        c->io_cap = need;
     }
-    HIP_TRY(hipMemcpy(c->d_io, in, 576, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(blsgpu::k_bytes_to_partial, dim3(1), dim3(64), blsgpu::TEAM_BYTES, 0, c->tabs,
-                       (const uint32_t*)c->d_io, c->d_part[1]);
-    HIP_TRY(hipGetLastError());
-    int rc = reduce_chain(c, c->d_part[1], 1, true, nullptr, c->d_out, 0);
+    int rc = ensure_workspace(c, m * MILLER_WAVES);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(out, c->d_out, 576, hipMemcpyDeviceToHost));
+    char* din = (char*)c->d_io;
+    char* dout = din + m * 576;
+    HIP_TRY(hipMemcpy(din, in, m * 576, hipMemcpyHostToDevice));
+    size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
+    unsigned blocks = (unsigned)((m + REDUCE_WAVES - 1) / REDUCE_WAVES);
+    hipLaunchKernelGGL(blsgpu::k_bytes_to_partials, dim3(blocks), dim3(REDUCE_WAVES * 64), lds, 0, c->tabs,
+                       (const uint32_t*)din, (uint32_t)m, c->d_part[1]);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(blsgpu::k_final_groups, dim3(blocks), dim3(REDUCE_WAVES * 64), lds, 0, c->tabs, c->d_part[1],
+                       1u, (uint32_t)m, (uint32_t*)dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, m * 576, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+BLSGPU_EXPORT int blsgpu_final_exp(blsgpu_ctx* c, const uint8_t in[576], uint8_t out[576]) {
+    return blsgpu_final_exp_batch(c, in, 1, out);
+}
+
+// `groups` independent multi-pairings of gsz pairs each (pairs stored group after
+// group): out[g] = fq_ate_pairing_multi of group g.  One wavefront per pair for
+// the Miller loops, one wavefront per group for product + final exponentiation.
+BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t gsz, size_t groups,
+                                                 void* d_out, void* stream) {
+    if (!c || (groups && !d_out)) return fail(-EINVAL, "NULL argument");
+    if (groups == 0) return 0;
+    size_t n = gsz * groups;
+    if (n && (!d_g1 || !d_g2)) return fail(-EINVAL, "NULL point buffer");
+    if (n > 0x3FFFFFF0ull) return fail(-EINVAL, "batch too large");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_workspace(c, (n + 1) * MILLER_WAVES);      // one partial per PAIR here
+    if (rc) return rc;
+    if (n) {
+        KernelTimer kt(c, st, 0);
+        hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)n), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs,
+                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, c->d_part[0]);
+    }
+    HIP_TRY(hipGetLastError());
+    size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
+    unsigned blocks = (unsigned)((groups + REDUCE_WAVES - 1) / REDUCE_WAVES);
+    {
+        KernelTimer kt(c, st, 2);
+        hipLaunchKernelGGL(blsgpu::k_final_groups, dim3(blocks), dim3(REDUCE_WAVES * 64), lds, st, c->tabs, c->d_part[0],
+                           (uint32_t)gsz, (uint32_t)groups, (uint32_t*)d_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+BLSGPU_EXPORT int blsgpu_pairing_multi_batch(blsgpu_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t gsz, size_t groups,
+                                             uint8_t* out) {
+    if (!c || (groups && !out)) return fail(-EINVAL, "NULL argument");
+    if (groups == 0) return 0;
+    size_t n = gsz * groups;
+    if (n && (!g1 || !g2)) return fail(-EINVAL, "NULL point buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t need = n * (BLSGPU_G1_BYTES + BLSGPU_G2_BYTES) + groups * 576 + 64;
+    if (need > c->io_cap) {
+        if (c->d_io) (void)hipFree(c->d_io);
+        c->d_io = nullptr;
+        c->io_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_io, need));
+        c->io_cap = need;
+    }
+    char* d1 = (char*)c->d_io;
+    char* d2 = d1 + n * BLSGPU_G1_BYTES;
+    char* dout = d2 + n * BLSGPU_G2_BYTES;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(d1, g1, n * BLSGPU_G1_BYTES, hipMemcpyHostToDevice, 0));
+        HIP_TRY(hipMemcpyAsync(d2, g2, n * BLSGPU_G2_BYTES, hipMemcpyHostToDevice, 0));
+    }
+    int rc = blsgpu_pairing_multi_batch_dev(c, d1, d2, gsz, groups, dout, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, dout, groups * 576, hipMemcpyDeviceToHost));
     return 0;
 }
 

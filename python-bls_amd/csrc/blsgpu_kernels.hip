@@ -356,4 +356,64 @@ __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------
+// Kernel 3: many independent results.  Team g multiplies partials
+// [g * gsz, (g + 1) * gsz) (Montgomery Fq12, 144 u32 each), applies the final
+// exponentiation and writes 576 canonical bytes to out_bytes[g].  No workgroup
+// barrier: every team is on its own.
+__global__ void __launch_bounds__(512) k_final_groups(VmTables T, const uint32_t* __restrict__ in, uint32_t gsz, uint32_t groups,
+                                                       uint32_t* __restrict__ out_bytes) {
+    uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwaves = blockDim.x >> 6;
+    const uint32_t g = blockIdx.x * nwaves + wave;
+    if (g >= groups) return;
+    uint32_t* team = smem + wave * TEAM_DW;
+    const uint32_t base16 = wave * (TEAM_BYTES / 16);
+    team_init_consts(T, team, lane);
+    wave_fence();
+    if (gsz == 0) team_set_acc(team, lane, true);
+    for (uint32_t i = 0; i < gsz; ++i) {
+        const uint32_t* src = in + ((size_t)g * gsz + i) * 144;
+        const uint32_t dst = (i == 0) ? F_DW : R1_DW;
+        for (uint32_t k = lane; k < 144; k += 64) team[dst + k] = src[k];
+        wave_fence();
+        if (i) run_rounds(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, base16, lane);
+    }
+    wave_fence();
+    run_rounds(T, T.fflat, BLSVM_FEXP_FLAT_LEN, base16, lane);
+    run_rounds(T, T.segflat + BLSVM_SEGF_FROM_MONT_1_0_OFF, BLSVM_SEGF_FROM_MONT_1_0_LEN, base16, lane);
+    if (lane < 12) {
+        uint32_t X[12];
+        lds_load12(X, base16 + (BLSVM_SLOT_REG0 + 12 + lane) * 3);
+        bls::fq_canon(X);
+        lds_store12(X, base16 + (BLSVM_SLOT_REG0 + 12 + lane) * 3);
+    }
+    wave_fence();
+    for (uint32_t k = lane; k < 144; k += 64) {
+        uint32_t c = k / 12, w = k % 12;
+        out_bytes[(size_t)g * 144 + k] = bswap32(team[R1_DW + c * 12 + (11 - w)]);
+    }
+}
+
+// bytes (m x 576, canonical big-endian) -> Montgomery partials (m x 144 u32), one team each
+__global__ void __launch_bounds__(512) k_bytes_to_partials(VmTables T, const uint32_t* __restrict__ in_bytes, uint32_t m,
+                                                           uint32_t* __restrict__ out_partials) {
+    uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (g >= m) return;
+    uint32_t* team = smem + wave * TEAM_DW;
+    team_init_consts(T, team, lane);
+    for (uint32_t k = lane; k < 144; k += 64) {
+        uint32_t cidx = k / 12, w = k % 12;
+        team[R1_DW + cidx * 12 + (11 - w)] = bswap32(in_bytes[(size_t)g * 144 + k]);
+    }
+    wave_fence();
+    run_rounds(T, T.segflat + BLSVM_SEGF_TO_MONT_0_1_OFF, BLSVM_SEGF_TO_MONT_0_1_LEN, wave * (TEAM_BYTES / 16), lane);
+    for (uint32_t k = lane; k < 144; k += 64) out_partials[(size_t)g * 144 + k] = team[F_DW + k];
+}
+
 }  // namespace blsgpu

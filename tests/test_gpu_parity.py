@@ -129,3 +129,21 @@ def test_reference_boundary_signature(golden):
     assert fh.fq_ate_pairing_multi((), ()) == (1,) + (0,) * 11
     with pytest.raises(ValueError):
         fh.fq_ate_pairing_multi((Ps[0],), ((Qs[0][0], Qs[0][1], True),))
+
+
+def test_batched_independent_pairings(engine, golden, seeded_pairs, oracle):
+    """blsgpu_pairing_multi_batch: many small fq_ate_pairing_multi calls at once
+    (the verify step of C4: 2 pairs per group), and blsgpu_final_exp_batch."""
+    g1, g2 = seeded_pairs
+    for gsz, groups in ((2, 9), (1, 5), (3, 4), (5, 1)):
+        n = gsz * groups
+        out = engine.pairing_multi_batch(g1[:96 * n], g2[:192 * n], gsz, groups)
+        for g in range(groups):
+            want = oracle.pairing_multi(g1[96 * gsz * g:96 * gsz * (g + 1)], g2[192 * gsz * g:192 * gsz * (g + 1)], gsz)
+            assert out[576 * g:576 * (g + 1)] == want, (gsz, g)
+    v = golden("verify4.json")
+    one = (1).to_bytes(48, "big") + bytes(48 * 11)
+    assert engine.pairing_multi_batch(cat(v["pairing_g1"]) * 3, cat(v["pairing_g2"]) * 3, 5, 3) == one * 3
+    recs = golden("pairing.json")["final_exp"]
+    ins = b"".join(bytes.fromhex(r["in"]) for r in recs) * 4
+    assert engine.final_exp_batch(ins) == b"".join(bytes.fromhex(r["out"]) for r in recs) * 4

@@ -17,6 +17,21 @@ def oracle_provider(oracle):
 
         def final_exp(self, x):
             return oracle.final_exp(x)
+
+        def _msm(self, fn, psz, pts, scalars, k, groups):
+            out, inf = b"", []
+            for g in range(groups):
+                sc = None if scalars is None else scalars[k * g:k * (g + 1)]
+                o, i = fn(pts[psz * k * g:psz * k * (g + 1)], sc, k)
+                out += o
+                inf.append(i)
+            return out, inf
+
+        def g1_msm(self, pts, scalars, k, groups=1):
+            return self._msm(oracle.g1_msm, 96, pts, scalars, k, groups)
+
+        def g2_msm(self, pts, scalars, k, groups=1):
+            return self._msm(oracle.g2_msm, 192, pts, scalars, k, groups)
     backend.use(P())
     yield
     backend.use(None)
@@ -133,6 +148,9 @@ def test_verify4_inputs_match_reference(golden):
     inner = backend.get()
 
     class Spy:
+        g1_msm = staticmethod(inner.g1_msm)
+        g2_msm = staticmethod(inner.g2_msm)
+
         def pairing_multi(self, g1, g2, n):
             seen["g1"], seen["g2"], seen["n"] = g1, g2, n
             return inner.pairing_multi(g1, g2, n)
