@@ -252,7 +252,7 @@ __device__ __forceinline__ void wg_product_tree(const VmTables& T, uint32_t* sme
 // Infinity follows the reference's observable behaviour (tests/golden/pairing.json
 // "edge"): coordinates (0,0) for Q contribute 1 (0 if P.y is 0 too), (0,0) for P
 // contributes 1.
-__global__ void __launch_bounds__(256) k_miller(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+__global__ void __launch_bounds__(256, 3) k_miller(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
                                                 uint32_t n, uint32_t* __restrict__ partials) {
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;

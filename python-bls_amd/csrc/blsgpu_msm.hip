@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t inf_dword(const uint32_t* team, uint32_t k) 
 //   pts:     affine big-endian coordinates, 96*DEG bytes per point ((0,0) = infinity)
 //   scalars: 32 bytes big-endian per point, or nullptr for all-ones (plain sums)
 template <int DEG>
-__global__ void __launch_bounds__(256) k_msm(VmTables T, const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars,
+__global__ void __launch_bounds__(256, 3) k_msm(VmTables T, const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars,
                                              uint32_t k, uint32_t chunk, uint32_t bpg, uint32_t* __restrict__ partials) {
     using C = MsmCfg<DEG>;
     constexpr uint32_t PT_DW = 24 * DEG;            // dwords per affine input point
