@@ -47,6 +47,11 @@ int blsgpu_ctx_create(int device, blsgpu_ctx **out);
 void blsgpu_ctx_destroy(blsgpu_ctx *ctx);
 /* Pre-size the per-context workspace for batches of up to max_pairs pairs. */
 int blsgpu_ctx_reserve(blsgpu_ctx *ctx, size_t max_pairs);
+/* Batches of at least `pairs` pairs run the throughput-oriented Miller kernel
+ * (several pairs per wavefront sharing one accumulator); smaller batches the
+ * latency-oriented one (one pair per wavefront).  Default 4096; 0 = always the
+ * throughput kernel.  Results are identical either way. */
+int blsgpu_ctx_set_mp_threshold(blsgpu_ctx *ctx, size_t pairs);
 
 /* fq_ate_pairing_multi(Ps, Qs) -- fields_t.py:1114-1121 / fields_t_c.pyx:2333-2391.
  * Host buffers in, 576 result bytes out; synchronous.  n == 0 returns one. */

@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libblsgpu.so")
 
 SYMBOLS = (
     "blsgpu_version", "blsgpu_last_error", "blsgpu_ctx_create", "blsgpu_ctx_destroy",
-    "blsgpu_ctx_reserve", "blsgpu_pairing_multi", "blsgpu_pairing_multi_dev",
+    "blsgpu_ctx_reserve", "blsgpu_ctx_set_mp_threshold", "blsgpu_pairing_multi", "blsgpu_pairing_multi_dev",
     "blsgpu_miller_product_dev", "blsgpu_final_exp_product_dev", "blsgpu_final_exp",
     "blsgpu_timing_enable", "blsgpu_timing_read",
     "blsgpu_g1_msm", "blsgpu_g2_msm", "blsgpu_g1_msm_dev", "blsgpu_g2_msm_dev",
@@ -55,6 +55,7 @@ def load_library(path=None):
         L.blsgpu_ctx_destroy.argtypes = [vp]
         L.blsgpu_ctx_destroy.restype = None
         L.blsgpu_ctx_reserve.argtypes = [vp, sz]
+        L.blsgpu_ctx_set_mp_threshold.argtypes = [vp, sz]
         L.blsgpu_pairing_multi.argtypes = [vp, cp, cp, sz, cp]
         L.blsgpu_pairing_multi_dev.argtypes = [vp, vp, vp, sz, vp, vp]
         L.blsgpu_miller_product_dev.argtypes = [vp, vp, vp, sz, vp, vp]
@@ -104,6 +105,10 @@ class Engine:
 
     def version(self):
         return self.lib.blsgpu_version().decode()
+
+    def set_mp_threshold(self, pairs):
+        """Batches >= pairs use the throughput kernel (several pairs per wavefront)."""
+        self._check(self.lib.blsgpu_ctx_set_mp_threshold(self.h, pairs), "blsgpu_ctx_set_mp_threshold")
 
     def reserve(self, max_pairs):
         self._check(self.lib.blsgpu_ctx_reserve(self.h, max_pairs), "blsgpu_ctx_reserve")

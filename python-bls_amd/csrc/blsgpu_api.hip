@@ -5,6 +5,7 @@
 
 #include <errno.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -43,6 +44,7 @@ struct blsgpu_ctx {
     void* d_io = nullptr;              // staging for the host-buffer entry points
     size_t io_cap = 0;
     uint32_t* d_out = nullptr;         // 576-byte result staging
+    size_t mp_threshold = 4096;        // pairs from which k_miller_mp is used
     uint32_t* d_msm_part = nullptr;    // MSM partials
     size_t msm_part_cap = 0;           // in u32
     // optional per-kernel timing (blsgpu_timing_enable): HIP events recorded on
@@ -69,10 +71,21 @@ struct KernelTimer {
 };
 }  // namespace
 
-static size_t n_blocks_miller(size_t n) { return (n + MILLER_WAVES - 1) / MILLER_WAVES; }
+// Batches of at least mp_threshold pairs use the multi-pair program (k_miller_mp:
+// fewer instructions per pairing, longer per-batch latency); smaller ones the
+// one-pair-per-wavefront program (k_miller).  Default 4096; per context via
+// blsgpu_ctx_set_mp_threshold, or BLSGPU_MP_THRESHOLD in the environment.
+static size_t default_mp_threshold() {
+    const char* e = getenv("BLSGPU_MP_THRESHOLD");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4096;
+}
+static bool use_mp(const blsgpu_ctx* c, size_t n) { return n >= c->mp_threshold; }
+static size_t n_blocks_miller(const blsgpu_ctx* c, size_t n) {
+    return use_mp(c, n) ? (n + BLSVM_MP_G - 1) / BLSVM_MP_G : (n + MILLER_WAVES - 1) / MILLER_WAVES;
+}
 
 static int ensure_workspace(blsgpu_ctx* c, size_t max_pairs) {
-    size_t need = n_blocks_miller(max_pairs) + 1;
+    size_t need = (max_pairs + 2) / 3 + (max_pairs + MILLER_WAVES - 1) / MILLER_WAVES + 1;
     if (need > c->part_cap) {
         for (int i = 0; i < 2; i++) {
             if (c->d_part[i]) (void)hipFree(c->d_part[i]);
@@ -181,10 +194,12 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     HIP_TRY(hipSetDevice(device));
     blsgpu_ctx* c = new blsgpu_ctx();
     c->device = device;
+    c->mp_threshold = default_mp_threshold();
     // pack all tables into one device allocation (16-byte aligned pieces)
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     size_t o_m = 0;
-    size_t o_f = o_m + al(sizeof(BLSVM_MILLER_FLAT));
+    size_t o_mp = o_m + al(sizeof(BLSVM_MILLER_FLAT));
+    size_t o_f = o_mp + al(sizeof(BLSVM_MP_FLAT));
     size_t o_s = o_f + al(sizeof(BLSVM_FEXP_FLAT));
     size_t o_data = o_s + al(sizeof(BLSVM_SEG_FLAT));
     size_t o_c = o_data + al(sizeof(BLSVM_DATA));
@@ -195,7 +210,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     }
     char* base = (char*)c->d_tables;
     struct { size_t off; const void* src; size_t len; } parts[] = {
-        {o_m, BLSVM_MILLER_FLAT, sizeof(BLSVM_MILLER_FLAT)}, {o_f, BLSVM_FEXP_FLAT, sizeof(BLSVM_FEXP_FLAT)},
+        {o_m, BLSVM_MILLER_FLAT, sizeof(BLSVM_MILLER_FLAT)}, {o_mp, BLSVM_MP_FLAT, sizeof(BLSVM_MP_FLAT)},
+        {o_f, BLSVM_FEXP_FLAT, sizeof(BLSVM_FEXP_FLAT)},
         {o_s, BLSVM_SEG_FLAT, sizeof(BLSVM_SEG_FLAT)},       {o_data, BLSVM_DATA, sizeof(BLSVM_DATA)},
         {o_c, BLSVM_CONSTS, sizeof(BLSVM_CONSTS)}};
     for (auto& p : parts) {
@@ -206,6 +222,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
         }
     }
     c->tabs.mflat = (const uint2*)(base + o_m);
+    c->tabs.mpflat = (const uint2*)(base + o_mp);
     c->tabs.fflat = (const uint2*)(base + o_f);
     c->tabs.segflat = (const uint2*)(base + o_s);
     c->tabs.data = (const uint16_t*)(base + o_data);
@@ -227,6 +244,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
                               MILLER_WAVES * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize,
                               REDUCE_WAVES * blsgpu::TEAM_BYTES);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_miller_mp, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              blsgpu::MP_TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_final_groups, hipFuncAttributeMaxDynamicSharedMemorySize,
                               REDUCE_WAVES * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_bytes_to_partials, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -288,6 +307,12 @@ BLSGPU_EXPORT int blsgpu_timing_read(blsgpu_ctx* c, float* ms, int* kind, size_t
     return 0;
 }
 
+BLSGPU_EXPORT int blsgpu_ctx_set_mp_threshold(blsgpu_ctx* c, size_t pairs) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    c->mp_threshold = pairs;
+    return 0;
+}
+
 BLSGPU_EXPORT int blsgpu_ctx_reserve(blsgpu_ctx* c, size_t max_pairs) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
@@ -325,9 +350,13 @@ static int reduce_chain(blsgpu_ctx* c, const uint32_t* d_in, size_t m, bool do_f
 
 static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t n, uint32_t* d_partials,
                          hipStream_t st) {
-    size_t blocks = n_blocks_miller(n);
-    size_t lds = (size_t)MILLER_WAVES * blsgpu::TEAM_BYTES;
-    {
+    size_t blocks = n_blocks_miller(c, n);
+    if (use_mp(c, n)) {
+        KernelTimer kt(c, st, 0);
+        hipLaunchKernelGGL(blsgpu::k_miller_mp, dim3((unsigned)blocks), dim3(64), (size_t)blsgpu::MP_TEAM_BYTES, st, c->tabs,
+                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, d_partials);
+    } else {
+        size_t lds = (size_t)MILLER_WAVES * blsgpu::TEAM_BYTES;
         KernelTimer kt(c, st, 0);
         hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)blocks), dim3(MILLER_WAVES * 64), lds, st, c->tabs,
                            (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, d_partials);
@@ -343,7 +372,7 @@ BLSGPU_EXPORT int blsgpu_miller_product_dev(blsgpu_ctx* c, const void* d_g1, con
     if (n > 0xFFFFFFF0ull) return fail(-EINVAL, "n too large");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
-    if (n_blocks_miller(n) + 1 > c->part_cap) {
+    if (n_blocks_miller(c, n) + 1 > c->part_cap) {
         int rc = ensure_workspace(c, n);
         if (rc) return rc;
     }
@@ -351,7 +380,7 @@ BLSGPU_EXPORT int blsgpu_miller_product_dev(blsgpu_ctx* c, const void* d_g1, con
         int rc = launch_miller(c, d_g1, d_g2, n, c->d_part[0], st);
         if (rc) return rc;
     }
-    return reduce_chain(c, c->d_part[0], n_blocks_miller(n), false, (uint32_t*)d_partial, nullptr, st);
+    return reduce_chain(c, c->d_part[0], n_blocks_miller(c, n), false, (uint32_t*)d_partial, nullptr, st);
 }
 
 BLSGPU_EXPORT int blsgpu_final_exp_product_dev(blsgpu_ctx* c, const void* d_partials, size_t m, void* d_out, void* stream) {
@@ -372,7 +401,7 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_dev(blsgpu_ctx* c, const void* d_g1, cons
     if (n > 0xFFFFFFF0ull) return fail(-EINVAL, "n too large");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
-    if (n_blocks_miller(n) + 1 > c->part_cap) {
+    if (n_blocks_miller(c, n) + 1 > c->part_cap) {
         int rc = ensure_workspace(c, n);
         if (rc) return rc;
     }
@@ -380,7 +409,7 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_dev(blsgpu_ctx* c, const void* d_g1, cons
         int rc = launch_miller(c, d_g1, d_g2, n, c->d_part[0], st);
         if (rc) return rc;
     }
-    return reduce_chain(c, c->d_part[0], n_blocks_miller(n), true, nullptr, d_out, st);
+    return reduce_chain(c, c->d_part[0], n_blocks_miller(c, n), true, nullptr, d_out, st);
 }
 
 BLSGPU_EXPORT int blsgpu_pairing_multi(blsgpu_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t out[576]) {

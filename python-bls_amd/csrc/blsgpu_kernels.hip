@@ -30,6 +30,7 @@ namespace blsgpu {
 
 struct VmTables {
     const uint2* mflat;       // Miller loop: flat round sequence {data_off, meta}
+    const uint2* mpflat;      // Miller loop, BLSVM_MP_G pairs per team
     const uint2* fflat;       // final exponentiation
     const uint2* segflat;     // directly called segments (BLSVM_SEGF_*)
     const uint16_t* data;
@@ -252,7 +253,13 @@ __device__ __forceinline__ void wg_product_tree(const VmTables& T, uint32_t* sme
 // Infinity follows the reference's observable behaviour (tests/golden/pairing.json
 // "edge"): coordinates (0,0) for Q contribute 1 (0 if P.y is 0 too), (0,0) for P
 // contributes 1.
-__global__ void __launch_bounds__(256, 3) k_miller(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+#ifndef BLSGPU_MILLER_WPS
+#define BLSGPU_MILLER_WPS 4
+#endif
+#ifndef BLSGPU_MP_WPS
+#define BLSGPU_MP_WPS 3
+#endif
+__global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
                                                 uint32_t n, uint32_t* __restrict__ partials) {
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
@@ -301,6 +308,76 @@ __global__ void __launch_bounds__(256, 3) k_miller(VmTables T, const uint32_t* _
         wave_fence();
         for (uint32_t i = lane; i < 144; i += 64) partials[(size_t)blockIdx.x * 144 + i] = team[F_DW + i];
     }
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 1b (large batches): BLSVM_MP_G pairs per wavefront sharing ONE Miller
+// accumulator  f <- f^2 * prod_g l_g  -- one squaring per iteration for the whole
+// team and much better lane packing (vmgen/programs.py build_multi): ~31 % fewer
+// instructions per pairing.  One team per block; a team with an incomplete or a
+// special (zero-coordinate) pair falls back to the single-pair program for each
+// of its pairs, so the observable behaviour is that of k_miller.
+constexpr int MP_TEAM_DW = BLSVM_MP_TEAM_SLOTS * 12;
+constexpr int MP_TEAM_BYTES = MP_TEAM_DW * 4;
+
+__device__ __forceinline__ uint32_t mp_pair_base(uint32_t g) {
+    return g == 0 ? (uint32_t)BLSVM_SLOT_PX : (uint32_t)(BLSVM_MP_BLOCK0 + BLSVM_PAIR_BLOCK * (g - 1));
+}
+// raw big-endian pair -> 6 limb slots starting at slot `dst`
+__device__ __forceinline__ void load_pair_raw(uint32_t* team, uint32_t dst, const uint32_t* __restrict__ g1,
+                                              const uint32_t* __restrict__ g2, size_t pair, uint32_t lane) {
+    for (uint32_t d = lane; d < 72; d += 64) {
+        uint32_t w = (d < 24) ? g1[pair * 24 + d] : g2[pair * 48 + (d - 24)];
+        uint32_t e = d / 12, k = d % 12;
+        team[(dst + e) * 12 + (11 - k)] = bswap32(w);
+    }
+}
+// bit0: P == (0,0); bit1: P.y == 0; bit2: Q == (0,0)   (wave-uniform result)
+__device__ __forceinline__ uint32_t pair_flags(const uint32_t* team, uint32_t slot, uint32_t lane) {
+    uint32_t v0 = team[slot * 12 + lane];                          // dwords 0..63 of the 72
+    uint32_t v1 = (lane < 8) ? team[slot * 12 + 64 + lane] : 0u;   // dwords 64..71
+    uint64_t nz0 = __ballot(v0 != 0), nz1 = __ballot(v1 != 0);
+    uint32_t f = 0;
+    if ((nz0 & 0xFFFFFFull) == 0) f |= 1u;
+    if ((nz0 & 0xFFF000ull) == 0) f |= 2u;
+    if ((nz0 >> 24) == 0 && nz1 == 0) f |= 4u;
+    return f;
+}
+
+__global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+                                                     uint32_t n, uint32_t* __restrict__ partials) {
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t first = blockIdx.x * BLSVM_MP_G;
+    const uint32_t cnt = min((uint32_t)BLSVM_MP_G, n - first);
+    team_init_consts(T, team, lane);
+    wave_fence();
+    uint32_t special = (cnt < (uint32_t)BLSVM_MP_G) ? 1u : 0u;
+    for (uint32_t g = 0; g < cnt; ++g) {
+        load_pair_raw(team, mp_pair_base(g), g1, g2, first + g, lane);
+        wave_fence();
+        special |= pair_flags(team, mp_pair_base(g), lane);
+    }
+    if (!special) {
+        run_rounds(T, T.mpflat, BLSVM_MP_FLAT_LEN, 0, lane);
+    } else {
+        bool have = false;
+        for (uint32_t g = 0; g < cnt; ++g) {
+            load_pair_raw(team, BLSVM_SLOT_PX, g1, g2, first + g, lane);
+            wave_fence();
+            const uint32_t fl = pair_flags(team, BLSVM_SLOT_PX, lane);
+            if (fl & 4u) team_set_acc(team, lane, !(fl & 2u));
+            else if (fl & 1u) team_set_acc(team, lane, true);
+            else run_rounds(T, T.mflat, BLSVM_MILLER_FLAT_LEN, 0, lane);
+            wave_fence();
+            if (have) run_rounds(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, 0, lane);
+            run_rounds(T, T.segflat + BLSVM_SEGF_COPY_1_0_OFF, BLSVM_SEGF_COPY_1_0_LEN, 0, lane);
+            have = true;
+        }
+        if (!have) team_set_acc(team, lane, true);
+    }
+    wave_fence();
+    for (uint32_t i = lane; i < 144; i += 64) partials[(size_t)blockIdx.x * 144 + i] = team[F_DW + i];
 }
 
 // ---------------------------------------------------------------------------

@@ -308,6 +308,10 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
     release_at = defaultdict(list)
     fixed_claimed = {}
     for ri, r in enumerate(rounds):
+        # a slot whose last reader is THIS round can already take a result of this
+        # round: inside a round every lane reads before any lane writes
+        for off in release_at.pop(ri, []):
+            free.append(off)
         for v in r.ops:
             want = out_fixed.get(v.id, [])
             chosen = None
@@ -329,14 +333,11 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
                 if v.id in live_out:
                     lu = nrounds      # must survive until the final copy
                 else:
-                    release_at[lu].append(off)
+                    release_at[max(lu, ri + 1)].append(off)
             slot[v.id] = chosen
             for fx in want:
                 if fx != chosen:
                     copies.append((v, fx))
-        # slots whose last reader is this round can be recycled from the next
-        for off in release_at.pop(ri, []):
-            free.append(off)
     # outputs that are plain inputs (pass-through to another slot)
     for v, fx in b.outputs:
         if v.kind == "in" and v.fixed != fx:

@@ -162,33 +162,40 @@ def t_add(cfg, Tp, Qa, px, py):
     return (X3, Y3, Z3), (l0, l1, l4)
 
 
-def seg_init(cfg, first_add):
-    """Raw inputs -> Montgomery; T = Q, F = 1; first tangent(+chord) step."""
-    b = Builder("init")
-    r2 = b.inp(C(C_R2))
-    one = b.inp(C(C_ONE))
-    px = (b.inp(T(PX)) * r2).mat()
-    py = (b.inp(T(PY)) * r2).mat()
-    q = [(b.inp(T(QX0 + i)) * r2).mat() for i in range(4)]
-    b.out(px, T(PX)), b.out(py, T(PY))
-    for i in range(4):
-        b.out(q[i], T(QX0 + i))
-    px3n = (px * -3).mat()
-    b.out(px3n, T(NPX3))
-    b.out(one, T(F))
-    zero = b.inp(C(C_ZERO))
-    for i in range(1, 12):
-        b.out(zero, T(F + i))
-    Tp = ((q[0], q[1]), (q[2], q[3]), (one, b.zero()))
-    Qa = ((q[0], q[1]), (q[2], q[3]))
-    # Z = (1, 0): products with the zero imaginary part vanish at trace time
-    T2, ld = t_double(cfg, Tp, px3n, py)
-    la = None
-    if first_add:
-        T2 = tuple(tw.f2_mat(c) for c in T2)
-        T2, la = t_add(cfg, T2, Qa, px, py)
-    _out_t(b, T2, ld, la, zero)
-    return b
+# Per-pair block: PX, PY, QX0, QX1, QY0, QY1, T(6), LD(6), LA(6), NPX3 = 25 slots.
+# Pair 0 uses the named slots above (PX .. NPX3 are contiguous); in the multi-pair
+# programs pairs 1.. live in further blocks at MP_BLOCK0 + 25 (g - 1).
+PAIR_BLOCK = 25
+MP_BLOCK0 = REG0 + 24                      # overlays registers R2.. (unused by the Miller kernel)
+MP_G = 3                                   # pairs per team in the multi-pair programs
+
+
+def pair_base(g):
+    return PX if g == 0 else MP_BLOCK0 + PAIR_BLOCK * (g - 1)
+
+
+def mp_temp0(G):
+    return max(TEMP0, MP_BLOCK0 + PAIR_BLOCK * (G - 1))
+
+
+class PairSlots:
+    def __init__(self, g):
+        o = pair_base(g)
+        self.PX, self.PY, self.QX0, self.QY0 = o, o + 1, o + 2, o + 4
+        self.TX, self.TY, self.TZ = o + 6, o + 8, o + 10
+        self.LD, self.LA, self.NPX3 = o + 12, o + 18, o + 24
+
+
+assert PairSlots(0).TX == TX and PairSlots(0).LD == LD and PairSlots(0).LA == LA and PairSlots(0).NPX3 == NPX3
+
+
+def _out_t(b, ps, T2, ld, la, zero):
+    _out2z(b, T2[0], ps.TX, zero), _out2z(b, T2[1], ps.TY, zero), _out2z(b, T2[2], ps.TZ, zero)
+    for i, c in enumerate(ld):
+        _out2z(b, c, ps.LD + 2 * i, zero)
+    if la is not None:
+        for i, c in enumerate(la):
+            _out2z(b, c, ps.LA + 2 * i, zero)
 
 
 def _out2z(b, e, off, zero):
@@ -196,51 +203,77 @@ def _out2z(b, e, off, zero):
     b.out(e[1] if not e[1].is_zero() else zero, T(off + 1))
 
 
-def _out_t(b, T2, ld, la, zero):
-    _out2z(b, T2[0], TX, zero), _out2z(b, T2[1], TY, zero), _out2z(b, T2[2], TZ, zero)
-    for i, c in enumerate(ld):
-        _out2z(b, c, LD + 2 * i, zero)
-    if la is not None:
-        for i, c in enumerate(la):
-            _out2z(b, c, LA + 2 * i, zero)
-
-
-def seg_body(cfg, cur_add, nxt):
-    """One pipelined Miller iteration:
-         f <- f^2 * LD (* LA if cur_add)          [lines of the current step]
-         (T, LD, LA) <- next step of the T chain  [nxt: 0 tangent, 1 tangent+chord,
-                                                   2 nothing (last iteration)]"""
-    b = Builder("body_%d%d" % (cur_add, nxt))
-    f = in12(b, F)
-    ld = [in2(b, LD + 2 * i) for i in range(3)]
-    f = tw.f12_sqr(cfg, f)
-    f = tw.f12_mul_by_014(cfg, f, *ld)
-    if cur_add:
-        la = [in2(b, LA + 2 * i) for i in range(3)]
-        f = tw.f12_mul_by_014(cfg, f, *la)
-    out12(b, f, F)
-    if nxt != 2:
-        zero = b.inp(C(C_ZERO))
-        Tp = (in2(b, TX), in2(b, TY), in2(b, TZ))
-        Qa = (in2(b, QX0), in2(b, QY0))
-        px, py, px3n = b.inp(T(PX)), b.inp(T(PY)), b.inp(T(NPX3))
-        T2, ldn = t_double(cfg, Tp, px3n, py)
-        lan = None
-        if nxt == 1:
+def seg_init(cfg, first_add, G=1, name="init"):
+    """Raw inputs -> Montgomery; T = Q, F = 1; first tangent(+chord) step, for G pairs."""
+    b = Builder(name)
+    r2 = b.inp(C(C_R2))
+    one = b.inp(C(C_ONE))
+    zero = b.inp(C(C_ZERO))
+    b.out(one, T(F))
+    for i in range(1, 12):
+        b.out(zero, T(F + i))
+    for g in range(G):
+        ps = PairSlots(g)
+        px = (b.inp(T(ps.PX)) * r2).mat()
+        py = (b.inp(T(ps.PY)) * r2).mat()
+        q = [(b.inp(T(ps.QX0 + i)) * r2).mat() for i in range(4)]
+        b.out(px, T(ps.PX)), b.out(py, T(ps.PY))
+        for i in range(4):
+            b.out(q[i], T(ps.QX0 + i))
+        px3n = (px * -3).mat()
+        b.out(px3n, T(ps.NPX3))
+        Tp = ((q[0], q[1]), (q[2], q[3]), (one, b.zero()))
+        Qa = ((q[0], q[1]), (q[2], q[3]))
+        # Z = (1, 0): products with the zero imaginary part vanish at trace time
+        T2, ld = t_double(cfg, Tp, px3n, py)
+        la = None
+        if first_add:
             T2 = tuple(tw.f2_mat(c) for c in T2)
-            T2, lan = t_add(cfg, T2, Qa, px, py)
-        _out_t(b, T2, ldn, lan, zero)
+            T2, la = t_add(cfg, T2, Qa, px, py)
+        _out_t(b, ps, T2, ld, la, zero)
     return b
 
 
-def miller_script():
+def seg_body(cfg, cur_add, nxt, G=1, prefix="body"):
+    """One pipelined Miller iteration for G pairs sharing the accumulator:
+         f <- f^2 * prod_g LD_g (* LA_g if cur_add)    [lines of the current step]
+         (T_g, LD_g, LA_g) <- next step of each T chain [nxt: 0 tangent, 1 tangent+chord,
+                                                         2 nothing (last iteration)]"""
+    b = Builder("%s_%d%d" % (prefix, cur_add, nxt))
+    f = in12(b, F)
+    f = tw.f12_sqr(cfg, f)
+    for g in range(G):
+        ps = PairSlots(g)
+        ld = [in2(b, ps.LD + 2 * i) for i in range(3)]
+        f = tw.f12_mul_by_014(cfg, f, *ld)
+        if cur_add:
+            la = [in2(b, ps.LA + 2 * i) for i in range(3)]
+            f = tw.f12_mul_by_014(cfg, f, *la)
+    out12(b, f, F)
+    if nxt != 2:
+        zero = b.inp(C(C_ZERO))
+        for g in range(G):
+            ps = PairSlots(g)
+            Tp = (in2(b, ps.TX), in2(b, ps.TY), in2(b, ps.TZ))
+            Qa = (in2(b, ps.QX0), in2(b, ps.QY0))
+            px, py, px3n = b.inp(T(ps.PX)), b.inp(T(ps.PY)), b.inp(T(ps.NPX3))
+            T2, ldn = t_double(cfg, Tp, px3n, py)
+            lan = None
+            if nxt == 1:
+                T2 = tuple(tw.f2_mat(c) for c in T2)
+                T2, lan = t_add(cfg, T2, Qa, px, py)
+            _out_t(b, ps, T2, ldn, lan, zero)
+    return b
+
+
+def miller_script(init="init", prefix="body"):
     """[(segment name)] for the whole loop.  Step p (p = 62 .. 0) multiplies by
     the chord line iff bit p of |x| is set (fields_t.py:1104)."""
     bits = [(NX >> p) & 1 for p in range(62, -1, -1)]
-    script = ["init"]
+    script = [init]
     for k, bit in enumerate(bits):
         nxt = 2 if k + 1 == len(bits) else bits[k + 1]
-        script.append("body_%d%d" % (bit, nxt))
+        script.append("%s_%d%d" % (prefix, bit, nxt))
     return script, bits[0]
 
 
@@ -387,10 +420,24 @@ def build_all(cfg=None, verbose=False):
     for name in sorted(set(mscript[1:])):
         builders.append(seg_body(cfg, int(name[5]), int(name[6])))
     fscript = final_exp_script()
-    extra = ["from_mont_1_0", "to_mont_0_1", "to_mont_1_1", "set_one_0", "mul_0_1", "copy_0_1"]
+    extra = ["from_mont_1_0", "to_mont_0_1", "to_mont_1_1", "set_one_0", "mul_0_1", "copy_0_1", "copy_1_0"]
     for name in sorted(set(fscript + extra)):
         builders.append(seg_by_name(cfg, name))
     segs = {}
     for b in builders:
         segs[b.name] = schedule(b, temp_base=TEMP0, verbose=verbose)
     return segs, mscript, fscript
+
+
+def build_multi(cfg=None, G=MP_G, verbose=False):
+    """Miller-loop programs for G pairs per team sharing one accumulator:
+    returns (segments by name, script)."""
+    cfg = cfg or tw.Cfg()
+    script, first_add = miller_script("mp_init", "mp_body")
+    builders = [seg_init(cfg, first_add, G, "mp_init")]
+    for name in sorted(set(script[1:])):
+        builders.append(seg_body(cfg, int(name[-2]), int(name[-1]), G, "mp_body"))
+    segs = {}
+    for b in builders:
+        segs[b.name] = schedule(b, temp_base=mp_temp0(G), verbose=verbose)
+    return segs, script
