@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--streams", type=int, default=8,
                     help="independent verifications kept in flight (each on its own HIP stream + context)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1 (gloo: rehearsal on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -67,14 +69,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    local_dev = local % max(1, ndev)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     S = max(1, args.streams)
-    engs = [_native.Engine(local) for _ in range(S)]
+    engs = [_native.Engine(local_dev) for _ in range(S)]
     eng = engs[0]
 
     gold = os.path.join(ROOT, "tests", "golden")
@@ -113,7 +120,13 @@ def main():
         else:
             engs[k].miller_product_dev(t1.data_ptr(), t2.data_ptr(), n, parts[k].data_ptr(), st)
             with torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(gath[k], parts[k])
+                if args.backend == "nccl":
+                    dist.all_gather_into_tensor(gath[k], parts[k])       # RCCL: 576 bytes per rank
+                else:
+                    stream.synchronize()
+                    host = [torch.zeros(144, dtype=torch.int32) for _ in range(world)]
+                    dist.all_gather(host, parts[k].cpu())
+                    gath[k].copy_(torch.cat(host).to(dev))
             engs[k].final_exp_product_dev(gath[k].data_ptr(), world, outs[k].data_ptr(), st)
 
     torch.cuda.synchronize()
@@ -138,24 +151,25 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    results = [bytes(o.cpu().numpy()) for o in outs[:min(S, args.steps)]]
     ktimes = [t for e in engs for t in e.timing_read()]        # HIP events around every kernel, on its stream
     overlapped_miller_ms = [ms for k, ms in ktimes if k == 0]
     # the same launches again with nothing else on the GPU: per-launch duration of
     # the dominant kernel for the roofline object (overlapping launches stretch
     # each other's durations, which would understate the kernel)
+    solo_out = torch.zeros(576, dtype=torch.uint8, device=dev)
     for i in range(min(args.steps, 16)):
-        engs[0].pairing_multi_dev(t1.data_ptr(), t2.data_ptr(), n, outs[0].data_ptr(), streams[0].cuda_stream)
+        engs[0].pairing_multi_dev(t1.data_ptr(), t2.data_ptr(), n, solo_out.data_ptr(), streams[0].cuda_stream)
         streams[0].synchronize()
     solo = engs[0].timing_read()
     miller_ms = [ms for k, ms in solo if k == 0]
     fexp_ms = [ms for k, ms in solo if k == 2]
     kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
-    results = [bytes(o.cpu().numpy()) for o in outs[:min(S, args.steps)]]
     assert all(r == results[0] for r in results), "streams disagree"
     result = results[0]
 
