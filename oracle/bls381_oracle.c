@@ -133,10 +133,79 @@ static void fq_pow_limbs(fq *r, const fq *a, const uint64_t *e, int nl) {
         }
     *r = res;
 }
-/* fq_invert, fields_t.py:47-55.  The reference runs extended Euclid, which
- * returns 0 for input 0; a^(q-2) yields the same residue for every input,
- * including 0 -> 0. */
-static void fq_inv(fq *r, const fq *a) { fq_pow_limbs(r, a, ORC_Q_MINUS_2, 6); }
+/* fq_invert, fields_t.py:47-55.  The reference runs the extended Euclidean
+ * algorithm on Python ints and returns 0 for input 0.  Same function here as a
+ * binary extended Euclid on the (Montgomery) content: c^-1 mod q, then two
+ * Montgomery multiplications by R^2 bring  (xR)^-1  back to  x^-1 R.
+ * (a^(q-2) gives the same residues; it is kept as fq_inv_fermat for the tests.) */
+static void fq_inv_fermat(fq *r, const fq *a) { fq_pow_limbs(r, a, ORC_Q_MINUS_2, 6); }
+
+static int big_is_one(const uint64_t *a) { return a[0] == 1 && !(a[1] | a[2] | a[3] | a[4] | a[5]); }
+static int big_geq(const uint64_t *a, const uint64_t *b) {
+    for (int i = 5; i >= 0; i--) {
+        if (a[i] > b[i]) return 1;
+        if (a[i] < b[i]) return 0;
+    }
+    return 1;
+}
+static void big_sub(uint64_t *a, const uint64_t *b) {
+    u128 br = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 d = (u128)a[i] - b[i] - (uint64_t)br;
+        a[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+}
+static void big_shr1(uint64_t *a, uint64_t top) {
+    for (int i = 0; i < 5; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 63);
+    a[5] = (a[5] >> 1) | (top << 63);
+}
+static void mod_half(uint64_t *x) {            /* x / 2 mod q, x < q */
+    uint64_t carry = 0;
+    if (x[0] & 1) {
+        u128 c = 0;
+        for (int i = 0; i < 6; i++) {
+            c += (u128)x[i] + ORC_Q[i];
+            x[i] = (uint64_t)c;
+            c >>= 64;
+        }
+        carry = (uint64_t)c;
+    }
+    big_shr1(x, carry);
+}
+static void mod_sub(uint64_t *x, const uint64_t *y) {   /* (x - y) mod q */
+    u128 br = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 d = (u128)x[i] - y[i] - (uint64_t)br;
+        x[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+    if (br) {
+        u128 c = 0;
+        for (int i = 0; i < 6; i++) {
+            c += (u128)x[i] + ORC_Q[i];
+            x[i] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+}
+static void fq_inv(fq *r, const fq *a) {
+    if (fq_is_zero(a)) { *r = FQ_ZERO; return; }
+    uint64_t u[6], v[6], x1[6] = {1, 0, 0, 0, 0, 0}, x2[6] = {0, 0, 0, 0, 0, 0};
+    memcpy(u, a->l, sizeof u);
+    memcpy(v, ORC_Q, sizeof v);
+    while (!big_is_one(u) && !big_is_one(v)) {
+        while (!(u[0] & 1)) { big_shr1(u, 0); mod_half(x1); }
+        while (!(v[0] & 1)) { big_shr1(v, 0); mod_half(x2); }
+        if (big_geq(u, v)) { big_sub(u, v); mod_sub(x1, x2); }
+        else { big_sub(v, u); mod_sub(x2, x1); }
+    }
+    fq t, r2;
+    memcpy(t.l, big_is_one(u) ? x1 : x2, sizeof t.l);   /* content^-1 = x^-1 R^-1 */
+    memcpy(r2.l, ORC_R2, sizeof r2.l);
+    fq_mul(&t, &t, &r2);                                 /* x^-1 */
+    fq_mul(r, &t, &r2);                                  /* x^-1 R */
+}
 
 static void fq_from_bytes(fq *r, const uint8_t *be) {
     fq t;
@@ -755,5 +824,14 @@ EXPORT int oracle_g2_msm(const uint8_t *pts, const uint8_t *scalars, size_t slen
     fq2_to_bytes(out, &r.x); fq2_to_bytes(out + 96, &r.y);
     if (out_inf) *out_inf = (uint8_t)r.inf;
     return 0;
+}
+/* test hook: both inversion routes agree (1) or not (0) on the given element */
+EXPORT int oracle_inv_selfcheck(const uint8_t a[48]) {
+    ensure_init();
+    fq x, r1, r2;
+    fq_from_bytes(&x, a);
+    fq_inv(&r1, &x);
+    fq_inv_fermat(&r2, &x);
+    return fq_eq(&r1, &r2);
 }
 EXPORT const char *oracle_version(void) { return "bls381-oracle/1 (restates python-bls v0.1.10 fields_t.py)"; }
