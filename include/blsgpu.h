@@ -108,6 +108,15 @@ int blsgpu_g1_msm_dev(blsgpu_ctx *ctx, const void *d_pts, const void *d_scalars,
 int blsgpu_g2_msm_dev(blsgpu_ctx *ctx, const void *d_pts, const void *d_scalars, size_t k,
                       size_t groups, void *d_out, void *d_out_inf, void *stream);
 
+/* Hash to G2 after the SHA-256 step: hash_to_point_prehashed_Fq2 (ec.py:528-550)
+ * from the two Fq2 elements t0, t1 (the four hash512 values of ec.py:531-534,
+ * reduced mod q) onwards: sw_encode twice (ec.py:449-507), their sum, cofactor
+ * clearing with psi.  t: n x 192 bytes (t0.c0, t0.c1, t1.c0, t1.c1 big-endian
+ * canonical); out: n x 192 bytes affine G2, (0,0) for infinity.  t = 0 encodes
+ * to infinity as in ec.py:450-452. */
+int blsgpu_map_to_g2(blsgpu_ctx *ctx, const uint8_t *t, size_t n, uint8_t *out);
+int blsgpu_map_to_g2_dev(blsgpu_ctx *ctx, const void *d_t, size_t n, void *d_out, void *stream);
+
 /* Measurement aid (bench.py): when enabled, HIP events are recorded on the
  * launch stream around every kernel this context launches (up to 1024 launches
  * between reads).  blsgpu_timing_read waits for them and returns, per launch,

@@ -18,6 +18,7 @@ SYMBOLS = (
     "blsgpu_timing_enable", "blsgpu_timing_read",
     "blsgpu_g1_msm", "blsgpu_g2_msm", "blsgpu_g1_msm_dev", "blsgpu_g2_msm_dev",
     "blsgpu_final_exp_batch", "blsgpu_pairing_multi_batch", "blsgpu_pairing_multi_batch_dev",
+    "blsgpu_map_to_g2", "blsgpu_map_to_g2_dev",
 )
 
 _lib = None
@@ -68,6 +69,8 @@ def load_library(path=None):
         L.blsgpu_final_exp_batch.argtypes = [vp, cp, sz, cp]
         L.blsgpu_pairing_multi_batch.argtypes = [vp, cp, cp, sz, sz, cp]
         L.blsgpu_pairing_multi_batch_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp]
+        L.blsgpu_map_to_g2.argtypes = [vp, cp, sz, cp]
+        L.blsgpu_map_to_g2_dev.argtypes = [vp, vp, sz, vp, vp]
         L.blsgpu_timing_enable.argtypes = [vp, ctypes.c_int]
         L.blsgpu_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), sz,
                                          ctypes.POINTER(sz)]
@@ -141,6 +144,14 @@ class Engine:
         out = ctypes.create_string_buffer(max(1, 576 * groups))
         self._check(self.lib.blsgpu_pairing_multi_batch(self.h, g1, g2, gsz, groups, out), "blsgpu_pairing_multi_batch")
         return out.raw[:576 * groups]
+
+    def map_to_g2(self, t: bytes) -> bytes:
+        """t: n x 192 bytes (t0.c0, t0.c1, t1.c0, t1.c1) -> n x 192 bytes affine G2."""
+        if len(t) % 192:
+            raise ValueError("need n x 192 bytes")
+        out = ctypes.create_string_buffer(max(1, len(t)))
+        self._check(self.lib.blsgpu_map_to_g2(self.h, t, len(t) // 192, out), "blsgpu_map_to_g2")
+        return out.raw[:len(t)]
 
     def _msm(self, fn, psz, pts, scalars, k, groups):
         n = k * groups

@@ -25,10 +25,14 @@ class HipProvider:
     def g2_msm(self, pts: bytes, scalars, k: int, groups: int = 1):
         return self._eng.g2_msm(pts, scalars, k, groups)
 
+    def map_to_g2(self, t: bytes) -> bytes:
+        return self._eng.map_to_g2(t)
+
 
 def use(provider):
     """Install a provider object with pairing_multi(g1, g2, n), final_exp(x),
-    g1_msm / g2_msm(pts, scalars|None, k, groups) -> (bytes, [is_inf])."""
+    g1_msm / g2_msm(pts, scalars|None, k, groups) -> (bytes, [is_inf]),
+    map_to_g2(t: n x 192 bytes) -> n x 192 bytes."""
     global _provider
     _provider = provider
 

@@ -8,7 +8,7 @@ from . import hostmath as H
 from .aggregation_info import AggregationInfo
 from .bls12381 import n as GROUP_ORDER
 from .ec import (AffinePoint, JacobianPoint, default_ec, generator_Fq,
-                 hash_to_point_prehashed_Fq2)
+                 hash_to_points_prehashed_Fq2)
 from .fields import Fq12
 from .keys import PrivateKey, PublicKey
 from .pairing import ate_pairing_multi
@@ -86,7 +86,7 @@ class BLS:
         by_message = {}
         for mh, pk in zip(info.message_hashes, info.public_keys):
             by_message.setdefault(mh, []).append(pk)
-        key_groups, exp_groups, Qs = [], [], []
+        key_groups, exp_groups = [], []
         for mh, keys in by_message.items():
             uniq = list(set(keys))
             try:
@@ -94,7 +94,7 @@ class BLS:
             except KeyError:
                 return False
             key_groups.append([pk.value for pk in uniq])
-            Qs.append(hash_to_point_prehashed_Fq2(mh))
+        Qs = hash_to_points_prehashed_Fq2(list(by_message))
         Ps = [t.to_affine() for t in _g1_sums(key_groups, exp_groups)]
         neg_g1 = generator_Fq() * (GROUP_ORDER - 1)
         res = ate_pairing_multi([neg_g1] + Ps, [signature.value.to_affine()] + Qs, default_ec)

@@ -205,5 +205,16 @@ def hash_to_point_prehashed_Fq2(m, ec=default_ec_twist):
     return AffinePoint._from(H.F2, H.hash_to_g2_prehashed(_as_bytes(m), hash512), ec)
 
 
+def hash_to_points_prehashed_Fq2(ms, ec=default_ec_twist):
+    """Batch form of hash_to_point_prehashed_Fq2: the SHA-256 chain on the host, then
+    encodings, sum and cofactor clearing for all messages in one GPU call."""
+    from . import backend
+    ms = [_as_bytes(m) for m in ms]
+    if not ms:
+        return []
+    out = backend.get().map_to_g2(b"".join(H.g2_hash_field_elements(m, hash512) for m in ms))
+    return [AffinePoint._from(H.F2, H.g2_from_abi(out[192 * i:192 * (i + 1)]), ec) for i in range(len(ms))]
+
+
 def hash_to_point_Fq2(m, ec=default_ec_twist):
     return hash_to_point_prehashed_Fq2(hash256(m), ec)

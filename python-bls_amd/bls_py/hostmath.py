@@ -330,13 +330,24 @@ def hash_to_g1_prehashed(m, hash512):
     return jac_to_affine(F1, jac_mul(F1, P, C.h))
 
 
+def g2_hash_field_elements(m, hash512):
+    """The four field elements of ec.py:531-534 as 192 bytes (t0.c0, t0.c1, t1.c0, t1.c1):
+    the input of blsgpu_map_to_g2."""
+    return b"".join(fq_bytes(int.from_bytes(hash512(m + tag), "big") % Q)
+                    for tag in (b"G2_0_c0", b"G2_0_c1", b"G2_1_c0", b"G2_1_c1"))
+
+
 def hash_to_g2_prehashed(m, hash512):
     """ec.py:528-550: two SW encodings, then Budroni-Pintore cofactor clearing."""
     def t(tag):
         return int.from_bytes(hash512(m + tag), "big") % Q
     t0 = (t(b"G2_0_c0"), t(b"G2_0_c1"))
     t1 = (t(b"G2_1_c0"), t(b"G2_1_c1"))
-    P = jac_add(F2, aff_to_jac(F2, sw_encode(F2, t0)), aff_to_jac(F2, sw_encode(F2, t1)))
+    return clear_cofactor_g2(jac_add(F2, aff_to_jac(F2, sw_encode(F2, t0)), aff_to_jac(F2, sw_encode(F2, t1))))
+
+
+def clear_cofactor_g2(P):
+    """ec.py:536-550 (Budroni-Pintore); Jacobian in, affine out."""
     x = -C.x
     aff = lambda J: jac_to_affine(F2, J)            # noqa: E731
     jac = lambda A: aff_to_jac(F2, A)               # noqa: E731

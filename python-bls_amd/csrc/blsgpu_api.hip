@@ -13,6 +13,7 @@
 #include "../../include/blsgpu.h"
 #include "blsgpu_kernels.hip"
 #include "blsgpu_msm.hip"
+#include "blsgpu_h2c.hip"
 
 namespace {
 
@@ -199,7 +200,9 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     size_t o_m = 0;
     size_t o_mp = o_m + al(sizeof(BLSVM_MILLER_FLAT));
-    size_t o_f = o_mp + al(sizeof(BLSVM_MP_FLAT));
+    size_t o_h1 = o_mp + al(sizeof(BLSVM_MP_FLAT));
+    size_t o_h2 = o_h1 + al(sizeof(BLSVM_H1_FLAT));
+    size_t o_f = o_h2 + al(sizeof(BLSVM_H2_FLAT));
     size_t o_s = o_f + al(sizeof(BLSVM_FEXP_FLAT));
     size_t o_data = o_s + al(sizeof(BLSVM_SEG_FLAT));
     size_t o_c = o_data + al(sizeof(BLSVM_DATA));
@@ -211,6 +214,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     char* base = (char*)c->d_tables;
     struct { size_t off; const void* src; size_t len; } parts[] = {
         {o_m, BLSVM_MILLER_FLAT, sizeof(BLSVM_MILLER_FLAT)}, {o_mp, BLSVM_MP_FLAT, sizeof(BLSVM_MP_FLAT)},
+        {o_h1, BLSVM_H1_FLAT, sizeof(BLSVM_H1_FLAT)},        {o_h2, BLSVM_H2_FLAT, sizeof(BLSVM_H2_FLAT)},
         {o_f, BLSVM_FEXP_FLAT, sizeof(BLSVM_FEXP_FLAT)},
         {o_s, BLSVM_SEG_FLAT, sizeof(BLSVM_SEG_FLAT)},       {o_data, BLSVM_DATA, sizeof(BLSVM_DATA)},
         {o_c, BLSVM_CONSTS, sizeof(BLSVM_CONSTS)}};
@@ -223,6 +227,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     }
     c->tabs.mflat = (const uint2*)(base + o_m);
     c->tabs.mpflat = (const uint2*)(base + o_mp);
+    c->tabs.h1flat = (const uint2*)(base + o_h1);
+    c->tabs.h2flat = (const uint2*)(base + o_h2);
     c->tabs.fflat = (const uint2*)(base + o_f);
     c->tabs.segflat = (const uint2*)(base + o_s);
     c->tabs.data = (const uint16_t*)(base + o_data);
@@ -244,6 +250,10 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
                               MILLER_WAVES * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize,
                               REDUCE_WAVES * blsgpu::TEAM_BYTES);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_encode, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              blsgpu::H1_TEAM_DW * 4);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_clear, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              blsgpu::H2_TEAM_DW * 4);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_miller_mp, hipFuncAttributeMaxDynamicSharedMemorySize,
                               blsgpu::MP_TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_final_groups, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -548,6 +558,55 @@ BLSGPU_EXPORT int blsgpu_g2_msm_dev(blsgpu_ctx* c, const void* d_pts, const void
     if (!c || !d_out) return fail(-EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     return msm_dev<2>(c, d_pts, d_scalars, k, groups, d_out, d_out_inf, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------ hash to G2 -----
+// t: n x 192 bytes = (t0.c0, t0.c1, t1.c0, t1.c1) canonical big-endian, the four
+// hash512 values of ec.py:531-534 reduced mod q; out: n x 192 bytes affine G2.
+BLSGPU_EXPORT int blsgpu_map_to_g2_dev(blsgpu_ctx* c, const void* d_t, size_t n, void* d_out, void* stream) {
+    if (!c || (n && (!d_t || !d_out))) return fail(-EINVAL, "NULL argument");
+    if (n == 0) return 0;
+    if (n > 0x3FFFFFF0ull) return fail(-EINVAL, "batch too large");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    size_t need = 2 * n * 60;                       // Montgomery (x, y, z.c0) per encoding, u32
+    if (need > c->msm_part_cap) {
+        if (c->d_msm_part) (void)hipFree(c->d_msm_part);
+        c->d_msm_part = nullptr;
+        c->msm_part_cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_msm_part, need * sizeof(uint32_t)));
+        c->msm_part_cap = need;
+    }
+    unsigned b1 = (unsigned)((2 * n + BLSVM_H1_NE - 1) / BLSVM_H1_NE);
+    hipLaunchKernelGGL(blsgpu::k_h2c_encode, dim3(b1), dim3(64), (size_t)blsgpu::H1_TEAM_DW * 4, st, c->tabs,
+                       (const uint32_t*)d_t, (uint32_t)(2 * n), c->d_msm_part);
+    HIP_TRY(hipGetLastError());
+    unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);
+    hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs,
+                       c->d_msm_part, (uint32_t)n, (uint32_t*)d_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+BLSGPU_EXPORT int blsgpu_map_to_g2(blsgpu_ctx* c, const uint8_t* t, size_t n, uint8_t* out) {
+    if (!c || (n && (!t || !out))) return fail(-EINVAL, "NULL argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t need = n * 192 * 2 + 64;
+    if (need > c->io_cap) {
+        if (c->d_io) (void)hipFree(c->d_io);
+        c->d_io = nullptr;
+        c->io_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_io, need));
+        c->io_cap = need;
+    }
+    char* din = (char*)c->d_io;
+    char* dout = din + n * 192;
+    HIP_TRY(hipMemcpy(din, t, n * 192, hipMemcpyHostToDevice));
+    int rc = blsgpu_map_to_g2_dev(c, din, n, dout, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, dout, n * 192, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 #ifdef BLSGPU_STAMPS

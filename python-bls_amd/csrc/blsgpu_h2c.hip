@@ -1,0 +1,68 @@
+// blsgpu_h2c.hip -- hash-to-G2 after the SHA-256 step (included by blsgpu_api.hip).
+//
+// Replaces, for batches, the reference's hash_to_point_prehashed_Fq2 (ec.py:528-550)
+// from the field elements t0, t1 onwards: sw_encode (ec.py:449-507) twice, the sum,
+// and the psi-based cofactor clearing.  Branch-free restatement in
+// vmgen/h2c_programs.py; the SHA-256/hash512 chain stays on the host.
+#pragma once
+
+namespace blsgpu {
+
+constexpr int H1_TEAM_DW = BLSVM_H1_SLOTS * 12;
+constexpr int H2_TEAM_DW = BLSVM_H2_SLOTS * 12;
+
+__device__ __forceinline__ void team_init_consts_h2c(const VmTables& T, uint32_t* team, uint32_t lane) {
+    for (uint32_t i = lane; i < BLSVM_NCONST_H2C * 12; i += 64) team[i] = T.consts[i];
+}
+
+// Kernel H1: one team = BLSVM_H1_NE encodings.  t: n_enc x 96 bytes (c0 || c1,
+// big-endian canonical); out: n_enc x 60 u32 = (x, y, z.c0) in Montgomery limbs, z = 0 for infinity.
+__global__ void __launch_bounds__(64, 2) k_h2c_encode(VmTables T, const uint32_t* __restrict__ t, uint32_t n_enc,
+                                                      uint32_t* __restrict__ out) {
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t first = blockIdx.x * BLSVM_H1_NE;
+    team_init_consts_h2c(T, team, lane);
+    for (uint32_t d = lane; d < BLSVM_H1_NE * 24; d += 64) {
+        uint32_t e = d / 24, o = d % 24, c = o / 12, w = o % 12;
+        // encodings past the end run on t = (1, 0); their results are dropped
+        uint32_t v = (first + e < n_enc) ? bswap32(t[(size_t)(first + e) * 24 + o]) : ((c == 0 && w == 11) ? 1u : 0u);
+        team[(BLSVM_H1_T + 2 * e + c) * 12 + (11 - w)] = v;
+    }
+    wave_fence();
+    run_rounds(T, T.h1flat, BLSVM_H1_FLAT_LEN, 0, lane);
+    for (uint32_t d = lane; d < BLSVM_H1_NE * 60; d += 64) {
+        uint32_t e = d / 60;
+        if (first + e < n_enc) out[(size_t)first * 60 + d] = team[BLSVM_H1_S * 12 + d];
+    }
+}
+
+// Kernel H2: one team = BLSVM_H2_NM messages: P = S0 + S1, cofactor clearing,
+// canonical affine bytes (x.c0 || x.c1 || y.c0 || y.c1, 192 B per message).
+__global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg,
+                                                     uint32_t* __restrict__ out) {
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t first = blockIdx.x * BLSVM_H2_NM;
+    team_init_consts_h2c(T, team, lane);
+    for (uint32_t d = lane; d < BLSVM_H2_NM * 120; d += 64) {
+        uint32_t m = d / 120;
+        uint32_t src_m = (first + m < n_msg) ? first + m : first;       // pad with a valid message
+        team[BLSVM_H2_S * 12 + d] = enc[(size_t)src_m * 120 + (d % 120)];
+    }
+    wave_fence();
+    run_rounds(T, T.h2flat, BLSVM_H2_FLAT_LEN, 0, lane);
+    if (lane < 4u * BLSVM_H2_NM) {
+        uint32_t X[12];
+        lds_load12(X, (BLSVM_H2_OUT + lane) * 3);
+        bls::fq_canon(X);
+        lds_store12(X, (BLSVM_H2_OUT + lane) * 3);
+    }
+    wave_fence();
+    for (uint32_t d = lane; d < BLSVM_H2_NM * 48; d += 64) {
+        uint32_t m = d / 48, o = d % 48, e = o / 12, w = o % 12;
+        if (first + m < n_msg) out[(size_t)(first + m) * 48 + o] = bswap32(team[(BLSVM_H2_OUT + 4 * m + e) * 12 + (11 - w)]);
+    }
+}
+
+}  // namespace blsgpu

@@ -31,6 +31,8 @@ namespace blsgpu {
 struct VmTables {
     const uint2* mflat;       // Miller loop: flat round sequence {data_off, meta}
     const uint2* mpflat;      // Miller loop, BLSVM_MP_G pairs per team
+    const uint2* h1flat;      // hash to G2: the two SW encodings
+    const uint2* h2flat;      // hash to G2: sum + cofactor clearing
     const uint2* fflat;       // final exponentiation
     const uint2* segflat;     // directly called segments (BLSVM_SEGF_*)
     const uint16_t* data;
@@ -122,7 +124,7 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
     gptr_u2 rec = (gptr_u2)(gdata + h0.x + lane * rec_len(h0.y));
     uint2 e = ld2(rec, 0);
 #ifdef BLSGPU_STAMPS
-    unsigned long long st_acc[3] = {0, 0, 0}, st_cnt[3] = {0, 0, 0}, st_lin[3] = {0, 0, 0};
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_cnt[4] = {0, 0, 0, 0}, st_lin[3] = {0, 0, 0};
 #endif
     for (uint32_t i = 0; i < n; ++i) {
 #ifdef BLSGPU_STAMPS
@@ -170,14 +172,14 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
             uint32_t S[2][12];
 #define BLSGPU_UOP(p) ((((p) + 1) & 1) ? ((((p) + 1) & 2) ? (ch[((p) + 1) >> 2].y >> 16) : (ch[((p) + 1) >> 2].x >> 16)) \
                                        : ((((p) + 1) & 2) ? (ch[((p) + 1) >> 2].y & 0xFFFFu) : (ch[((p) + 1) >> 2].x & 0xFFFFu)))
-            if (K > 0) lds_load12(S[0], base16 + (BLSGPU_UOP(0) & 511u) * 3u);
+            if (K > 0) lds_load12(S[0], base16 + (BLSGPU_UOP(0) & 1023u) * 3u);
 #pragma unroll
             for (int p = 0; p < 4 * LIN_CHUNKS - 1; p++) {
                 if ((uint32_t)p < K) {
                     if (p + 1 < 4 * LIN_CHUNKS - 1 && (uint32_t)(p + 1) < K)
-                        lds_load12(S[(p + 1) & 1], base16 + (BLSGPU_UOP(p + 1) & 511u) * 3u);
+                        lds_load12(S[(p + 1) & 1], base16 + (BLSGPU_UOP(p + 1) & 1023u) * 3u);
                     const uint32_t u = BLSGPU_UOP(p);
-                    bls::fat_mac(acc, S[p & 1], (u >> 9) & 63u, (uint32_t)((int32_t)(u << 16) >> 31));
+                    bls::fat_mac(acc, S[p & 1], (u >> 10) & 31u, (uint32_t)((int32_t)(u << 16) >> 31));
                 }
             }
 #undef BLSGPU_UOP
@@ -193,12 +195,20 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
             st_lin[0] += lt1 - lt0; st_lin[1] += lt2 - lt1; st_lin[2] += K;
 #endif
             if (rd != 0xFFFFu) lds_store12(D, base16 + rd);
-        } else {                                             // INV
+        } else if (kind == 2u) {                             // INV
             uint32_t ra = e_cur.x & 0xFFFFu, rd = e_cur.y & 0xFFFFu;
             if (rd != 0xFFFFu) {
                 uint32_t A[12], D[12];
                 lds_load12(A, base16 + ra);
                 bls::fq_inv(D, A);
+                lds_store12(D, base16 + rd);
+            }
+        } else {                                             // SGN
+            uint32_t ra = e_cur.x & 0xFFFFu, rd = e_cur.y & 0xFFFFu;
+            if (rd != 0xFFFFu) {
+                uint32_t A[12], D[12];
+                lds_load12(A, base16 + ra);
+                bls::fq_sgn(D, A);
                 lds_store12(D, base16 + rd);
             }
         }

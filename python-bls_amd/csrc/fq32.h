@@ -318,6 +318,28 @@ BLS_HD void fat_reduce(uint32_t* __restrict__ out, const uint64_t* __restrict__ 
     }
 }
 
+// ---- sign of a field element (the VM's SGN rounds) ----------------------------
+#define BLS_HALF_LIMBS /* (q - 1) / 2 */ \
+    {0xffffd555u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u, 0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u}
+#define BLS_ONE_MONT_LIMBS /* R mod q */ \
+    {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u, 0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u}
+// out = Montgomery 1 if the canonical value of a (Montgomery, relaxed) exceeds (q-1)/2, else 0:
+// the "lexicographically larger than its negation" test of ec.py:94-100
+BLS_HD void fq_sgn(uint32_t* __restrict__ out, const uint32_t* __restrict__ a) {
+    const uint32_t half[12] = BLS_HALF_LIMBS;
+    const uint32_t onem[12] = BLS_ONE_MONT_LIMBS;
+    const uint32_t raw1[12] = {1u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t x[12];
+    fq_mul_relaxed(x, a, raw1);       // leaves the Montgomery domain; result <= q
+    fq_canon(x);
+    uint32_t br = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) (void)subc(half[j], x[j], br);   // borrow <=> x > half
+    const bool gt = br != 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) out[j] = gt ? onem[j] : 0u;
+}
+
 // ---- helpers for the inversion ------------------------------------------
 BLS_HD bool big_is_one(const uint32_t* a) {
     uint32_t t = a[0] ^ 1u;

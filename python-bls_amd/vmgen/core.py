@@ -5,9 +5,11 @@ pairing formulas.  One wavefront ("team") owns one pairing; its Fq values live
 in an LDS scratchpad of 48-byte slots, and the 64 lanes execute *rounds*:
 
   MUL round   every active lane:  dst <- A * B            (Montgomery product)
-  LIN round   every active lane:  dst <- sum of +/- coef * slot, coef = 1..63
+  LIN round   every active lane:  dst <- sum of +/- coef * slot, coef = 1..31
   INV round   every active lane:  dst <- A^-1             (0 -> 0, like the
                                                            reference's fq_invert)
+  SGN round   every active lane:  dst <- 1 if canonical(A) > (q-1)/2 else 0
+                                  (the "lexicographically larger" test of ec.py:94-100)
 
 This module traces straight-line formulas written over `E` expressions into a
 DAG, list-schedules the DAG into rounds (<= 64 lanes each), allocates LDS slots
@@ -83,6 +85,9 @@ class E:
     def inv(self):
         return self.b.inv(self)
 
+    def sgn(self):
+        return self.b.sgn(self)
+
 
 class Builder:
     """Traces one segment."""
@@ -130,6 +135,10 @@ class Builder:
         a = self.materialise(x)
         return E(self, {self._new("inv", a=a): 1})
 
+    def sgn(self, x):
+        a = self.materialise(x)
+        return E(self, {self._new("sgn", a=a): 1})
+
     def out(self, e, fixed):
         """Declare that expression e must be left in the fixed slot reference."""
         assert not e.is_zero(), "segment outputs must be non-constant-zero (copy from ZERO const instead)"
@@ -138,7 +147,7 @@ class Builder:
 
 
 # ---------------------------------------------------------------------------
-MAX_COEF = 63          # a micro-op adds coef * x, x = slot or its 384-bit complement
+MAX_COEF = 31          # a micro-op adds coef * x, x = slot or its 384-bit complement
 MAX_LIN_MAG = 120      # sum of |coefficients| per linear combination
 K1_SLOT = None         # set by programs.py: slot holding -(2^384 - 1) mod q
 
@@ -202,7 +211,7 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
         needed.add(v.id)
         if v.kind in ("mul",):
             stack += [v.a, v.b]
-        elif v.kind == "inv":
+        elif v.kind in ("inv", "sgn"):
             stack.append(v.a)
         elif v.kind == "lin":
             stack += [t for _, t in v.terms]
@@ -211,7 +220,7 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
     def srcs(v):
         if v.kind == "mul":
             return [v.a, v.b]
-        if v.kind == "inv":
+        if v.kind in ("inv", "sgn"):
             return [v.a]
         return [t for _, t in v.terms]
 
@@ -222,7 +231,7 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
     # critical-path priority (cost: mul 10, inv 60, lin 1+terms/4)
     cost = {}
     for v in ops:
-        cost[v.id] = 10 if v.kind == "mul" else (60 if v.kind == "inv" else 1 + len(v.terms) // 4)
+        cost[v.id] = 10 if v.kind == "mul" else (60 if v.kind == "inv" else (8 if v.kind == "sgn" else 1 + len(v.terms) // 4))
     prio = {}
     for v in reversed(ops):
         prio[v.id] = cost[v.id] + max([prio[u.id] for u in users[v.id]], default=0)
@@ -232,7 +241,7 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
     # the longest input->v path.  A heavy op may run at any level in
     # [asap, alap] without lengthening the schedule; ops with slack are used
     # to fill lanes of rounds that must run anyway.
-    heavy = lambda v: v.kind in ("mul", "inv")
+    heavy = lambda v: v.kind in ("mul", "inv", "sgn")
     asap = {v.id: 0 for v in vals if v.kind == "in"}
     for v in ops:
         asap[v.id] = max([asap[s.id] for s in srcs(v)], default=0) + (1 if heavy(v) else 0)
@@ -270,7 +279,7 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
         if not pending:
             break
         level += 1
-        for kind in ("inv", "mul"):
+        for kind in ("inv", "sgn", "mul"):
             rh = [v for v in pending if v.kind == kind and all(s.id in done for s in srcs(v))]
             must = [v for v in rh if alap[v.id] <= level]
             if not must:
@@ -349,10 +358,10 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
             for v in r.ops:
                 lanes_out.append((slot[v.a.id], slot[v.b.id], slot[v.id]))
             seg.rounds.append({"kind": "mul", "K": 0, "lanes": lanes_out})
-        elif r.kind == "inv":
+        elif r.kind in ("inv", "sgn"):
             for v in r.ops:
                 lanes_out.append((slot[v.a.id], slot[v.id]))
-            seg.rounds.append({"kind": "inv", "K": 0, "lanes": lanes_out})
+            seg.rounds.append({"kind": r.kind, "K": 0, "lanes": lanes_out})
         else:
             K = 0
             for v in r.ops:
@@ -364,9 +373,14 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
     # destination is another copy's source must be ordered: do them in one
     # round, which is safe because every lane reads before any lane writes.
     if copies:
-        assert len(copies) <= lanes, "too many output copies"
-        seg.rounds.append({"kind": "lin", "K": 1,
-                           "lanes": [([(0, 1, slot[v.id])], fx) for v, fx in copies]})
+        # a copy must not overwrite a slot that a LATER copy round still reads
+        srcs_all = {slot[v.id] for v, _ in copies}
+        for i in range(0, len(copies), lanes):
+            chunk = copies[i:i + lanes]
+            later = {slot[v.id] for v, _ in copies[i + lanes:]}
+            assert not ({fx for _, fx in chunk} & later), "copy rounds would clobber a pending source"
+            seg.rounds.append({"kind": "lin", "K": 1,
+                               "lanes": [([(0, 1, slot[v.id])], fx) for v, fx in chunk]})
     seg.ntemp = ntemp
     nm = sum(len(r["lanes"]) for r in seg.rounds if r["kind"] == "mul")
     rm = sum(1 for r in seg.rounds if r["kind"] == "mul")

@@ -27,8 +27,8 @@ class Machine:
         self.const_base = const_base
         for i, c in enumerate(consts):
             self.team[const_base + i] = c
-        self.rounds_run = {"mul": 0, "lin": 0, "inv": 0}
-        self.lane_ops = {"mul": 0, "lin": 0, "inv": 0}
+        self.rounds_run = {"mul": 0, "lin": 0, "inv": 0, "sgn": 0}
+        self.lane_ops = {"mul": 0, "lin": 0, "inv": 0, "sgn": 0}
         self.uop_depth = 0
 
     def rd(self, r):
@@ -52,6 +52,9 @@ class Machine:
                     x = self.rd(a)
                     # content of inverse: (x R^-1)^-1 R = x^-1 R^2 ; 0 -> 0
                     writes.append((d, (pow(x, -1, Q) * R * R) % Q if x else 0))
+            elif kind == "sgn":
+                for a, d in rnd["lanes"]:
+                    writes.append((d, to_m(1) if from_m(self.rd(a)) > (Q - 1) // 2 else 0))
             else:
                 self.uop_depth += rnd["K"]
                 for uops, d in rnd["lanes"]:
