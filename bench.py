@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- BLS12-381 pairings/sec through the HIP multi-pairing engine.
 
-One "step" = one pass of the hot path (fq_ate_pairing_multi: Miller loops,
-Fq12 product, one final exponentiation) over one batch that is already resident
-in HBM.  Workload = BASELINE.json configs[1] shape: 1025 (pk, H(m)) pairs per
-GPU (1024 signatures + the (-G1, aggregate) pair).  With N ranks every rank
-processes its own 1025 pairs of ONE logical verification (weak scaling): Miller
-products per rank, one RCCL all-gather of the 576-byte Fq12 partials, final
-exponentiation on every rank.
+One "step" = one pass of the hot path over one batch that is already resident in
+HBM: B independent aggregate verifications (default 16), each the BASELINE.json
+configs[1] shape -- fq_ate_pairing_multi over 1025 (pk, H(m)) pairs per GPU (1024
+signatures + the (-G1, aggregate) pair): Miller loops, Fq12 product, its own
+final exponentiation.  One launch sequence per step (blsgpu_pairing_multi_batch_dev).
+With N ranks every rank holds 1025 pairs of EACH verification (weak scaling):
+Miller products per rank, one RCCL all-gather of the B x 576-byte Fq12 partials,
+B final exponentiations on every rank.  A single verification alone is latency
+bound (one wavefront runs its final exponentiation); its latency is reported in
+"single_verification".
 
 Prints ONE JSON line on rank 0.
 """
@@ -19,11 +22,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "python-bls_amd"))
-# independent verifications are kept in flight on separate HIP streams; the ROCm
-# runtime multiplexes streams onto 4 hardware queues unless told otherwise
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PAIRS_PER_GPU = 1025
+VERIFICATIONS_PER_STEP = 16
 # algorithmic work, SURVEY.md section 8(d): 6754 Fq-mults per pairing at 300
 # 32-bit MACs each, plus ~9.5k Fq-mults per final exponentiation
 MAC_PER_PAIRING = 6754 * 300
@@ -50,13 +52,15 @@ def cpu_baseline(g1, g2, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
-    ap.add_argument("--streams", type=int, default=8,
-                    help="independent verifications kept in flight (each on its own HIP stream + context)")
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per verification")
+    ap.add_argument("--verifications", type=int, default=VERIFICATIONS_PER_STEP,
+                    help="independent aggregate verifications per step (one launch sequence)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="steps in flight (the final exponentiations of one step overlap the Miller loops of the next)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for --gpus > 1 (gloo: rehearsal on a box with fewer GPUs than ranks)")
+                    help="gloo: CPU-side collective, for rehearsing the multi-rank path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -81,6 +85,7 @@ def main():
         else:
             dist.init_process_group("gloo")
     S = max(1, args.streams)
+    B = max(1, args.verifications)
     engs = [_native.Engine(local_dev) for _ in range(S)]
     eng = engs[0]
 
@@ -93,53 +98,48 @@ def main():
     reps = (n + 1024) // 1025
     g1 = (g1_all * reps)[:96 * n]
     g2 = (g2_all * reps)[:192 * n]
-    # every rank works on a rotation of the seeded batch (different data per rank)
-    rot = (rank * 131) % n
-    g1r = g1[96 * rot:] + g1[:96 * rot]
-    g2r = g2[192 * rot:] + g2[:192 * rot]
-    t1 = torch.frombuffer(bytearray(g1r), dtype=torch.uint8).to(dev)
-    t2 = torch.frombuffer(bytearray(g2r), dtype=torch.uint8).to(dev)
-    # Steps are independent verifications.  They are issued round-robin on S
-    # streams (own context/workspace/output each) so that the single-wavefront
-    # final exponentiation of one step overlaps the Miller loops of the next.
-    outs = [torch.zeros(576, dtype=torch.uint8, device=dev) for _ in range(S)]
-    parts = [torch.zeros(144, dtype=torch.int32, device=dev) for _ in range(S)]
-    gath = [torch.zeros(world * 144, dtype=torch.int32, device=dev) for _ in range(S)]
+
+    def shard(v, r):
+        """Pairs of verification v held by rank r: a rotation of the seeded batch
+        (different data per verification and per rank; a rotation keeps the product)."""
+        rot = (v * 37 + r * 131) % n
+        return g1[96 * rot:] + g1[:96 * rot], g2[192 * rot:] + g2[:192 * rot]
+    mine = [shard(v, rank) for v in range(B)]
+    t1 = torch.frombuffer(bytearray(b"".join(a for a, _ in mine)), dtype=torch.uint8).to(dev)
+    t2 = torch.frombuffer(bytearray(b"".join(b for _, b in mine)), dtype=torch.uint8).to(dev)
+    outs = [torch.zeros(B * 576, dtype=torch.uint8, device=dev) for _ in range(S)]
+    parts = [torch.zeros(B * 144, dtype=torch.int32, device=dev) for _ in range(S)]
+    gath = [torch.zeros(world * B * 144, dtype=torch.int32, device=dev) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     for e in engs:
-        e.reserve(n)
-        if S > 1:
-            e.set_mp_threshold(0)      # verifications in flight: use the throughput-oriented kernel
+        e.reserve((n + 3) * B)
+        e.set_mp_threshold(0 if n * B >= 2048 else 1 << 40)    # throughput kernel once the batch can fill the GPU
 
     def step(i):
         k = i % S
         stream = streams[k]
         st = stream.cuda_stream
         if world == 1:
-            engs[k].pairing_multi_dev(t1.data_ptr(), t2.data_ptr(), n, outs[k].data_ptr(), st)
+            engs[k].pairing_multi_batch_dev(t1.data_ptr(), t2.data_ptr(), n, B, outs[k].data_ptr(), st)
         else:
-            engs[k].miller_product_dev(t1.data_ptr(), t2.data_ptr(), n, parts[k].data_ptr(), st)
+            engs[k].miller_product_batch_dev(t1.data_ptr(), t2.data_ptr(), n, B, parts[k].data_ptr(), st)
             with torch.cuda.stream(stream):
                 if args.backend == "nccl":
-                    dist.all_gather_into_tensor(gath[k], parts[k])       # RCCL: 576 bytes per rank
+                    dist.all_gather_into_tensor(gath[k], parts[k])       # RCCL: B x 576 bytes per rank
                 else:
                     stream.synchronize()
-                    host = [torch.zeros(144, dtype=torch.int32) for _ in range(world)]
+                    host = [torch.zeros(B * 144, dtype=torch.int32) for _ in range(world)]
                     dist.all_gather(host, parts[k].cpu())
                     gath[k].copy_(torch.cat(host).to(dev))
-            engs[k].final_exp_product_dev(gath[k].data_ptr(), world, outs[k].data_ptr(), st)
+            engs[k].final_exp_product_batch_dev(gath[k].data_ptr(), world, B, outs[k].data_ptr(), st)
 
     torch.cuda.synchronize()
-    for e in engs:
-        e.timing_enable(True)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    for e in engs:
-        e.timing_read()               # drop the warm-up launches
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -156,68 +156,84 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     results = [bytes(o.cpu().numpy()) for o in outs[:min(S, args.steps)]]
-    ktimes = [t for e in engs for t in e.timing_read()]        # HIP events around every kernel, on its stream
-    overlapped_miller_ms = [ms for k, ms in ktimes if k == 0]
-    # the same launches again with nothing else on the GPU: per-launch duration of
-    # the dominant kernel for the roofline object (overlapping launches stretch
-    # each other's durations, which would understate the kernel)
-    solo_out = torch.zeros(576, dtype=torch.uint8, device=dev)
-    for i in range(min(args.steps, 16)):
-        engs[0].pairing_multi_dev(t1.data_ptr(), t2.data_ptr(), n, solo_out.data_ptr(), streams[0].cuda_stream)
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    # Per-kernel durations for the roofline object: the same step again, one at a
+    # time, with HIP events around every kernel on the stream it runs on (steps in
+    # flight stretch each other's kernel durations; a lone step does not).
+    eng.timing_enable(True)
+    solo_out = torch.zeros(B * 576, dtype=torch.uint8, device=dev)
+    for i in range(min(args.steps, 8)):
+        if world == 1:
+            eng.pairing_multi_batch_dev(t1.data_ptr(), t2.data_ptr(), n, B, solo_out.data_ptr(), streams[0].cuda_stream)
+        else:
+            eng.miller_product_batch_dev(t1.data_ptr(), t2.data_ptr(), n, B, parts[0].data_ptr(), streams[0].cuda_stream)
         streams[0].synchronize()
-    solo = engs[0].timing_read()
+    solo = eng.timing_read()
+    eng.timing_enable(False)
     miller_ms = [ms for k, ms in solo if k == 0]
+    reduce_ms = [ms for k, ms in solo if k == 1]
     fexp_ms = [ms for k, ms in solo if k == 2]
-    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    # single verification alone on the GPU (latency view of the same workload)
+    one_ms = []
+    eng.set_mp_threshold(4096)
+    for i in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(streams[0])
+        eng.pairing_multi_dev(t1.data_ptr(), t2.data_ptr(), n, solo_out.data_ptr(), streams[0].cuda_stream)
+        b.record(streams[0])
+        streams[0].synchronize()
+        one_ms.append(a.elapsed_time(b))
     assert all(r == results[0] for r in results), "streams disagree"
     result = results[0]
 
     if rank == 0:
-        total_pairs = n * world * args.steps
+        total_pairs = n * B * world * args.steps
         value = total_pairs / dt
-        # correctness gate: N=1 on the seeded 1025 batch must equal the committed
-        # golden vector (made by the reference); other shapes are checked against
-        # a single-GPU pass over the concatenated input
+        # correctness gate.  N=1 with the seeded 1025 pairs: every verification is a
+        # rotation of the batch whose result the reference produced (committed golden
+        # vector).  Other shapes: verification 0 against a single-GPU pass over the
+        # concatenation of every rank's shard, and all B verifications the same power.
         check = "unchecked"
+        per = [result[576 * v:576 * (v + 1)] for v in range(B)]
         if world == 1 and n == 1025:
             with open(os.path.join(gold, "pairing.json")) as f:
                 want = bytes.fromhex(json.load(f)["seeded"]["1025"]["out"])
-            check = "golden-ok" if result == want else "MISMATCH"
+            check = "golden-ok" if all(p == want for p in per) else "MISMATCH"
         else:
-            cat1 = b"".join((g1[96 * ((r * 131) % n):] + g1[:96 * ((r * 131) % n)]) for r in range(world))
-            cat2 = b"".join((g2[192 * ((r * 131) % n):] + g2[:192 * ((r * 131) % n)]) for r in range(world))
-            check = "single-gpu-ok" if eng.pairing_multi(cat1, cat2, n * world) == result else "MISMATCH"
+            cat1 = b"".join(shard(0, r)[0] for r in range(world))
+            cat2 = b"".join(shard(0, r)[1] for r in range(world))
+            ok = eng.pairing_multi(cat1, cat2, n * world) == per[0] and all(p == per[0] for p in per)
+            check = "single-gpu-ok" if ok else "MISMATCH"
         if check == "MISMATCH":
             raise SystemExit("result mismatch -- bench invalid")
-        # dominant kernel = the Miller kernel (all the per-pairing work).  S launches
-        # overlap on the device, so its rate over the timed region is
-        # (algorithmic MACs of all its launches) / (wall time of the region); a lone
-        # launch (1025 pairs cannot fill 1024 SIMDs twice over) is reported beside it.
+        # dominant kernel = the Miller kernel (all the per-pairing work): algorithmic
+        # MACs of one launch (B x n pairings) over its average duration
         miller_avg = sum(miller_ms) / len(miller_ms)
-        ach_solo = MAC_PER_PAIRING * n / (miller_avg * 1e-3) / 1e12
-        ach = MAC_PER_PAIRING * n * world * len(overlapped_miller_ms) / dt / 1e12 if overlapped_miller_ms else ach_solo
+        ach = MAC_PER_PAIRING * n * B / (miller_avg * 1e-3) / 1e12
         line = {
             "metric": "BLS12-381 pairings/sec (aggregate_verify multi-pairing)",
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "multi-pairing of %d (pk, H(m)) pairs per GPU, 1 final exp per step "
-                                   "(BASELINE configs[1] shape)" % n,
-                       "pairs_per_gpu": n, "parallelism": "shard%d+allgather576B" % world, "streams_in_flight": S, "check": check},
+            "config": {"workload": "%d independent aggregate verifications per step, each a multi-pairing of %d (pk, H(m)) "
+                                   "pairs per GPU with its own final exponentiation (BASELINE configs[1] shape x %d)" % (B, n, B),
+                       "pairs_per_verification_per_gpu": n, "verifications_per_step": B, "pairs_per_step_per_gpu": n * B,
+                       "parallelism": "shard%d+allgather%dB" % (world, 576 * B), "steps_in_flight": S, "check": check},
             "roofline": {"bound": "valu-int32-mac", "achieved": ach, "peak": PEAK_TMACS, "unit": "TMAC/s",
-                         "frac": ach / PEAK_TMACS, "traffic": None, "kernel": "k_miller_mp" if S > 1 or n >= 4096 else "k_miller",
-                         "kernel_launches": len(overlapped_miller_ms),
-                         "kernel_ms_avg": (sum(overlapped_miller_ms) / len(overlapped_miller_ms)) if overlapped_miller_ms else None,
-                         "solo_launch": {"kernel_ms_avg": miller_avg, "achieved": ach_solo, "frac": ach_solo / PEAK_TMACS},
+                         "frac": ach / PEAK_TMACS, "traffic": None,
+                         "kernel": "k_miller_mp" if n * B >= 2048 else "k_miller",
+                         "kernel_launches_timed": len(miller_ms), "kernel_ms_avg": miller_avg,
+                         "pairings_per_launch": n * B, "mac_per_pairing": MAC_PER_PAIRING,
+                         "reduce_kernels_ms_per_step": sum(reduce_ms) / max(1, len(miller_ms)),
                          "final_exp_kernel_ms_avg": (sum(fexp_ms) / len(fexp_ms)) if fexp_ms else None,
-                         "whole_step_TMACs": (MAC_PER_PAIRING * n + MAC_PER_FINAL_EXP) * world / (dt / args.steps) / 1e12,
-                         "step_latency_ms_avg": kern_avg_ms, "step_latency_ms_min": kern_ms[0],
-                         "hbm_GBps_algorithmic": HBM_BYTES_PER_PAIRING * n / (miller_avg * 1e-3) / 1e9,
+                         "whole_step_TMACs": (MAC_PER_PAIRING * n + MAC_PER_FINAL_EXP) * B * world / (dt / args.steps) / 1e12,
+                         "step_latency_ms_avg": sum(step_ms) / len(step_ms), "step_latency_ms_min": step_ms[0],
+                         "hbm_GBps_algorithmic": HBM_BYTES_PER_PAIRING * n * B / (miller_avg * 1e-3) / 1e9,
                          "hbm_peak_GBps": PEAK_HBM_GBS},
+            "single_verification": {"pairs": n, "latency_ms": min(one_ms), "pairings_per_s": n / (min(one_ms) * 1e-3)},
         }
         if not args.no_cpu_baseline:
-            cb, cpu_out = cpu_baseline(g1r if world == 1 else g1, g2r if world == 1 else g2, n)
+            cb, cpu_out = cpu_baseline(mine[0][0], mine[0][1], n)
             line["cpu_baseline"] = cb
         print(json.dumps(line))
     if dist:

@@ -90,6 +90,16 @@ int blsgpu_pairing_multi_batch(blsgpu_ctx *ctx, const uint8_t *g1, const uint8_t
 int blsgpu_pairing_multi_batch_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2, size_t gsz,
                                    size_t groups, void *d_out, void *stream);
 
+/* Sharded form of the batch: every rank holds gsz pairs of each of the `groups`
+ * multi-pairings.  Step 1 writes one partial per group (groups x
+ * BLSGPU_PARTIAL_WORDS uint32).  Step 2 takes the all-gathered buffer of m ranks
+ * (partial of rank i, group g at index i * groups + g), multiplies per group and
+ * applies fq12_final_exp (fields_t.py:1116-1121 per group) -> groups x 576 bytes. */
+int blsgpu_miller_product_batch_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2, size_t gsz,
+                                    size_t groups, void *d_partials, void *stream);
+int blsgpu_final_exp_product_batch_dev(blsgpu_ctx *ctx, const void *d_partials, size_t m,
+                                       size_t groups, void *d_out, void *stream);
+
 /* Multi-scalar sums  out[g] = sum_{i<k} scalars[g*k+i] * pts[g*k+i]  for `groups`
  * independent groups of k points: the loops of BLS.aggregate_pub_keys
  * (bls.py:203-223, G1), BLS.aggregate_sigs* (bls.py:12-151, G2) and

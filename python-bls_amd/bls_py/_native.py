@@ -19,6 +19,7 @@ SYMBOLS = (
     "blsgpu_g1_msm", "blsgpu_g2_msm", "blsgpu_g1_msm_dev", "blsgpu_g2_msm_dev",
     "blsgpu_final_exp_batch", "blsgpu_pairing_multi_batch", "blsgpu_pairing_multi_batch_dev",
     "blsgpu_map_to_g2", "blsgpu_map_to_g2_dev",
+    "blsgpu_miller_product_batch_dev", "blsgpu_final_exp_product_batch_dev",
 )
 
 _lib = None
@@ -69,6 +70,8 @@ def load_library(path=None):
         L.blsgpu_final_exp_batch.argtypes = [vp, cp, sz, cp]
         L.blsgpu_pairing_multi_batch.argtypes = [vp, cp, cp, sz, sz, cp]
         L.blsgpu_pairing_multi_batch_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp]
+        L.blsgpu_miller_product_batch_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp]
+        L.blsgpu_final_exp_product_batch_dev.argtypes = [vp, vp, sz, sz, vp, vp]
         L.blsgpu_map_to_g2.argtypes = [vp, cp, sz, cp]
         L.blsgpu_map_to_g2_dev.argtypes = [vp, vp, sz, vp, vp]
         L.blsgpu_timing_enable.argtypes = [vp, ctypes.c_int]
@@ -200,6 +203,18 @@ class Engine:
     def final_exp_product_dev(self, d_partials, m, d_out, stream=0):
         self._check(self.lib.blsgpu_final_exp_product_dev(self.h, d_partials, m, d_out, stream),
                     "blsgpu_final_exp_product_dev")
+
+    def pairing_multi_batch_dev(self, d_g1, d_g2, gsz, groups, d_out, stream=0):
+        self._check(self.lib.blsgpu_pairing_multi_batch_dev(self.h, d_g1, d_g2, gsz, groups, d_out, stream),
+                    "blsgpu_pairing_multi_batch_dev")
+
+    def miller_product_batch_dev(self, d_g1, d_g2, gsz, groups, d_partials, stream=0):
+        self._check(self.lib.blsgpu_miller_product_batch_dev(self.h, d_g1, d_g2, gsz, groups, d_partials, stream),
+                    "blsgpu_miller_product_batch_dev")
+
+    def final_exp_product_batch_dev(self, d_partials, m, groups, d_out, stream=0):
+        self._check(self.lib.blsgpu_final_exp_product_batch_dev(self.h, d_partials, m, groups, d_out, stream),
+                    "blsgpu_final_exp_product_batch_dev")
 
 
 _engines = {}

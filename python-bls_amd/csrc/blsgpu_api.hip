@@ -32,6 +32,7 @@ int fail(int code, const std::string& msg) {
 
 constexpr int MILLER_WAVES = 4;        // teams (pairings) per workgroup in k_miller
 constexpr int REDUCE_WAVES = 8;        // teams per workgroup in k_reduce
+constexpr size_t BATCH_TREE_MIN_GROUP = 24;   // batches of groups at least this long use the per-group product tree
 constexpr int REDUCE_PER_BLOCK = 64;   // partials folded by one k_reduce block
 
 }  // namespace
@@ -81,10 +82,6 @@ static size_t default_mp_threshold() {
     return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4096;
 }
 static bool use_mp(const blsgpu_ctx* c, size_t n) { return n >= c->mp_threshold; }
-static size_t n_blocks_miller(const blsgpu_ctx* c, size_t n) {
-    return use_mp(c, n) ? (n + BLSVM_MP_G - 1) / BLSVM_MP_G : (n + MILLER_WAVES - 1) / MILLER_WAVES;
-}
-
 static int ensure_workspace(blsgpu_ctx* c, size_t max_pairs) {
     size_t need = (max_pairs + 2) / 3 + (max_pairs + MILLER_WAVES - 1) / MILLER_WAVES + 1;
     if (need > c->part_cap) {
@@ -329,79 +326,108 @@ BLSGPU_EXPORT int blsgpu_ctx_reserve(blsgpu_ctx* c, size_t max_pairs) {
     return ensure_workspace(c, max_pairs);
 }
 
-// fold m partials (in d_in) down to one; the last launch optionally applies the
-// final exponentiation and writes bytes to d_out_bytes.  d_in is not modified
-// unless it is one of the context's ping-pong buffers.
-static int reduce_chain(blsgpu_ctx* c, const uint32_t* d_in, size_t m, bool do_final, uint32_t* d_out_partial,
-                        void* d_out_bytes, hipStream_t st) {
+// For each of `groups` groups fold its m partials down to one; the last launch
+// optionally applies the final exponentiation and writes 576 bytes per group to
+// d_out_bytes, otherwise one partial per group to d_out_partial.  Partial i of
+// group g is read from d_in[(i * istride + g * gstride) * 144].
+static int reduce_chain(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_t groups, size_t istride, size_t gstride,
+                        bool do_final, uint32_t* d_out_partial, void* d_out_bytes, hipStream_t st) {
     const uint32_t* src = d_in;
     int pp = (d_in == c->d_part[0]) ? 1 : 0;
     size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
+    if (groups > 65535) return fail(-EINVAL, "too many groups");
     while (true) {
         size_t blocks = (m + REDUCE_PER_BLOCK - 1) / REDUCE_PER_BLOCK;
         if (blocks == 0) blocks = 1;
         bool last = blocks == 1;
         uint32_t* dst = last ? d_out_partial : c->d_part[pp];
-        if (!last && blocks > c->part_cap) return fail(-ENOMEM, "workspace too small; call blsgpu_ctx_reserve");
+        if (!last && blocks * groups > c->part_cap) return fail(-ENOMEM, "workspace too small; call blsgpu_ctx_reserve");
         {
             KernelTimer kt(c, st, (last && do_final) ? 2 : 1);
-            hipLaunchKernelGGL(blsgpu::k_reduce, dim3((unsigned)blocks), dim3(REDUCE_WAVES * 64), lds, st, c->tabs, src,
-                               (uint32_t)m, (uint32_t)REDUCE_PER_BLOCK, dst, (uint32_t)(last && do_final ? 1 : 0),
-                               (uint32_t*)d_out_bytes);
+            hipLaunchKernelGGL(blsgpu::k_reduce, dim3((unsigned)blocks, (unsigned)groups), dim3(REDUCE_WAVES * 64), lds, st, c->tabs,
+                               src, (uint32_t)m, (uint32_t)REDUCE_PER_BLOCK, (uint32_t)istride, (uint32_t)gstride, dst,
+                               (uint32_t)(last && do_final ? 1 : 0), (uint32_t*)d_out_bytes);
         }
         HIP_TRY(hipGetLastError());
         if (last) break;
         src = dst;
         m = blocks;
+        istride = 1;
+        gstride = blocks;
         pp ^= 1;
     }
     return 0;
 }
 
-static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t n, uint32_t* d_partials,
-                         hipStream_t st) {
-    size_t blocks = n_blocks_miller(c, n);
-    if (use_mp(c, n)) {
+// Miller loops of `groups` runs of gsz pairs; returns the partials per group (bpg)
+static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t gsz, size_t groups, uint32_t* d_partials,
+                         hipStream_t st, size_t* bpg_out) {
+    const bool mp = use_mp(c, gsz * groups);
+    size_t bpg = mp ? (gsz + BLSVM_MP_G - 1) / BLSVM_MP_G : (gsz + MILLER_WAVES - 1) / MILLER_WAVES;
+    *bpg_out = bpg;
+    if (bpg * groups > 0x7FFFFFFFull) return fail(-EINVAL, "batch too large");
+    if (mp) {
         KernelTimer kt(c, st, 0);
-        hipLaunchKernelGGL(blsgpu::k_miller_mp, dim3((unsigned)blocks), dim3(64), (size_t)blsgpu::MP_TEAM_BYTES, st, c->tabs,
-                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, d_partials);
+        hipLaunchKernelGGL(blsgpu::k_miller_mp, dim3((unsigned)(bpg * groups)), dim3(64), (size_t)blsgpu::MP_TEAM_BYTES, st, c->tabs,
+                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, d_partials);
     } else {
         size_t lds = (size_t)MILLER_WAVES * blsgpu::TEAM_BYTES;
         KernelTimer kt(c, st, 0);
-        hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)blocks), dim3(MILLER_WAVES * 64), lds, st, c->tabs,
-                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, d_partials);
+        hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)(bpg * groups)), dim3(MILLER_WAVES * 64), lds, st, c->tabs,
+                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, d_partials);
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
+// Miller loops + per-group product; final exponentiation iff d_out_bytes
+static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t gsz, size_t groups, uint32_t* d_out_partial,
+                           void* d_out_bytes, hipStream_t st) {
+    size_t need_pairs = (gsz + 3) * groups;            // every group rounds its team count up
+    if ((need_pairs + 2) / 3 + (need_pairs + MILLER_WAVES - 1) / MILLER_WAVES + 1 > c->part_cap) {
+        int rc = ensure_workspace(c, need_pairs);
+        if (rc) return rc;
+    }
+    size_t bpg = 0;
+    if (gsz > 0) {
+        int rc = launch_miller(c, d_g1, d_g2, gsz, groups, c->d_part[0], st, &bpg);
+        if (rc) return rc;
+    }
+    return reduce_chain(c, c->d_part[0], bpg, groups, 1, bpg, d_out_bytes != nullptr, d_out_partial, d_out_bytes, st);
+}
+
 BLSGPU_EXPORT int blsgpu_miller_product_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t n, void* d_partial,
                               void* stream) {
-    if (!c || !d_partial) return fail(-EINVAL, "NULL argument");
-    if (n > 0 && (!d_g1 || !d_g2)) return fail(-EINVAL, "NULL point buffer");
-    if (n > 0xFFFFFFF0ull) return fail(-EINVAL, "n too large");
+    return blsgpu_miller_product_batch_dev(c, d_g1, d_g2, n, 1, d_partial, stream);
+}
+
+BLSGPU_EXPORT int blsgpu_miller_product_batch_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t gsz, size_t groups,
+                                                  void* d_partials, void* stream) {
+    if (!c || (groups && !d_partials)) return fail(-EINVAL, "NULL argument");
+    if (groups == 0) return 0;
+    if (gsz > 0 && (!d_g1 || !d_g2)) return fail(-EINVAL, "NULL point buffer");
+    if (gsz > 0xFFFFFFF0ull || gsz * groups > 0xFFFFFFF0ull) return fail(-EINVAL, "batch too large");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
-    if (n_blocks_miller(c, n) + 1 > c->part_cap) {
-        int rc = ensure_workspace(c, n);
-        if (rc) return rc;
-    }
-    if (n > 0) {
-        int rc = launch_miller(c, d_g1, d_g2, n, c->d_part[0], st);
-        if (rc) return rc;
-    }
-    return reduce_chain(c, c->d_part[0], n_blocks_miller(c, n), false, (uint32_t*)d_partial, nullptr, st);
+    return grouped_pairing(c, d_g1, d_g2, gsz, groups, (uint32_t*)d_partials, nullptr, (hipStream_t)stream);
 }
 
 BLSGPU_EXPORT int blsgpu_final_exp_product_dev(blsgpu_ctx* c, const void* d_partials, size_t m, void* d_out, void* stream) {
-    if (!c || !d_out) return fail(-EINVAL, "NULL argument");
+    return blsgpu_final_exp_product_batch_dev(c, d_partials, m, 1, d_out, stream);
+}
+
+// d_partials holds m x groups partials, partial (i, g) at index i * groups + g: the
+// layout an all-gather of every rank's `groups` partials produces.
+BLSGPU_EXPORT int blsgpu_final_exp_product_batch_dev(blsgpu_ctx* c, const void* d_partials, size_t m, size_t groups, void* d_out,
+                                                     void* stream) {
+    if (!c || (groups && !d_out)) return fail(-EINVAL, "NULL argument");
+    if (groups == 0) return 0;
     if (m > 0 && !d_partials) return fail(-EINVAL, "NULL partials");
     HIP_TRY(hipSetDevice(c->device));
-    if ((m + REDUCE_PER_BLOCK - 1) / REDUCE_PER_BLOCK + 1 > c->part_cap) {
-        int rc = ensure_workspace(c, m * MILLER_WAVES);
+    if (((m + REDUCE_PER_BLOCK - 1) / REDUCE_PER_BLOCK) * groups + 1 > c->part_cap) {
+        int rc = ensure_workspace(c, m * groups * MILLER_WAVES);
         if (rc) return rc;
     }
-    return reduce_chain(c, (const uint32_t*)d_partials, m, true, nullptr, d_out, (hipStream_t)stream);
+    return reduce_chain(c, (const uint32_t*)d_partials, m, groups, groups, 1, true, nullptr, d_out, (hipStream_t)stream);
 }
 
 BLSGPU_EXPORT int blsgpu_pairing_multi_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t n, void* d_out,
@@ -410,16 +436,7 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_dev(blsgpu_ctx* c, const void* d_g1, cons
     if (n > 0 && (!d_g1 || !d_g2)) return fail(-EINVAL, "NULL point buffer");
     if (n > 0xFFFFFFF0ull) return fail(-EINVAL, "n too large");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
-    if (n_blocks_miller(c, n) + 1 > c->part_cap) {
-        int rc = ensure_workspace(c, n);
-        if (rc) return rc;
-    }
-    if (n > 0) {
-        int rc = launch_miller(c, d_g1, d_g2, n, c->d_part[0], st);
-        if (rc) return rc;
-    }
-    return reduce_chain(c, c->d_part[0], n_blocks_miller(c, n), true, nullptr, d_out, st);
+    return grouped_pairing(c, d_g1, d_g2, n, 1, nullptr, d_out, (hipStream_t)stream);
 }
 
 BLSGPU_EXPORT int blsgpu_pairing_multi(blsgpu_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t out[576]) {
@@ -492,12 +509,13 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1
     if (n > 0x3FFFFFF0ull) return fail(-EINVAL, "batch too large");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
+    if (gsz >= BATCH_TREE_MIN_GROUP) return grouped_pairing(c, d_g1, d_g2, gsz, groups, nullptr, d_out, st);
     int rc = ensure_workspace(c, (n + 1) * MILLER_WAVES);      // one partial per PAIR here
     if (rc) return rc;
     if (n) {
         KernelTimer kt(c, st, 0);
         hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)n), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs,
-                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, c->d_part[0]);
+                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, (uint32_t)n, c->d_part[0]);
     }
     HIP_TRY(hipGetLastError());
     size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;

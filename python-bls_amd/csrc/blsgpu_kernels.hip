@@ -149,10 +149,18 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
             uint32_t A[12], B[12], D[12];
             lds_load12(A, base16 + ra);
             lds_load12(B, base16 + rb);
+#if defined(BLSGPU_EXP) && (BLSGPU_EXP & 1)
+            for (int j = 0; j < 12; j++) D[j] = A[j] ^ B[j];  // timing experiment only
+#else
             bls::fq_mul_relaxed(D, A, B);
+#endif
             if (rd != 0xFFFFu) lds_store12(D, base16 + rd);
         } else if (kind == 1u) {                             // LIN
+#if defined(BLSGPU_EXP) && (BLSGPU_EXP & 2)
+            const uint32_t K = ((meta >> 8) & 0xFFu) ? 1u : 0u;   // timing experiment only
+#else
             const uint32_t K = (meta >> 8) & 0xFFu;
+#endif
 #ifdef BLSGPU_STAMPS
             unsigned long long lt0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -188,7 +196,11 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
             unsigned long long lt1 = __builtin_amdgcn_s_memtime();
 #endif
             uint32_t D[12];
+#if defined(BLSGPU_EXP) && (BLSGPU_EXP & 4)
+            for (int j = 0; j < 12; j++) D[j] = (uint32_t)acc[j];  // timing experiment only
+#else
             bls::fat_reduce(D, acc);
+#endif
 #ifdef BLSGPU_STAMPS
             asm volatile("" :: "v"(D[0]), "v"(D[11]));
             unsigned long long lt2 = __builtin_amdgcn_s_memtime();
@@ -269,23 +281,28 @@ __device__ __forceinline__ void wg_product_tree(const VmTables& T, uint32_t* sme
 #ifndef BLSGPU_MP_WPS
 #define BLSGPU_MP_WPS 3
 #endif
+// Groups: the pairs form `groups` consecutive runs of gsz pairs; block b works on
+// group b / bpg and never mixes groups (bpg = blocks per group), so partials
+// [g * bpg, (g + 1) * bpg) belong to group g.  A single multi-pairing is one group.
 __global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
-                                                uint32_t n, uint32_t* __restrict__ partials) {
+                                                uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials) {
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nwaves = blockDim.x >> 6;
-    const uint32_t pair = blockIdx.x * nwaves + wave;
+    const uint32_t grp = blockIdx.x / bpg;
+    const uint32_t in_grp = (blockIdx.x - grp * bpg) * nwaves + wave;
+    const size_t pair = (size_t)grp * gsz + in_grp;
     uint32_t* team = smem + wave * TEAM_DW;
     const uint32_t base16 = wave * (TEAM_BYTES / 16);
     team_init_consts(T, team, lane);
-    if (pair < n) {
+    if (in_grp < gsz) {
         // coalesced load of the 72 big-endian dwords of the pair
         uint32_t w0, w1 = 0;
         {
             uint32_t d = lane;
-            w0 = (d < 24) ? g1[(size_t)pair * 24 + d] : g2[(size_t)pair * 48 + (d - 24)];
-            if (lane < 8) w1 = g2[(size_t)pair * 48 + (lane + 40)];
+            w0 = (d < 24) ? g1[pair * 24 + d] : g2[pair * 48 + (d - 24)];
+            if (lane < 8) w1 = g2[pair * 48 + (lane + 40)];
         }
         uint64_t nz0 = __ballot(w0 != 0);
         uint64_t nz1 = __ballot(lane < 8 && w1 != 0);
@@ -355,18 +372,22 @@ __device__ __forceinline__ uint32_t pair_flags(const uint32_t* team, uint32_t sl
 }
 
 __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
-                                                     uint32_t n, uint32_t* __restrict__ partials) {
+                                                     uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials) {
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t first = blockIdx.x * BLSVM_MP_G;
-    const uint32_t cnt = min((uint32_t)BLSVM_MP_G, n - first);
+    const uint32_t grp = blockIdx.x / bpg;                       // groups as in k_miller
+    const uint32_t in_grp = (blockIdx.x - grp * bpg) * BLSVM_MP_G;
+    const size_t first = (size_t)grp * gsz + in_grp;
+    const uint32_t cnt = min((uint32_t)BLSVM_MP_G, gsz - in_grp);
     team_init_consts(T, team, lane);
     wave_fence();
+    // the multi-pair tables address the scratchpad with the gamma constants
+    // squeezed out: every slot >= BLSVM_NCONST sits BLSVM_MP_SHIFT lower
     uint32_t special = (cnt < (uint32_t)BLSVM_MP_G) ? 1u : 0u;
     for (uint32_t g = 0; g < cnt; ++g) {
-        load_pair_raw(team, mp_pair_base(g), g1, g2, first + g, lane);
+        load_pair_raw(team, mp_pair_base(g) - BLSVM_MP_SHIFT, g1, g2, first + g, lane);
         wave_fence();
-        special |= pair_flags(team, mp_pair_base(g), lane);
+        special |= pair_flags(team, mp_pair_base(g) - BLSVM_MP_SHIFT, lane);
     }
     if (!special) {
         run_rounds(T, T.mpflat, BLSVM_MP_FLAT_LEN, 0, lane);
@@ -387,7 +408,8 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
         if (!have) team_set_acc(team, lane, true);
     }
     wave_fence();
-    for (uint32_t i = lane; i < 144; i += 64) partials[(size_t)blockIdx.x * 144 + i] = team[F_DW + i];
+    const uint32_t f_dw = special ? (uint32_t)F_DW : (uint32_t)(F_DW - BLSVM_MP_SHIFT * 12);
+    for (uint32_t i = lane; i < 144; i += 64) partials[(size_t)blockIdx.x * 144 + i] = team[f_dw + i];
 }
 
 // ---------------------------------------------------------------------------
@@ -396,7 +418,10 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
 // do_final != 0 (single block) the product additionally goes through the final
 // exponentiation and is written as 576 big-endian bytes (12 x 48, flat ZT
 // order of fields.py:624-629) to out_bytes.
+// blockIdx.y selects a group: its partial i is in[(i * istride + group * gstride) * 144];
+// outputs are group-major (out_partials[group * gridDim.x + block], out_bytes[group]).
 __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __restrict__ in, uint32_t m, uint32_t per_block,
+                                                 uint32_t istride, uint32_t gstride,
                                                  uint32_t* __restrict__ out_partials, uint32_t do_final,
                                                  uint32_t* __restrict__ out_bytes) {
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
@@ -411,7 +436,7 @@ __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __re
     const uint32_t hi = min(m, lo + per_block);
     bool first = true;
     for (uint32_t i = lo + wave; i < hi; i += nwaves) {
-        const uint32_t* src = in + (size_t)i * 144;
+        const uint32_t* src = in + ((size_t)i * istride + (size_t)blockIdx.y * gstride) * 144;
         uint32_t dst = first ? F_DW : R1_DW;
         for (uint32_t k = lane; k < 144; k += 64) team[dst + k] = src[k];
         wave_fence();
@@ -435,10 +460,11 @@ __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __re
             wave_fence();
             for (uint32_t k = lane; k < 144; k += 64) {
                 uint32_t c = k / 12, w = k % 12;
-                out_bytes[k] = bswap32(team[R1_DW + c * 12 + (11 - w)]);
+                out_bytes[(size_t)blockIdx.y * 144 + k] = bswap32(team[R1_DW + c * 12 + (11 - w)]);
             }
         } else {
-            for (uint32_t k = lane; k < 144; k += 64) out_partials[(size_t)blockIdx.x * 144 + k] = team[F_DW + k];
+            uint32_t* dstp = out_partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 144;
+            for (uint32_t k = lane; k < 144; k += 64) dstp[k] = team[F_DW + k];
         }
     }
 }

@@ -26,9 +26,13 @@ NX = 0xd201000000010000                   # |x|  (fields_t.py:25)
 # One scratchpad per team (= wavefront = pairing), in 48-byte slots.
 # constants (copied in by the kernel at start-up)
 C_ZERO, C_ONE, C_R2, C_RAW1 = 0, 1, 2, 3
-C_GAM = 4                                 # gamma_i^j, i=1..3, j=1..5: Fq2 each
-C_K1 = C_GAM + 3 * 5 * 2                  # -(2^384 - 1) mod q  (LIN complement surplus)
-NCONST = C_K1 + 1                         # 35
+C_K1 = 4                                  # -(2^384 - 1) mod q  (LIN complement surplus)
+C_GAM = 5                                 # gamma_i^j, i=1..3, j=1..5: Fq2 each (final exponentiation only)
+NCONST = C_GAM + 3 * 5 * 2                # 35
+# The multi-pair Miller programs never touch the gamma constants: their tables are
+# emitted with every slot >= NCONST moved down by MP_SHIFT, which is what lets 12
+# teams share a CU's LDS (emit.py).
+MP_SHIFT = NCONST - C_GAM
 # named values
 PX, PY = 36, 37
 QX0, QX1, QY0, QY1 = 38, 39, 40, 41

@@ -147,3 +147,52 @@ def test_batched_independent_pairings(engine, golden, seeded_pairs, oracle):
     recs = golden("pairing.json")["final_exp"]
     ins = b"".join(bytes.fromhex(r["in"]) for r in recs) * 4
     assert engine.final_exp_batch(ins) == b"".join(bytes.fromhex(r["out"]) for r in recs) * 4
+
+
+@pytest.mark.parametrize("gsz,groups,mp", [(25, 5, 0), (25, 5, 1 << 30), (205, 5, 0), (1025, 3, 0), (64, 16, 1 << 30)])
+def test_batched_large_groups(engine, seeded_pairs, gsz, groups, mp):
+    """Groups long enough for the per-group product tree (grouped k_miller / k_miller_mp +
+    k_reduce over blockIdx.y): every group must equal its own blsgpu_pairing_multi.
+    gsz not a multiple of 3 or 4 exercises the ragged last team of every group."""
+    g1, g2 = seeded_pairs
+    n = gsz * groups
+    reps = (n + 1024) // 1025
+    a, b = (g1 * reps)[:96 * n], (g2 * reps)[:192 * n]
+    try:
+        engine.set_mp_threshold(mp)
+        out = engine.pairing_multi_batch(a, b, gsz, groups)
+        singles = [engine.pairing_multi(a[96 * gsz * g:96 * gsz * (g + 1)], b[192 * gsz * g:192 * gsz * (g + 1)], gsz)
+                   for g in range(groups)]
+    finally:
+        engine.set_mp_threshold(4096)
+    assert [out[576 * g:576 * (g + 1)] for g in range(groups)] == singles
+    assert len(set(singles)) == groups or gsz * groups > 1025
+
+
+def test_batched_sharded_form(engine, golden, seeded_pairs):
+    """The multi-GPU decomposition of a batch on one device: 2 'ranks' x 3 verifications;
+    rank r holds a slice of every verification.  all-gather layout [rank][group]."""
+    import torch
+    g1, g2 = seeded_pairs
+    dev = torch.device("cuda:0")
+    groups, cuts = 3, (0, 400, 1025)                          # rank 0: pairs [0,400), rank 1: [400,1025)
+    rot = [0, 7, 500]                                         # every verification is a rotation of the seeded batch
+    def rotated(buf, sz, k):
+        return buf[sz * k:sz * 1025] + buf[:sz * k]
+    parts = torch.zeros(2, groups, 144, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    keep = []
+    for r in range(2):
+        lo, hi = cuts[r], cuts[r + 1]
+        a = b"".join(rotated(g1, 96, k)[96 * lo:96 * hi] for k in rot)
+        b = b"".join(rotated(g2, 192, k)[192 * lo:192 * hi] for k in rot)
+        ta = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
+        tb = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        keep += [ta, tb]
+        engine.miller_product_batch_dev(ta.data_ptr(), tb.data_ptr(), hi - lo, groups, parts[r].data_ptr(), st)
+    out = torch.zeros(groups, 576, dtype=torch.uint8, device=dev)
+    engine.final_exp_product_batch_dev(parts.data_ptr(), 2, groups, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    want = golden("pairing.json")["seeded"]["1025"]["out"]     # a rotation does not change the product
+    for g in range(groups):
+        assert bytes(out[g].cpu().numpy()).hex() == want

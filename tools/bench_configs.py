@@ -24,7 +24,7 @@ def main():
     g1 = open(os.path.join(gold, "pairs_seed1_g1.bin"), "rb").read()
     g2 = open(os.path.join(gold, "pairs_seed1_g2.bin"), "rb").read()
     th = json.load(open(os.path.join(gold, "threshold.json")))["67_of_100"]
-    which = set(sys.argv[1:]) or {"c3", "c4", "c5"}
+    which = set(sys.argv[1:]) or {"c3", "c4", "c5", "h2c"}
 
     def up(b):
         return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
@@ -88,6 +88,21 @@ def main():
         small, _ = eng.g1_msm(base, sc, 1024)
         want, _ = eng.g1_msm(small, [n // 1024], 1)
         print(json.dumps({"config": "C5: 1M-point G1 multi-scalar sum", "seconds": dt, "points_per_s": n / dt, "check": got == want}))
+    if "h2c" in which:
+        from bls_py import hostmath as H, util
+        n = 16384
+        uniq = [H.g2_hash_field_elements(hashlib.sha256(b"cfg-h2c-%d" % i).digest(), util.hash512) for i in range(256)]
+        tin = up(b"".join(uniq) * (n // 256))
+        tout = torch.zeros(n * 192, dtype=torch.uint8, device=dev)
+        lib, h = eng.lib, eng.h
+        dt = timed(lambda: lib.blsgpu_map_to_g2_dev(h, tin.data_ptr(), n, tout.data_ptr(), 0), 3)
+        got = bytes(tout.cpu().numpy())
+        t0 = time.perf_counter()
+        want0 = H.g2_affine_bytes(H.hash_to_g2_prehashed(hashlib.sha256(b"cfg-h2c-0").digest(), util.hash512))
+        host_dt = time.perf_counter() - t0
+        ok = got[:192] == want0 and got[:192 * 256] * (n // 256) == got
+        print(json.dumps({"config": "hash to G2 (after SHA-256): 16384 messages", "seconds": dt, "messages_per_s": n / dt,
+                          "host_python_one_message_s": host_dt, "check": ok}))
 
 
 if __name__ == "__main__":
