@@ -40,8 +40,8 @@ struct VmTables {
     unsigned long long* stamps;   // diagnostic builds only (-DBLSGPU_STAMPS), else unused
 };
 
-constexpr int LIN_CHUNKS = 8;                           // a LIN record holds <= 31 micro-ops
-static_assert(BLSVM_MAX_LIN_K <= 4 * LIN_CHUNKS - 1, "LIN record too long");
+constexpr int LIN_CHUNKS = 6;                           // a LIN record holds <= 22 micro-ops
+static_assert(BLSVM_MAX_LIN_K <= 4 * LIN_CHUNKS - 2, "LIN record too long");
 constexpr int TEAM_DW = BLSVM_TEAM_SLOTS * 12;           // dwords per team
 constexpr int TEAM_BYTES = TEAM_DW * 4;
 constexpr int F_DW = BLSVM_SLOT_REG0 * 12;               // register 0 (accumulator)
@@ -70,7 +70,7 @@ __device__ __forceinline__ void lds_store12(const uint32_t* x, uint32_t idx16) {
 // per-lane record length of a round, in u16 units (wave-uniform)
 __device__ __forceinline__ uint32_t rec_len(uint32_t meta) {
     if ((meta & 3u) != 1u) return 4u;
-    return (((meta >> 8) & 0xFFu) + 1u + 3u) & ~3u;
+    return (((meta >> 8) & 0xFFu) + 2u + 3u) & ~3u;      // destination, compensation count, K micro-ops
 }
 
 // global-address-space views: a pointer taken out of the kernel-argument struct
@@ -109,20 +109,48 @@ struct RecReader {
     }
 };
 
+// 64-bit value of another lane of the same quad (quad_perm control CTRL)
+// of the READING lane's `mask` (0 or ~0): the value if the lane absorbs it, else 0
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_quad64(uint64_t v, uint32_t mask) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, CTRL, 0xF, 0xF, true) & mask;
+    uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true) & mask;
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // Walk `n` rounds of a flat sequence on the team whose scratchpad starts at
-// base16 (16-byte units).  Round headers are read two rounds ahead and the
-// first 8 bytes of every lane record one round ahead, so that table latency
-// overlaps the arithmetic of the previous round.
+// base16 (16-byte units).  Round headers are read three rounds ahead and every
+// lane record one round ahead, so that table latency overlaps the arithmetic of
+// the previous round.
+// LIGHT = the program holds MUL and LIN rounds only (Miller loops, group sums):
+// the inversion and sign code is left out of the kernel.
+template <bool LIGHT = false>
 __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __restrict__ seq_, uint32_t n, uint32_t base16, uint32_t lane) {
     if (n == 0) return;
     gptr_u2 seq = (gptr_u2)seq_;
     gptr_u16 gdata = (gptr_u16)T.data;
     uint2 h0 = ld2(seq, 0);
     uint2 h1 = ld2(seq, n > 1 ? 1 : 0);
+    // header of round i + 2 waits in VGPRs (hraw) for a whole round before it is made
+    // wave-uniform: readfirstlane right after the load would stall on it every round
+    uint2 hraw = ld2(seq, n > 2 ? 2 : 0);
     h0.x = __builtin_amdgcn_readfirstlane(h0.x); h0.y = __builtin_amdgcn_readfirstlane(h0.y);
     h1.x = __builtin_amdgcn_readfirstlane(h1.x); h1.y = __builtin_amdgcn_readfirstlane(h1.y);
-    gptr_u2 rec = (gptr_u2)(gdata + h0.x + lane * rec_len(h0.y));
-    uint2 e = ld2(rec, 0);
+#if defined(BLSGPU_EXP) && (BLSGPU_EXP & 32)
+#define BLSGPU_DOFF(h) ((h).x & 0xFFFu)                      /* timing experiment only: records from one hot 8 KB window */
+#else
+#define BLSGPU_DOFF(h) ((h).x)
+#endif
+    // the lane's WHOLE record of the next round (<= LIN_CHUNKS x 4 u16) is fetched
+    // during the current round; positions are compile-time so every value stays in
+    // a fixed register
+    uint2 nx[LIN_CHUNKS];
+    {
+        gptr_u2 rec = (gptr_u2)(gdata + BLSGPU_DOFF(h0) + lane * rec_len(h0.y));
+        const uint32_t nch0 = rec_len(h0.y) >> 2;
+#pragma unroll
+        for (int c = 0; c < LIN_CHUNKS; c++) nx[c] = (c < (int)nch0) ? ld2(rec, c) : make_uint2(0u, 0u);
+    }
 #ifdef BLSGPU_STAMPS
     unsigned long long st_acc[4] = {0, 0, 0, 0}, st_cnt[4] = {0, 0, 0, 0}, st_lin[3] = {0, 0, 0};
 #endif
@@ -131,17 +159,20 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
         unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #endif
         const uint32_t meta = h0.y;
-        gptr_u2 rec_cur = rec;
-        const uint2 e_cur = e;
+        uint2 ch[LIN_CHUNKS];
+#pragma unroll
+        for (int c = 0; c < LIN_CHUNKS; c++) ch[c] = nx[c];
+        const uint2 e_cur = ch[0];
         // ---- prefetch for the following rounds
         h0 = h1;
-        if (i + 2 < n) {
-            uint2 t = ld2(seq, i + 2);
-            h1.x = __builtin_amdgcn_readfirstlane(t.x); h1.y = __builtin_amdgcn_readfirstlane(t.y);
-        }
+        h1.x = __builtin_amdgcn_readfirstlane(hraw.x); h1.y = __builtin_amdgcn_readfirstlane(hraw.y);
+        if (i + 3 < n) hraw = ld2(seq, i + 3);
         if (i + 1 < n) {
-            rec = (gptr_u2)(gdata + h0.x + lane * rec_len(h0.y));
-            e = ld2(rec, 0);
+            gptr_u2 rec = (gptr_u2)(gdata + BLSGPU_DOFF(h0) + lane * rec_len(h0.y));
+            const uint32_t nchn = rec_len(h0.y) >> 2;
+#pragma unroll
+            for (int c = 0; c < LIN_CHUNKS; c++)
+                if (c < (int)nchn) nx[c] = ld2(rec, c);
         }
         const uint32_t kind = meta & 3u;
         if (kind == 0u) {                                    // MUL
@@ -164,33 +195,51 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
 #ifdef BLSGPU_STAMPS
             unsigned long long lt0 = __builtin_amdgcn_s_memtime();
 #endif
-            // the lane's whole record (<= LIN_CHUNKS x 4 u16) is requested up front;
-            // positions are compile-time so every value stays in a fixed register
-            uint2 ch[LIN_CHUNKS];
-            ch[0] = e_cur;
-            const uint32_t nch = rec_len(meta) >> 2;
-#pragma unroll
-            for (int c = 1; c < LIN_CHUNKS; c++) ch[c] = (c < (int)nch) ? ld2(rec_cur, c) : make_uint2(0u, 0u);
             const uint32_t rd = ch[0].x & 0xFFFFu;
             uint64_t acc[12];
 #pragma unroll
             for (int j = 0; j < 12; j++) acc[j] = 0;
-            // micro-op p sits at record position p + 1; operands are fetched one
-            // micro-op ahead into two alternating buffers
+            // record: destination, compensation count, micro-ops; micro-op p sits at
+            // position p + 2; operands are fetched one micro-op ahead into two
+            // alternating buffers
             uint32_t S[2][12];
-#define BLSGPU_UOP(p) ((((p) + 1) & 1) ? ((((p) + 1) & 2) ? (ch[((p) + 1) >> 2].y >> 16) : (ch[((p) + 1) >> 2].x >> 16)) \
-                                       : ((((p) + 1) & 2) ? (ch[((p) + 1) >> 2].y & 0xFFFFu) : (ch[((p) + 1) >> 2].x & 0xFFFFu)))
-            if (K > 0) lds_load12(S[0], base16 + (BLSGPU_UOP(0) & 1023u) * 3u);
+#define BLSGPU_UOP(p) ((((p) + 2) & 1) ? ((((p) + 2) & 2) ? (ch[((p) + 2) >> 2].y >> 16) : (ch[((p) + 2) >> 2].x >> 16)) \
+                                       : ((((p) + 2) & 2) ? (ch[((p) + 2) >> 2].y & 0xFFFFu) : (ch[((p) + 2) >> 2].x & 0xFFFFu)))
+#if defined(BLSGPU_EXP) && (BLSGPU_EXP & 8)
+#define BLSGPU_SLOTMASK 3u                                   /* timing experiment only: 4 hot slots */
+#else
+#define BLSGPU_SLOTMASK 1023u
+#endif
+            if (K > 0) lds_load12(S[0], base16 + (BLSGPU_UOP(0) & BLSGPU_SLOTMASK) * 3u);
 #pragma unroll
-            for (int p = 0; p < 4 * LIN_CHUNKS - 1; p++) {
+            for (int p = 0; p < 4 * LIN_CHUNKS - 2; p++) {
                 if ((uint32_t)p < K) {
-                    if (p + 1 < 4 * LIN_CHUNKS - 1 && (uint32_t)(p + 1) < K)
-                        lds_load12(S[(p + 1) & 1], base16 + (BLSGPU_UOP(p + 1) & 1023u) * 3u);
+                    if (p + 1 < 4 * LIN_CHUNKS - 2 && (uint32_t)(p + 1) < K)
+                        lds_load12(S[(p + 1) & 1], base16 + (BLSGPU_UOP(p + 1) & BLSGPU_SLOTMASK) * 3u);
                     const uint32_t u = BLSGPU_UOP(p);
+#if defined(BLSGPU_EXP) && (BLSGPU_EXP & 16)
+                    for (int j = 0; j < 12; j++) acc[j] ^= S[p & 1][j];          // timing experiment only
+#else
                     bls::fat_mac(acc, S[p & 1], (u >> 10) & 31u, (uint32_t)((int32_t)(u << 16) >> 31));
+#endif
                 }
             }
 #undef BLSGPU_UOP
+            const uint32_t w1 = ch[0].x >> 16;               // N | absorb1 << 14 | absorb2 << 15
+            bls::fat_compensate(acc, w1 & 0x3FFFu);          // N * K1 for the lane's N complemented units
+            // a combination split over 2 or 4 adjacent lanes: the flagged lanes add their
+            // neighbours' partial limb accumulators (exact 64-bit integer adds)
+            const uint32_t levels = (meta >> 16) & 3u;
+            if (levels >= 1u) {
+                const uint32_t m1 = (uint32_t)((int32_t)(w1 << 17) >> 31);
+#pragma unroll
+                for (int j = 0; j < 12; j++) acc[j] += dpp_quad64<0xF5>(acc[j], m1);   // lanes 0,2 of a quad += lanes 1,3
+            }
+            if (levels >= 2u) {
+                const uint32_t m2 = (uint32_t)((int32_t)(w1 << 16) >> 31);
+#pragma unroll
+                for (int j = 0; j < 12; j++) acc[j] += dpp_quad64<0xAA>(acc[j], m2);   // lane 0 += lane 2
+            }
 #ifdef BLSGPU_STAMPS
             asm volatile("" :: "v"(acc[0]), "v"(acc[11]));
             unsigned long long lt1 = __builtin_amdgcn_s_memtime();
@@ -207,6 +256,8 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
             st_lin[0] += lt1 - lt0; st_lin[1] += lt2 - lt1; st_lin[2] += K;
 #endif
             if (rd != 0xFFFFu) lds_store12(D, base16 + rd);
+        } else if (LIGHT) {
+            // no other kind in a light program
         } else if (kind == 2u) {                             // INV
             uint32_t ra = e_cur.x & 0xFFFFu, rd = e_cur.y & 0xFFFFu;
             if (rd != 0xFFFFu) {
@@ -262,7 +313,7 @@ __device__ __forceinline__ void wg_product_tree(const VmTables& T, uint32_t* sme
             const uint32_t* other = smem + (wave + s) * TEAM_DW + F_DW;
             for (uint32_t i = lane; i < 144; i += 64) team[R1_DW + i] = other[i];
             wave_fence();
-            run_rounds(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, wave * (TEAM_BYTES / 16), lane);
+            run_rounds<true>(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, wave * (TEAM_BYTES / 16), lane);
         }
     }
 }
@@ -323,7 +374,7 @@ __global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, c
         } else if (p_zero) {
             team_set_acc(team, lane, true);
         } else {
-            run_rounds(T, T.mflat, BLSVM_MILLER_FLAT_LEN, base16, lane);
+            run_rounds<true>(T, T.mflat, BLSVM_MILLER_FLAT_LEN, base16, lane);
         }
     } else {
         wave_fence();
@@ -390,7 +441,7 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
         special |= pair_flags(team, mp_pair_base(g) - BLSVM_MP_SHIFT, lane);
     }
     if (!special) {
-        run_rounds(T, T.mpflat, BLSVM_MP_FLAT_LEN, 0, lane);
+        run_rounds<true>(T, T.mpflat, BLSVM_MP_FLAT_LEN, 0, lane);
     } else {
         bool have = false;
         for (uint32_t g = 0; g < cnt; ++g) {
@@ -399,10 +450,10 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
             const uint32_t fl = pair_flags(team, BLSVM_SLOT_PX, lane);
             if (fl & 4u) team_set_acc(team, lane, !(fl & 2u));
             else if (fl & 1u) team_set_acc(team, lane, true);
-            else run_rounds(T, T.mflat, BLSVM_MILLER_FLAT_LEN, 0, lane);
+            else run_rounds<true>(T, T.mflat, BLSVM_MILLER_FLAT_LEN, 0, lane);
             wave_fence();
-            if (have) run_rounds(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, 0, lane);
-            run_rounds(T, T.segflat + BLSVM_SEGF_COPY_1_0_OFF, BLSVM_SEGF_COPY_1_0_LEN, 0, lane);
+            if (have) run_rounds<true>(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, 0, lane);
+            run_rounds<true>(T, T.segflat + BLSVM_SEGF_COPY_1_0_OFF, BLSVM_SEGF_COPY_1_0_LEN, 0, lane);
             have = true;
         }
         if (!have) team_set_acc(team, lane, true);
@@ -440,7 +491,7 @@ __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __re
         uint32_t dst = first ? F_DW : R1_DW;
         for (uint32_t k = lane; k < 144; k += 64) team[dst + k] = src[k];
         wave_fence();
-        if (!first) run_rounds(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, base16, lane);
+        if (!first) run_rounds<true>(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, base16, lane);
         first = false;
     }
     if (first) team_set_acc(team, lane, true);
@@ -492,7 +543,7 @@ __global__ void __launch_bounds__(512) k_final_groups(VmTables T, const uint32_t
         const uint32_t dst = (i == 0) ? F_DW : R1_DW;
         for (uint32_t k = lane; k < 144; k += 64) team[dst + k] = src[k];
         wave_fence();
-        if (i) run_rounds(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, base16, lane);
+        if (i) run_rounds<true>(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, base16, lane);
     }
     wave_fence();
     run_rounds(T, T.fflat, BLSVM_FEXP_FLAT_LEN, base16, lane);
@@ -525,7 +576,7 @@ __global__ void __launch_bounds__(512) k_bytes_to_partials(VmTables T, const uin
         team[R1_DW + cidx * 12 + (11 - w)] = bswap32(in_bytes[(size_t)g * 144 + k]);
     }
     wave_fence();
-    run_rounds(T, T.segflat + BLSVM_SEGF_TO_MONT_0_1_OFF, BLSVM_SEGF_TO_MONT_0_1_LEN, wave * (TEAM_BYTES / 16), lane);
+    run_rounds<true>(T, T.segflat + BLSVM_SEGF_TO_MONT_0_1_OFF, BLSVM_SEGF_TO_MONT_0_1_LEN, wave * (TEAM_BYTES / 16), lane);
     for (uint32_t k = lane; k < 144; k += 64) out_partials[(size_t)g * 144 + k] = team[F_DW + k];
 }
 

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256, 3) k_msm(VmTables T, const uint32_t* __re
             sw[j] = v;
         }
         wave_fence();
-        run_rounds(T, T.segflat + C::LOAD_OFF, C::LOAD_LEN, base16, lane);
+        run_rounds<true>(T, T.segflat + C::LOAD_OFF, C::LOAD_LEN, base16, lane);
         // (0,0) inputs are the point at infinity
         uint32_t zero_in = 0;
         if (lane < C::NP) {
@@ -113,13 +113,13 @@ __global__ void __launch_bounds__(256, 3) k_msm(VmTables T, const uint32_t* __re
                     team[C::S * 12 + d] = ((bits >> p) & 1ull) ? team[C::A * 12 + d] : inf_dword<DEG>(team, d % PJ_DW);
                 }
                 wave_fence();
-                run_rounds(T, T.segflat + C::STEP_OFF, C::STEP_LEN, base16, lane);
+                run_rounds<true>(T, T.segflat + C::STEP_OFF, C::STEP_LEN, base16, lane);
             }
             if (32u * (j + 1) >= bl) break;
         }
     }
     wave_fence();
-    run_rounds(T, T.segflat + C::FOLD_OFF, C::FOLD_LEN, base16, lane);
+    run_rounds<true>(T, T.segflat + C::FOLD_OFF, C::FOLD_LEN, base16, lane);
     // product tree over the teams of the workgroup
     for (uint32_t s = 1; s < nwaves; s <<= 1) {
         __syncthreads();
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256, 3) k_msm(VmTables T, const uint32_t* __re
             const uint32_t* other = smem + (wave + s) * TEAM_DW + C::PR0 * 12;
             for (uint32_t i = lane; i < PJ_DW; i += 64) team[C::PR1 * 12 + i] = other[i];
             wave_fence();
-            run_rounds(T, T.segflat + C::PADD_OFF, C::PADD_LEN, base16, lane);
+            run_rounds<true>(T, T.segflat + C::PADD_OFF, C::PADD_LEN, base16, lane);
         }
     }
     if (wave == 0) {
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_msm_finish(VmTables T, const uint32_t* 
         const uint32_t dst = (i == 0) ? C::PR0 : C::PR1;
         for (uint32_t d = lane; d < PJ_DW; d += 64) team[dst * 12 + d] = src[d];
         wave_fence();
-        if (i) run_rounds(T, T.segflat + C::PADD_OFF, C::PADD_LEN, base16, lane);
+        if (i) run_rounds<true>(T, T.segflat + C::PADD_OFF, C::PADD_LEN, base16, lane);
     }
     run_rounds(T, T.segflat + C::AFF_OFF, C::AFF_LEN, base16, lane);
     if (lane < 2u * DEG) {

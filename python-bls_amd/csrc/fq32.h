@@ -296,6 +296,14 @@ BLS_HD void acc_reduce_relaxed(uint32_t* __restrict__ out, const uint32_t* __res
 #define BLS_QC_LIMBS /* 2^384 - q */ \
     {0x00005555u, 0x46010000u, 0x4eac0000u, 0xe1540001u, 0x094f09dbu, 0x98cf2d5fu, 0x0c7aed40u, 0x9b88b47bu, 0xbcb45328u, 0xb4e45849u, 0xc6801965u, 0xe5feee15u}
 
+#define BLS_K1_LIMBS /* -(2^384 - 1) mod q: cancels the surplus of one complemented term */ \
+    {0xfffcaaafu, 0x43f5ffffu, 0xed47fffdu, 0x32b7fff2u, 0xa2e99d69u, 0x07e83a49u, 0x8332bb7au, 0xeca8f331u, 0xa0f4c069u, 0xef148d1eu, 0x3eff0206u, 0x040ab326u}
+// acc += n * K1
+BLS_HD void fat_compensate(uint64_t* __restrict__ acc, uint32_t n) {
+    const uint32_t k1[12] = BLS_K1_LIMBS;
+#pragma unroll
+    for (int j = 0; j < 12; j++) acc[j] += (uint64_t)k1[j] * n;
+}
 // acc[j] += cf * (s[j] ^ negmask),  negmask = 0 or 0xffffffff
 BLS_HD void fat_mac(uint64_t* __restrict__ acc, const uint32_t* __restrict__ s, uint32_t cf, uint32_t negmask) {
 #pragma unroll

@@ -33,7 +33,61 @@ def sref(slot):
 
 
 def kpad(K):
-    return (K + 1 + 3) & ~3
+    """u16 per lane record of a LIN round: destination, compensation count, K micro-ops"""
+    return (K + 2 + 3) & ~3
+
+
+def plan_lin_round(lanes):
+    """Lane records of one LIN round: [(dst | None, negsum, uops)], K, levels.
+
+    * The compensation micro-ops N * K1 of core.lower_lin are folded into a per-lane
+      count N (the kernel adds N * K1 after the loop from constants).
+    * A long combination is split over 2 or 4 ADJACENT lanes (aligned), each summing a
+      share of the micro-ops into its own 64-bit limb accumulators; the kernel adds
+      the accumulators across the group (DPP, `levels` steps) and the group's first
+      lane reduces and stores.  Splitting is free of rounding: the accumulators are
+      exact integers.  Chosen to minimise K + levels, K = longest share."""
+    ops = []
+    for uops, d in lanes:
+        real = [u for u in uops if u[2] != P.C_K1]
+        nsum = sum(cf for neg, cf, s in real if neg)
+        assert nsum == sum(cf for neg, cf, s in uops if s == P.C_K1), "compensation does not match"
+        ops.append((d, real))
+    base = max(1, max(len(u) for _, u in ops))
+    best = (base, 0, [1] * len(ops))
+    for lv in (1, 2):
+        gmax = 1 << lv
+        for T in range(1, base):
+            if T + 1.5 * lv >= best[0] + 1.5 * best[1]:
+                break
+            gs, tot = [], 0
+            for _, u in ops:
+                g = 1
+                while -(-len(u) // g) > T and g < gmax:
+                    g *= 2
+                if -(-len(u) // g) > T:
+                    tot = None
+                    break
+                gs.append(g)
+                tot += g
+            if tot is not None and tot <= LANES:
+                best = (T, lv, gs)
+                break
+    T, lv, gs = best
+    plan = []
+    for g in (4, 2, 1):                                   # widest groups first keeps every group aligned
+        for (d, u), gg in zip(ops, gs):
+            if gg != g:
+                continue
+            share = -(-len(u) // g) if u else 0
+            for part in range(g):
+                mine = u[part * share:(part + 1) * share]
+                flags = (1 << 14 if g >= 2 and part % 2 == 0 else 0) | (1 << 15 if g == 4 and part == 0 else 0)
+                nsum = sum(cf for neg, cf, s in mine if neg)
+                assert nsum < (1 << 14)
+                plan.append((d if part == 0 else None, nsum | flags, mine))
+    K = max(1, max(len(m) for _, _, m in plan))
+    return plan, K, lv
 
 
 def pack(segs, order):
@@ -66,21 +120,22 @@ def pack(segs, order):
                     else:
                         data += [0, 0, INACTIVE, 0]
             else:
-                K = max(len(u) for u, _ in lanes)
-                assert K < 256
-                kp = (K + 1 + 3) & ~3
+                plan, K, lv = plan_lin_round(lanes)
+                assert K < 256 and len(plan) <= LANES
+                kp = kpad(K)
                 for ln in range(LANES):
                     rec = [0] * kp
-                    if ln < len(lanes):
-                        uops, d = lanes[ln]
-                        rec[0] = sref(mv(d))
+                    if ln < len(plan):
+                        d, nsum, uops = plan[ln]
+                        rec[0] = sref(mv(d)) if d is not None else INACTIVE
+                        rec[1] = nsum
                         for k, (neg, cf, s) in enumerate(uops):
                             assert 0 < cf < 32 and 0 <= s < 1024
-                            rec[1 + k] = (neg << 15) | (cf << 10) | mv(s)
+                            rec[2 + k] = (neg << 15) | (cf << 10) | mv(s)
                     else:
                         rec[0] = INACTIVE
                     data += rec
-                lst.append((off, KIND[kind] | (K << 8)))
+                lst.append((off, KIND[kind] | (K << 8) | (lv << 16)))
                 continue
             lst.append((off, KIND[kind]))
         seg_rounds[name] = lst
@@ -96,7 +151,8 @@ MSM_NP = {1: 6, 2: 2}                                         # points per team 
 H1_NE, H2_NM = 12, 2                                          # encodings / messages per team (hash to G2)
 
 
-def generate(path=None, verbose=False):
+def build_tables(verbose=False):
+    """Everything the header is made of, as Python objects (also what tablesim runs)."""
     segs, mscript, fscript = P.build_all(verbose=verbose)
     mpsegs, mpscript = P.build_multi(verbose=verbose)
     segs.update(mpsegs)
@@ -111,6 +167,16 @@ def generate(path=None, verbose=False):
     segs.update(h2segs)
     order = sorted(segs)
     seg_rounds, data = pack(segs, order)
+    return dict(segs=segs, mscript=mscript, fscript=fscript, mpsegs=mpsegs, mpscript=mpscript, msm=msm,
+                h1=(h1segs, h1lay, h1script), h2=(h2segs, h2lay, h2script), order=order,
+                seg_rounds=seg_rounds, data=data)
+
+
+def generate(path=None, verbose=False):
+    tb = build_tables(verbose)
+    segs, mscript, fscript, mpsegs, mpscript, msm = (tb[k] for k in ("segs", "mscript", "fscript", "mpsegs", "mpscript", "msm"))
+    (h1segs, h1lay, h1script), (h2segs, h2lay, h2script) = tb["h1"], tb["h2"]
+    order, seg_rounds, data = tb["order"], tb["seg_rounds"], tb["data"]
     team_slots = P.TEMP0 + max(s.ntemp for n, s in segs.items()
                                if not n.startswith("g") and not n.startswith("mp_") and not n.startswith("h"))
     mp_team_slots = max(team_slots, P.mp_temp0(P.MP_G) + max(s.ntemp for s in mpsegs.values()) - P.MP_SHIFT)
@@ -123,7 +189,7 @@ def generate(path=None, verbose=False):
     w = out.append
     w("/* generated by python-bls_amd/vmgen/emit.py -- do not edit */\n#pragma once\n#include <stdint.h>\n")
     w("#define BLSVM_NDATA %d\n" % len(data))
-    maxk = max(max(len(u) for u, _ in r["lanes"]) for s in segs.values() for r in s.rounds if r["kind"] == "lin")
+    maxk = max(plan_lin_round(r["lanes"])[1] for s in segs.values() for r in s.rounds if r["kind"] == "lin")
     w("#define BLSVM_MAX_LIN_K %d\n" % maxk)
     w("#define BLSVM_TEAM_SLOTS %d\n#define BLSVM_NCONST %d\n" % (team_slots, P.NCONST))
     for nm in ("PX", "PY", "QX0", "TX", "LD", "LA", "NPX3", "REG0", "NREG", "TEMP0", "C_ZERO", "C_ONE", "C_R2", "C_RAW1", "C_K1"):

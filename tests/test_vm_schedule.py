@@ -110,3 +110,57 @@ def test_committed_tables_are_current(tmp_path):
     with open(path) as f:
         have = re.search(r'BLSVM_TABLE_HASH "([0-9a-f]+)"', f.read()).group(1)
     assert have == info["hash"]
+
+
+def test_packed_tables_decode_like_the_kernel(golden):
+    """The PACKED tables (what vm_tables.h holds), decoded the way run_rounds decodes
+    them -- record layout, folded compensation counts, combinations split over
+    adjacent lanes -- reproduce the reference pairing: single-pair program, then the
+    3-pairs-per-team program in its shifted address space."""
+    from vmgen import tablesim
+    tb = emit.build_tables()
+    sr, data = tb["seg_rounds"], tb["data"]
+    consts = P.const_table()
+    g = golden("pairing.json")["gen"]
+    g1, g2 = bytes.fromhex(g["g1"]), bytes.fromhex(g["g2"])
+    vals = [int.from_bytes(g1[i * 48:(i + 1) * 48], "big") for i in range(2)] + \
+           [int.from_bytes(g2[i * 48:(i + 1) * 48], "big") for i in range(4)]
+    fexp = [r for n in tb["fscript"] for r in sr[n]] + sr["from_mont_1_0"]
+
+    def finish(f12):
+        m = tablesim.TableMachine(consts, 400, data, P.C_K1)
+        for i in range(12):
+            m.team[P.F + i] = f12[i]
+        m.run(fexp)
+        return b"".join(m.team[P.reg(1) + i].to_bytes(48, "big") for i in range(12))
+    m = tablesim.TableMachine(consts, 400, data, P.C_K1)
+    for i, v in enumerate(vals):
+        m.team[P.PX + i] = v
+    m.run([r for n in tb["mscript"] for r in sr[n]])
+    assert finish([m.team[P.F + i] for i in range(12)]).hex() == g["final_exp"]
+    # three pairs per team: small4[0..2]; expected = product of the three single pairings
+    v = golden("pairing.json")["small4"]
+    m = tablesim.TableMachine(consts[:P.C_GAM], 400, data, P.C_K1)
+    singles = []
+    for k in range(3):
+        a, b = bytes.fromhex(v["g1"][k]), bytes.fromhex(v["g2"][k])
+        pv = [int.from_bytes(a[i * 48:(i + 1) * 48], "big") for i in range(2)] + \
+             [int.from_bytes(b[i * 48:(i + 1) * 48], "big") for i in range(4)]
+        base = (P.PX if k == 0 else P.MP_BLOCK0 + P.PAIR_BLOCK * (k - 1)) - P.MP_SHIFT
+        for i, x in enumerate(pv):
+            m.team[base + i] = x
+        s = tablesim.TableMachine(consts, 400, data, P.C_K1)
+        for i, x in enumerate(pv):
+            s.team[P.PX + i] = x
+        s.run([r for n in tb["mscript"] for r in sr[n]])
+        singles.append([s.team[P.F + i] for i in range(12)])
+    m.run([r for n in tb["mpscript"] for r in sr[n]])
+    got = finish([m.team[P.F - P.MP_SHIFT + i] for i in range(12)])
+    acc = singles[0]
+    for nxt in singles[1:]:
+        t = tablesim.TableMachine(consts, 400, data, P.C_K1)
+        for i in range(12):
+            t.team[P.reg(0) + i], t.team[P.reg(1) + i] = acc[i], nxt[i]
+        t.run(sr["mul_0_1"])
+        acc = [t.team[P.reg(0) + i] for i in range(12)]
+    assert got == finish(acc)
