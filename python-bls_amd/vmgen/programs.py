@@ -290,9 +290,24 @@ def seg_mul(cfg, d, a):
     return b
 
 
-def seg_cyc_sqr(cfg, d):
-    b = Builder("cyc_sqr_%d" % d)         # R[d] <- R[d]^2 (cyclotomic subgroup only)
-    out12(b, tw.f12_cyclo_sqr(cfg, in12(b, reg(d))), reg(d))
+CYC_CHUNKS = (16, 8, 4, 2, 1)             # lengths of the chained-squaring segments
+
+
+def seg_cyc_sqr(cfg, n, d):
+    """R[d] <- R[d]^(2^n) (cyclotomic subgroup only).  The n squarings are chained
+    lazily: each keeps a materialised copy of its result (for the next one's +-2x
+    terms and as the output) while the operand pre-additions of the next squaring
+    are taken from the unmaterialised expressions, so that one LIN level sits
+    between consecutive MUL rounds: 2n + 1 rounds instead of 4n."""
+    b = Builder("cyc_sqr%d_%d" % (n, d))
+    lazy = tw.Cfg(m2=cfg.m2, s2=cfg.s2, mat2=False)
+    xm = in12(b, reg(d))
+    xl = xm
+    for _ in range(n):
+        y = tw.f12_cyclo_sqr(lazy, xl, ref=xm)
+        xm = tuple(tuple(tw.f2_mat(c) for c in h) for h in y)
+        xl = y
+    out12(b, xm, reg(d))
     return b
 
 
@@ -352,7 +367,11 @@ def seg_set_one(d):
 
 SEG_FACTORY = {
     "mul": lambda cfg, *r: seg_mul(cfg, *r),
-    "cyc_sqr": lambda cfg, *r: seg_cyc_sqr(cfg, *r),
+    "cyc_sqr16": lambda cfg, *r: seg_cyc_sqr(cfg, 16, *r),
+    "cyc_sqr8": lambda cfg, *r: seg_cyc_sqr(cfg, 8, *r),
+    "cyc_sqr4": lambda cfg, *r: seg_cyc_sqr(cfg, 4, *r),
+    "cyc_sqr2": lambda cfg, *r: seg_cyc_sqr(cfg, 2, *r),
+    "cyc_sqr1": lambda cfg, *r: seg_cyc_sqr(cfg, 1, *r),
     "copy": lambda cfg, *r: seg_copy(*r),
     "conj": lambda cfg, *r: seg_conj(*r),
     "frob1": lambda cfg, *r: seg_frob(cfg, 1, *r),
@@ -393,10 +412,20 @@ def final_exp_script():
     def pow_acc(e):
         """r0 <- r0^e (cyclotomic), clobbers r1."""
         S.append("copy_1_0")
+        run = 0
+
+        def flush(run):
+            for n in CYC_CHUNKS:
+                while run >= n:
+                    S.append("cyc_sqr%d_0" % n)
+                    run -= n
         for bit in range(e.bit_length() - 2, -1, -1):
-            S.append("cyc_sqr_0")
+            run += 1
             if (e >> bit) & 1:
+                flush(run)
+                run = 0
                 S.append("mul_0_1")
+        flush(run)
     # easy part
     S += ["inv12_2_0", "conj_1_0", "mul_1_2",      # r1 = f^(q^6-1)
           "frob2_0_1", "mul_0_1",                  # r0 = t (cyclotomic from here on)

@@ -210,10 +210,13 @@ def f12_frob(cfg, x, i, gam):
     return ((c(a0), g(a1, 2), g(a2, 4)), (g(b0, 1), g(b1, 3), g(b2, 5)))
 
 
-def f12_cyclo_sqr(cfg, x):
+def f12_cyclo_sqr(cfg, x, ref=None):
     """Granger-Scott squaring in the cyclotomic subgroup: 9 Fq2 squarings'
-    worth of products (as 3 Fq4 squarings)."""
+    worth of products (as 3 Fq4 squarings).  `ref`: the same element again, used
+    for the linear +-2x terms (chained squarings pass the materialised copy there
+    and the lazy one as x, so that one LIN level serves both)."""
     (a0, a1, a2), (b0, b1, b2) = x
+    (ra0, ra1, ra2), (rb0, rb1, rb2) = ref if ref is not None else x
 
     def fp4_sq(a, b):
         t0 = cfg.sqr2(a)
@@ -224,12 +227,12 @@ def f12_cyclo_sqr(cfg, x):
     t0, t1 = fp4_sq(a0, b1)
     t2, t3 = fp4_sq(b0, a2)
     t4, t5 = fp4_sq(a1, b2)
-    c00 = f2_sub(f2_scale(t0, 3), f2_scale(a0, 2))
-    c01 = f2_sub(f2_scale(t2, 3), f2_scale(a1, 2))
-    c02 = f2_sub(f2_scale(t4, 3), f2_scale(a2, 2))
-    c10 = f2_add(f2_scale(f2_mul_xi(t5), 3), f2_scale(b0, 2))
-    c11 = f2_add(f2_scale(t1, 3), f2_scale(b1, 2))
-    c12 = f2_add(f2_scale(t3, 3), f2_scale(b2, 2))
+    c00 = f2_sub(f2_scale(t0, 3), f2_scale(ra0, 2))
+    c01 = f2_sub(f2_scale(t2, 3), f2_scale(ra1, 2))
+    c02 = f2_sub(f2_scale(t4, 3), f2_scale(ra2, 2))
+    c10 = f2_add(f2_scale(f2_mul_xi(t5), 3), f2_scale(rb0, 2))
+    c11 = f2_add(f2_scale(t1, 3), f2_scale(rb1, 2))
+    c12 = f2_add(f2_scale(t3, 3), f2_scale(rb2, 2))
     return ((c00, c01, c02), (c10, c11, c12))
 
 
