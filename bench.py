@@ -2,10 +2,11 @@
 """bench.py -- BLS12-381 pairings/sec through the HIP multi-pairing engine.
 
 One "step" = one pass of the hot path over one batch that is already resident in
-HBM: B independent aggregate verifications (default 16), each the BASELINE.json
+HBM: B independent aggregate verifications (default 32), each the BASELINE.json
 configs[1] shape -- fq_ate_pairing_multi over 1025 (pk, H(m)) pairs per GPU (1024
 signatures + the (-G1, aggregate) pair): Miller loops, Fq12 product, its own
-final exponentiation.  One launch sequence per step (blsgpu_pairing_multi_batch_dev).
+final exponentiation.  One launch sequence per step (blsgpu_miller_product_batch_dev
++ blsgpu_final_exp_product_batch_dev, the sharded form of blsgpu_pairing_multi_batch_dev).
 With N ranks every rank holds 1025 pairs of EACH verification (weak scaling):
 Miller products per rank, one RCCL all-gather of the B x 576-byte Fq12 partials,
 B final exponentiations on every rank.  A single verification alone is latency
@@ -25,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "python-bls_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PAIRS_PER_GPU = 1025
-VERIFICATIONS_PER_STEP = 16
+VERIFICATIONS_PER_STEP = 32
 # algorithmic work, SURVEY.md section 8(d): 6754 Fq-mults per pairing at 300
 # 32-bit MACs each, plus ~9.5k Fq-mults per final exponentiation
 MAC_PER_PAIRING = 6754 * 300
@@ -52,7 +53,7 @@ def cpu_baseline(g1, g2, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per verification")
     ap.add_argument("--verifications", type=int, default=VERIFICATIONS_PER_STEP,
@@ -115,14 +116,25 @@ def main():
         e.reserve((n + 3) * B)
         e.set_mp_threshold(0 if n * B >= 2048 else 1 << 40)    # throughput kernel once the batch can fill the GPU
 
+    # A step = Miller loops + per-verification products (stream k), then the B final
+    # exponentiations.  Miller launches of consecutive steps are serialised with an
+    # event (they would only stretch each other), so the final exponentiations of
+    # step i (B wavefronts, latency bound) overlap the Miller loops of step i + 1.
+    miller_done = [None]
+
     def step(i):
         k = i % S
         stream = streams[k]
         st = stream.cuda_stream
+        if miller_done[0] is not None:
+            stream.wait_event(miller_done[0])
+        engs[k].miller_product_batch_dev(t1.data_ptr(), t2.data_ptr(), n, B, parts[k].data_ptr(), st)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        miller_done[0] = ev
         if world == 1:
-            engs[k].pairing_multi_batch_dev(t1.data_ptr(), t2.data_ptr(), n, B, outs[k].data_ptr(), st)
+            engs[k].final_exp_product_batch_dev(parts[k].data_ptr(), 1, B, outs[k].data_ptr(), st)
         else:
-            engs[k].miller_product_batch_dev(t1.data_ptr(), t2.data_ptr(), n, B, parts[k].data_ptr(), st)
             with torch.cuda.stream(stream):
                 if args.backend == "nccl":
                     dist.all_gather_into_tensor(gath[k], parts[k])       # RCCL: B x 576 bytes per rank
@@ -140,6 +152,8 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    for e in engs:
+        e.timing_enable(True)         # HIP events around every kernel, on the stream it runs on
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -157,22 +171,13 @@ def main():
     dt = float(tt.item())
     results = [bytes(o.cpu().numpy()) for o in outs[:min(S, args.steps)]]
     step_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    # Per-kernel durations for the roofline object: the same step again, one at a
-    # time, with HIP events around every kernel on the stream it runs on (steps in
-    # flight stretch each other's kernel durations; a lone step does not).
-    eng.timing_enable(True)
+    ktimes = [t for e in engs for t in e.timing_read()]        # every kernel of the timed region
+    for e in engs:
+        e.timing_enable(False)
+    miller_ms = [ms for k, ms in ktimes if k == 0]
+    reduce_ms = [ms for k, ms in ktimes if k == 1]
+    fexp_ms = [ms for k, ms in ktimes if k == 2]
     solo_out = torch.zeros(B * 576, dtype=torch.uint8, device=dev)
-    for i in range(min(args.steps, 8)):
-        if world == 1:
-            eng.pairing_multi_batch_dev(t1.data_ptr(), t2.data_ptr(), n, B, solo_out.data_ptr(), streams[0].cuda_stream)
-        else:
-            eng.miller_product_batch_dev(t1.data_ptr(), t2.data_ptr(), n, B, parts[0].data_ptr(), streams[0].cuda_stream)
-        streams[0].synchronize()
-    solo = eng.timing_read()
-    eng.timing_enable(False)
-    miller_ms = [ms for k, ms in solo if k == 0]
-    reduce_ms = [ms for k, ms in solo if k == 1]
-    fexp_ms = [ms for k, ms in solo if k == 2]
     # single verification alone on the GPU (latency view of the same workload)
     one_ms = []
     eng.set_mp_threshold(4096)
@@ -207,7 +212,8 @@ def main():
         if check == "MISMATCH":
             raise SystemExit("result mismatch -- bench invalid")
         # dominant kernel = the Miller kernel (all the per-pairing work): algorithmic
-        # MACs of one launch (B x n pairings) over its average duration
+        # MACs of one launch (B x n pairings) over its average duration in the timed
+        # region (launches do not overlap each other, see step())
         miller_avg = sum(miller_ms) / len(miller_ms)
         ach = MAC_PER_PAIRING * n * B / (miller_avg * 1e-3) / 1e12
         line = {
