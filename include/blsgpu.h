@@ -127,6 +127,18 @@ int blsgpu_g2_msm_dev(blsgpu_ctx *ctx, const void *d_pts, const void *d_scalars,
 int blsgpu_map_to_g2(blsgpu_ctx *ctx, const uint8_t *t, size_t n, uint8_t *out);
 int blsgpu_map_to_g2_dev(blsgpu_ctx *ctx, const void *d_t, size_t n, void *d_out, void *stream);
 
+/* Batched point decompression: PublicKey.from_bytes (keys.py:28-40) and
+ * Signature.from_bytes (signature.py:21-38) from the serialised bytes: mask the top
+ * three bits (`& 0x1f`), y_for_x (ec.py:255-269; square roots fields.py:199-205 and
+ * 463-482), and the reference's choice between y and -y by bit 0x80 (G2: on the
+ * imaginary part only, signature.py:31-35).  in: n x 48 (G1) / n x 96 (G2) bytes;
+ * out: n x 96 / n x 192 bytes affine; ok[i] = 1 iff the reference accepts encoding i
+ * (it raises ValueError otherwise; out bytes of such an entry are unspecified). */
+int blsgpu_g1_decompress(blsgpu_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, uint8_t *ok);
+int blsgpu_g2_decompress(blsgpu_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, uint8_t *ok);
+int blsgpu_g1_decompress_dev(blsgpu_ctx *ctx, const void *d_in, size_t n, void *d_out, void *d_ok, void *stream);
+int blsgpu_g2_decompress_dev(blsgpu_ctx *ctx, const void *d_in, size_t n, void *d_out, void *d_ok, void *stream);
+
 /* Measurement aid (bench.py): when enabled, HIP events are recorded on the
  * launch stream around every kernel this context launches (up to 1024 launches
  * between reads).  blsgpu_timing_read waits for them and returns, per launch,

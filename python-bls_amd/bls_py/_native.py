@@ -20,6 +20,7 @@ SYMBOLS = (
     "blsgpu_final_exp_batch", "blsgpu_pairing_multi_batch", "blsgpu_pairing_multi_batch_dev",
     "blsgpu_map_to_g2", "blsgpu_map_to_g2_dev",
     "blsgpu_miller_product_batch_dev", "blsgpu_final_exp_product_batch_dev",
+    "blsgpu_g1_decompress", "blsgpu_g2_decompress", "blsgpu_g1_decompress_dev", "blsgpu_g2_decompress_dev",
 )
 
 _lib = None
@@ -72,6 +73,10 @@ def load_library(path=None):
         L.blsgpu_pairing_multi_batch_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp]
         L.blsgpu_miller_product_batch_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp]
         L.blsgpu_final_exp_product_batch_dev.argtypes = [vp, vp, sz, sz, vp, vp]
+        L.blsgpu_g1_decompress.argtypes = [vp, cp, sz, cp, cp]
+        L.blsgpu_g2_decompress.argtypes = [vp, cp, sz, cp, cp]
+        L.blsgpu_g1_decompress_dev.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.blsgpu_g2_decompress_dev.argtypes = [vp, vp, sz, vp, vp, vp]
         L.blsgpu_map_to_g2.argtypes = [vp, cp, sz, cp]
         L.blsgpu_map_to_g2_dev.argtypes = [vp, vp, sz, vp, vp]
         L.blsgpu_timing_enable.argtypes = [vp, ctypes.c_int]
@@ -147,6 +152,23 @@ class Engine:
         out = ctypes.create_string_buffer(max(1, 576 * groups))
         self._check(self.lib.blsgpu_pairing_multi_batch(self.h, g1, g2, gsz, groups, out), "blsgpu_pairing_multi_batch")
         return out.raw[:576 * groups]
+
+    def _decompress(self, fn, name, insz, data):
+        if len(data) % insz:
+            raise ValueError("need n x %d bytes" % insz)
+        k = len(data) // insz
+        out = ctypes.create_string_buffer(max(1, 2 * len(data)))
+        ok = ctypes.create_string_buffer(max(1, k))
+        self._check(fn(self.h, data, k, out, ok), name)
+        return out.raw[:2 * len(data)], [b != 0 for b in ok.raw[:k]]
+
+    def g1_decompress(self, data: bytes):
+        """n x 48 bytes -> (n x 96 bytes affine, [accepted])."""
+        return self._decompress(self.lib.blsgpu_g1_decompress, "blsgpu_g1_decompress", 48, data)
+
+    def g2_decompress(self, data: bytes):
+        """n x 96 bytes -> (n x 192 bytes affine, [accepted])."""
+        return self._decompress(self.lib.blsgpu_g2_decompress, "blsgpu_g2_decompress", 96, data)
 
     def map_to_g2(self, t: bytes) -> bytes:
         """t: n x 192 bytes (t0.c0, t0.c1, t1.c0, t1.c1) -> n x 192 bytes affine G2."""

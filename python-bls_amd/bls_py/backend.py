@@ -28,11 +28,18 @@ class HipProvider:
     def map_to_g2(self, t: bytes) -> bytes:
         return self._eng.map_to_g2(t)
 
+    def g1_decompress(self, data: bytes):
+        return self._eng.g1_decompress(data)
+
+    def g2_decompress(self, data: bytes):
+        return self._eng.g2_decompress(data)
+
 
 def use(provider):
     """Install a provider object with pairing_multi(g1, g2, n), final_exp(x),
     g1_msm / g2_msm(pts, scalars|None, k, groups) -> (bytes, [is_inf]),
-    map_to_g2(t: n x 192 bytes) -> n x 192 bytes."""
+    map_to_g2(t: n x 192 bytes) -> n x 192 bytes,
+    g1_decompress / g2_decompress(bytes) -> (affine bytes, [accepted])."""
     global _provider
     _provider = provider
 

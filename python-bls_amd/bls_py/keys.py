@@ -28,6 +28,23 @@ class PublicKey:
         return PublicKey(JacobianPoint._from(H.F1, H.aff_to_jac(H.F1, A), default_ec))
 
     @staticmethod
+    def from_bytes_batch(buffers):
+        """[PublicKey.from_bytes(b) for b in buffers] with the square roots of all keys
+        in one GPU call (blsgpu_g1_decompress); ValueError on the first bad encoding,
+        as from_bytes raises."""
+        from . import backend
+        buffers = [bytes(b) for b in buffers]
+        if any(len(b) != PublicKey.PUBLIC_KEY_SIZE for b in buffers):
+            raise ValueError("public keys are %d bytes" % PublicKey.PUBLIC_KEY_SIZE)
+        if not buffers:
+            return []
+        out, ok = backend.get().g1_decompress(b"".join(buffers))
+        if not all(ok):
+            raise ValueError("No y for point x")
+        return [PublicKey(JacobianPoint._from(H.F1, H.aff_to_jac(H.F1, H.g1_from_abi(out[96 * i:96 * (i + 1)])), default_ec))
+                for i in range(len(buffers))]
+
+    @staticmethod
     def from_g1(g1_el):
         assert type(g1_el) is JacobianPoint
         return PublicKey(g1_el)

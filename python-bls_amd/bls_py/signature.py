@@ -19,6 +19,23 @@ class Signature:
         return Signature(JacobianPoint._from(H.F2, H.aff_to_jac(H.F2, A), default_ec_twist), aggregation_info)
 
     @staticmethod
+    def from_bytes_batch(buffers, aggregation_infos=None):
+        """[Signature.from_bytes(b, info) ...] with all square roots in one GPU call
+        (blsgpu_g2_decompress); ValueError on the first bad encoding."""
+        from . import backend
+        buffers = [bytes(b) for b in buffers]
+        if any(len(b) != Signature.SIGNATURE_SIZE for b in buffers):
+            raise ValueError("signatures are %d bytes" % Signature.SIGNATURE_SIZE)
+        if not buffers:
+            return []
+        infos = aggregation_infos or [None] * len(buffers)
+        out, ok = backend.get().g2_decompress(b"".join(buffers))
+        if not all(ok):
+            raise ValueError("No y for point x")
+        return [Signature(JacobianPoint._from(H.F2, H.aff_to_jac(H.F2, H.g2_from_abi(out[192 * i:192 * (i + 1)])), default_ec_twist),
+                          infos[i]) for i in range(len(buffers))]
+
+    @staticmethod
     def from_g2(g2_el, aggregation_info=None):
         return Signature(g2_el, aggregation_info)
 

@@ -96,6 +96,44 @@ static int ensure_workspace(blsgpu_ctx* c, size_t max_pairs) {
     return 0;
 }
 
+// ------------------------------------------------------------ decompression --
+namespace {
+template <int DEG>
+int decompress_dev(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out, void* d_ok, hipStream_t st) {
+    using C = blsgpu::DecompCfg<DEG>;
+    if (n == 0) return 0;
+    if (n > 0x3FFFFFF0ull) return fail(-EINVAL, "batch too large");
+    unsigned blocks = (unsigned)((n + C::NE - 1) / C::NE);
+    hipLaunchKernelGGL(blsgpu::k_decompress<DEG>, dim3(blocks), dim3(64), (size_t)C::SLOTS * 48, st, c->tabs,
+                       (const uint32_t*)d_in, (uint32_t)n, (uint32_t*)d_out, (uint8_t*)d_ok);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <int DEG>
+int decompress_host(blsgpu_ctx* c, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+    if (!c || (n && (!in || !out || !ok))) return fail(-EINVAL, "NULL argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t need = n * (48 * DEG + 96 * DEG + 1) + 64;
+    if (need > c->io_cap) {
+        if (c->d_io) (void)hipFree(c->d_io);
+        c->d_io = nullptr;
+        c->io_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_io, need));
+        c->io_cap = need;
+    }
+    char* din = (char*)c->d_io;
+    char* dout = din + n * 48 * DEG;
+    char* dok = dout + n * 96 * DEG;
+    HIP_TRY(hipMemcpy(din, in, n * 48 * DEG, hipMemcpyHostToDevice));
+    int rc = decompress_dev<DEG>(c, din, n, dout, dok, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, dout, n * 96 * DEG, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ok, dok, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+}  // namespace
+
 // ---------------------------------------------------------------- MSM -------
 namespace {
 constexpr int MSM_WAVES = 4;
@@ -199,7 +237,9 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     size_t o_mp = o_m + al(sizeof(BLSVM_MILLER_FLAT));
     size_t o_h1 = o_mp + al(sizeof(BLSVM_MP_FLAT));
     size_t o_h2 = o_h1 + al(sizeof(BLSVM_H1_FLAT));
-    size_t o_f = o_h2 + al(sizeof(BLSVM_H2_FLAT));
+    size_t o_d1 = o_h2 + al(sizeof(BLSVM_H2_FLAT));
+    size_t o_d2 = o_d1 + al(sizeof(BLSVM_D1_FLAT));
+    size_t o_f = o_d2 + al(sizeof(BLSVM_D2_FLAT));
     size_t o_s = o_f + al(sizeof(BLSVM_FEXP_FLAT));
     size_t o_data = o_s + al(sizeof(BLSVM_SEG_FLAT));
     size_t o_c = o_data + al(sizeof(BLSVM_DATA));
@@ -212,6 +252,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     struct { size_t off; const void* src; size_t len; } parts[] = {
         {o_m, BLSVM_MILLER_FLAT, sizeof(BLSVM_MILLER_FLAT)}, {o_mp, BLSVM_MP_FLAT, sizeof(BLSVM_MP_FLAT)},
         {o_h1, BLSVM_H1_FLAT, sizeof(BLSVM_H1_FLAT)},        {o_h2, BLSVM_H2_FLAT, sizeof(BLSVM_H2_FLAT)},
+        {o_d1, BLSVM_D1_FLAT, sizeof(BLSVM_D1_FLAT)},        {o_d2, BLSVM_D2_FLAT, sizeof(BLSVM_D2_FLAT)},
         {o_f, BLSVM_FEXP_FLAT, sizeof(BLSVM_FEXP_FLAT)},
         {o_s, BLSVM_SEG_FLAT, sizeof(BLSVM_SEG_FLAT)},       {o_data, BLSVM_DATA, sizeof(BLSVM_DATA)},
         {o_c, BLSVM_CONSTS, sizeof(BLSVM_CONSTS)}};
@@ -226,6 +267,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     c->tabs.mpflat = (const uint2*)(base + o_mp);
     c->tabs.h1flat = (const uint2*)(base + o_h1);
     c->tabs.h2flat = (const uint2*)(base + o_h2);
+    c->tabs.d1flat = (const uint2*)(base + o_d1);
+    c->tabs.d2flat = (const uint2*)(base + o_d2);
     c->tabs.fflat = (const uint2*)(base + o_f);
     c->tabs.segflat = (const uint2*)(base + o_s);
     c->tabs.data = (const uint16_t*)(base + o_data);
@@ -251,6 +294,10 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
                               blsgpu::H1_TEAM_DW * 4);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_clear, hipFuncAttributeMaxDynamicSharedMemorySize,
                               blsgpu::H2_TEAM_DW * 4);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              BLSVM_D1_SLOTS * 48);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              BLSVM_D2_SLOTS * 48);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_miller_mp, hipFuncAttributeMaxDynamicSharedMemorySize,
                               blsgpu::MP_TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_final_groups, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -625,6 +672,24 @@ BLSGPU_EXPORT int blsgpu_map_to_g2(blsgpu_ctx* c, const uint8_t* t, size_t n, ui
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, dout, n * 192, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// ------------------------------------------------------------ decompression --
+BLSGPU_EXPORT int blsgpu_g1_decompress(blsgpu_ctx* c, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+    return decompress_host<1>(c, in, n, out, ok);
+}
+BLSGPU_EXPORT int blsgpu_g2_decompress(blsgpu_ctx* c, const uint8_t* in, size_t n, uint8_t* out, uint8_t* ok) {
+    return decompress_host<2>(c, in, n, out, ok);
+}
+BLSGPU_EXPORT int blsgpu_g1_decompress_dev(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out, void* d_ok, void* stream) {
+    if (!c || (n && (!d_in || !d_out || !d_ok))) return fail(-EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return decompress_dev<1>(c, d_in, n, d_out, d_ok, (hipStream_t)stream);
+}
+BLSGPU_EXPORT int blsgpu_g2_decompress_dev(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out, void* d_ok, void* stream) {
+    if (!c || (n && (!d_in || !d_out || !d_ok))) return fail(-EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return decompress_dev<2>(c, d_in, n, d_out, d_ok, (hipStream_t)stream);
 }
 
 #ifdef BLSGPU_STAMPS

@@ -65,4 +65,68 @@ __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t*
     }
 }
 
+// ---------------------------------------------------------------------------
+// Point decompression: PublicKey.from_bytes (keys.py:28-40, DEG 1)
+// and Signature.from_bytes (signature.py:21-38, DEG 2) for a batch.  in: n x 48*DEG
+// bytes as serialised (bit 0x80 of byte 0 = "the larger y", top three bits masked as
+// `& 0x1f`); out: n x 96*DEG bytes affine (x, y) canonical big-endian; ok[i] = 1 iff
+// the reference would have accepted the encoding (it raises ValueError otherwise;
+// the point bytes are then unspecified).  Programs: vmgen/decomp_programs.py.
+template <int DEG> struct DecompCfg;
+template <> struct DecompCfg<1> {
+    static constexpr int NE = BLSVM_D1_NE, SLOTS = BLSVM_D1_SLOTS, X = BLSVM_D1_X, BIG = BLSVM_D1_BIG, OUT = BLSVM_D1_OUT,
+                         LEN = BLSVM_D1_FLAT_LEN;
+    static __device__ __forceinline__ const uint2* flat(const VmTables& T) { return T.d1flat; }
+};
+template <> struct DecompCfg<2> {
+    static constexpr int NE = BLSVM_D2_NE, SLOTS = BLSVM_D2_SLOTS, X = BLSVM_D2_X, BIG = BLSVM_D2_BIG, OUT = BLSVM_D2_OUT,
+                         LEN = BLSVM_D2_FLAT_LEN;
+    static __device__ __forceinline__ const uint2* flat(const VmTables& T) { return T.d2flat; }
+};
+
+template <int DEG>
+__global__ void __launch_bounds__(64, 2) k_decompress(VmTables T, const uint32_t* __restrict__ in, uint32_t n,
+                                                      uint32_t* __restrict__ out, uint8_t* __restrict__ ok) {
+    using C = DecompCfg<DEG>;
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t first = blockIdx.x * C::NE;
+    team_init_consts_h2c(T, team, lane);
+    wave_fence();
+    constexpr uint32_t DW_IN = 12 * DEG;                       // dwords per encoded point
+    for (uint32_t d = lane; d < C::NE * DW_IN; d += 64) {
+        const uint32_t e = d / DW_IN, o = d % DW_IN, c = o / 12, w = o % 12;
+        // points past the end decode x = 0 (any value would do; their results are dropped)
+        uint32_t v = (first + e < n) ? bswap32(in[(size_t)(first + e) * DW_IN + o]) : 0u;
+        if (o == 0) {                                          // byte 0 carries the flags
+            team[(C::BIG + e) * 12] = (v >> 31) ? 1u : 0u;     // raw 1 / 0, made Montgomery below
+            v &= 0x1FFFFFFFu;
+        }
+        team[(C::X + DEG * e + c) * 12 + (11 - w)] = v;
+    }
+    for (uint32_t d = lane; d < C::NE * 11; d += 64) team[(C::BIG + d / 11) * 12 + 1 + d % 11] = 0u;
+    wave_fence();
+    if (lane < (uint32_t)C::NE) {                              // flag -> Montgomery 0 / 1
+        const uint32_t onem[12] = BLS_ONE_MONT_LIMBS;
+        const bool big = team[(C::BIG + lane) * 12] != 0u;
+        for (int j = 0; j < 12; j++) team[(C::BIG + lane) * 12 + j] = big ? onem[j] : 0u;
+    }
+    wave_fence();
+    run_rounds(T, C::flat(T), C::LEN, 0, lane);
+    constexpr uint32_t NOUT = 2 * DEG + 1;                     // x, y coordinates and the flag
+    for (uint32_t d = lane; d < C::NE * NOUT; d += 64) {       // relaxed -> canonical residues
+        uint32_t X[12];
+        lds_load12(X, (C::OUT + d) * 3);
+        bls::fq_canon(X);
+        lds_store12(X, (C::OUT + d) * 3);
+    }
+    wave_fence();
+    constexpr uint32_t DW_OUT = 24 * DEG;
+    for (uint32_t d = lane; d < C::NE * DW_OUT; d += 64) {
+        const uint32_t e = d / DW_OUT, o = d % DW_OUT, c = o / 12, w = o % 12;
+        if (first + e < n) out[(size_t)(first + e) * DW_OUT + o] = bswap32(team[(C::OUT + NOUT * e + c) * 12 + (11 - w)]);
+    }
+    if (lane < (uint32_t)C::NE && first + lane < n) ok[first + lane] = (uint8_t)(team[(C::OUT + NOUT * lane + 2 * DEG) * 12] & 1u);
+}
+
 }  // namespace blsgpu

@@ -17,6 +17,7 @@ Layout consumed by csrc/blsgpu_kernels.hip:
 import hashlib
 import os
 
+from . import decomp_programs as DP
 from . import h2c_programs as HP
 from . import msm_programs as MP
 from . import programs as P
@@ -149,6 +150,7 @@ def limbs32(v):
 DIRECT_SEGS = ["mul_0_1", "from_mont_1_0", "to_mont_0_1", "copy_1_0"]   # called by name from the kernels
 MSM_NP = {1: 6, 2: 2}                                         # points per team in the MSM kernels
 H1_NE, H2_NM = 12, 2                                          # encodings / messages per team (hash to G2)
+D1_NE, D2_NE = 32, 16                                         # points per team (decompression)
 
 
 def build_tables(verbose=False):
@@ -165,10 +167,15 @@ def build_tables(verbose=False):
     h2segs, h2lay, h2script = HP.build_h2(H2_NM, verbose=verbose)
     segs.update(h1segs)
     segs.update(h2segs)
+    d1segs, d1lay, d1script = DP.build_d1(D1_NE, verbose=verbose)
+    d2segs, d2lay, d2script = DP.build_d2(D2_NE, verbose=verbose)
+    segs.update(d1segs)
+    segs.update(d2segs)
     order = sorted(segs)
     seg_rounds, data = pack(segs, order)
     return dict(segs=segs, mscript=mscript, fscript=fscript, mpsegs=mpsegs, mpscript=mpscript, msm=msm,
-                h1=(h1segs, h1lay, h1script), h2=(h2segs, h2lay, h2script), order=order,
+                h1=(h1segs, h1lay, h1script), h2=(h2segs, h2lay, h2script),
+                d1=(d1segs, d1lay, d1script), d2=(d2segs, d2lay, d2script), order=order,
                 seg_rounds=seg_rounds, data=data)
 
 
@@ -178,7 +185,8 @@ def generate(path=None, verbose=False):
     (h1segs, h1lay, h1script), (h2segs, h2lay, h2script) = tb["h1"], tb["h2"]
     order, seg_rounds, data = tb["order"], tb["seg_rounds"], tb["data"]
     team_slots = P.TEMP0 + max(s.ntemp for n, s in segs.items()
-                               if not n.startswith("g") and not n.startswith("mp_") and not n.startswith("h"))
+                               if not n.startswith("g") and not n.startswith("mp_") and not n.startswith("h")
+                               and not n.startswith("d1") and not n.startswith("d2"))
     mp_team_slots = max(team_slots, P.mp_temp0(P.MP_G) + max(s.ntemp for s in mpsegs.values()) - P.MP_SHIFT)
     for deg, (msegs, lay) in msm.items():
         team_slots = max(team_slots, lay.TEMP0 + max(s.ntemp for s in msegs.values()))
@@ -207,6 +215,10 @@ def generate(path=None, verbose=False):
     w("#define BLSVM_H2_NM %d\n#define BLSVM_H2_SLOTS %d\n" % (H2_NM, h2lay.TEMP0 + max(s.ntemp for s in h2segs.values())))
     w("#define BLSVM_H1_T %d\n#define BLSVM_H1_S %d\n#define BLSVM_H2_S %d\n#define BLSVM_H2_OUT %d\n" % (h1lay.T, h1lay.S, h2lay.S, h2lay.OUT))
     w("#define BLSVM_NCONST_H2C %d\n" % HP.HC_END)
+    for tag, ne, (dsegs, dlay, dscript) in (("D1", D1_NE, tb["d1"]), ("D2", D2_NE, tb["d2"])):
+        w("#define BLSVM_%s_NE %d\n#define BLSVM_%s_SLOTS %d\n" % (tag, ne, tag, dlay.TEMP0 + max(s.ntemp for s in dsegs.values())))
+        w("#define BLSVM_%s_X %d\n#define BLSVM_%s_BIG %d\n#define BLSVM_%s_OUT %d\n" % (tag, dlay.X, tag, dlay.BIG, tag, dlay.OUT))
+        flat("BLSVM_%s_FLAT" % tag, [r for n in dscript for r in seg_rounds[n]])
     flat("BLSVM_H1_FLAT", [r for n in h1script for r in seg_rounds[n]])
     flat("BLSVM_H2_FLAT", [r for n in h2script for r in seg_rounds[n]])
     flat("BLSVM_MILLER_FLAT", mflat)

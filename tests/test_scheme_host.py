@@ -33,6 +33,30 @@ def oracle_provider(oracle):
         def g2_msm(self, pts, scalars, k, groups=1):
             return self._msm(oracle.g2_msm, 192, pts, scalars, k, groups)
 
+        def g1_decompress(self, data):
+            from bls_py import hostmath as H
+            out, ok = b"", []
+            for i in range(len(data) // 48):
+                try:
+                    out += H.g1_affine_bytes(H.g1_decompress(data[48 * i:48 * (i + 1)]))
+                    ok.append(True)
+                except ValueError:
+                    out += bytes(96)
+                    ok.append(False)
+            return out, ok
+
+        def g2_decompress(self, data):
+            from bls_py import hostmath as H
+            out, ok = b"", []
+            for i in range(len(data) // 96):
+                try:
+                    out += H.g2_affine_bytes(H.g2_decompress(data[96 * i:96 * (i + 1)]))
+                    ok.append(True)
+                except ValueError:
+                    out += bytes(192)
+                    ok.append(False)
+            return out, ok
+
         def map_to_g2(self, t):
             # stand-in for the GPU map: the host integer implementation, pinned to the
             # reference by test_hash_to_curve_and_sw_encode below

@@ -24,7 +24,7 @@ def main():
     g1 = open(os.path.join(gold, "pairs_seed1_g1.bin"), "rb").read()
     g2 = open(os.path.join(gold, "pairs_seed1_g2.bin"), "rb").read()
     th = json.load(open(os.path.join(gold, "threshold.json")))["67_of_100"]
-    which = set(sys.argv[1:]) or {"c3", "c4", "c5", "h2c"}
+    which = set(sys.argv[1:]) or {"c3", "c4", "c5", "h2c", "decompress"}
 
     def up(b):
         return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
@@ -103,6 +103,20 @@ def main():
         ok = got[:192] == want0 and got[:192 * 256] * (n // 256) == got
         print(json.dumps({"config": "hash to G2 (after SHA-256): 16384 messages", "seconds": dt, "messages_per_s": n / dt,
                           "host_python_one_message_s": host_dt, "check": ok}))
+    if "decompress" in which:
+        from bls_py import hostmath as H
+        lib, h = eng.lib, eng.h
+        for deg, src, insz in ((1, g1, 48), (2, g2, 96)):
+            pts = [src[2 * insz * i:2 * insz * (i + 1)] for i in range(1024)]
+            enc = b"".join((H.g1_compress(H.g1_from_abi(p)) if deg == 1 else H.g2_compress(H.g2_from_abi(p))) for p in pts)
+            n = 1 << 16
+            tin = up(enc * (n // 1024))
+            tout = torch.zeros(n * 2 * insz, dtype=torch.uint8, device=dev)
+            tok = torch.zeros(n, dtype=torch.uint8, device=dev)
+            fn = lib.blsgpu_g1_decompress_dev if deg == 1 else lib.blsgpu_g2_decompress_dev
+            dt = timed(lambda: fn(h, tin.data_ptr(), n, tout.data_ptr(), tok.data_ptr(), 0), 3)
+            ok = bytes(tout.cpu().numpy()) == src[:2 * insz * 1024] * (n // 1024) and bool(tok.all())
+            print(json.dumps({"config": "G%d decompression, %d points" % (deg, n), "seconds": dt, "points_per_s": n / dt, "check": ok}))
 
 
 if __name__ == "__main__":
