@@ -701,6 +701,25 @@ BLSGPU_EXPORT int blsgpu_debug_stamps(blsgpu_ctx* c, unsigned long long out[9]) 
     HIP_TRY(hipMemset(c->tabs.stamps, 0, 128));
     return 0;
 }
+// diagnostic build: load a whole scratchpad image (nslots x 12 u32), run the first `nrounds`
+// rounds of flat program `which` (0 miller, 1 multi-pair, 2 final exp, 3 h1, 4 h2, 5 d1, 6 d2)
+// on one team and copy the image back -- lets tools/trace_rounds.py bisect a wrong result
+// against vmgen/tablesim.py round by round
+BLSGPU_EXPORT int blsgpu_debug_run(blsgpu_ctx* c, int which, unsigned nrounds, unsigned nslots, uint32_t* image) {
+    if (!c || !image || nslots == 0 || nslots > 1023) return fail(-EINVAL, "bad argument");
+    const uint2* seqs[7] = {c->tabs.mflat, c->tabs.mpflat, c->tabs.fflat, c->tabs.h1flat, c->tabs.h2flat, c->tabs.d1flat, c->tabs.d2flat};
+    if (which < 0 || which > 6) return fail(-EINVAL, "bad program");
+    uint32_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)nslots * 48));
+    HIP_TRY(hipMemcpy(d, image, (size_t)nslots * 48, hipMemcpyHostToDevice));
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_debug_run, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nslots * 48);
+    hipLaunchKernelGGL(blsgpu::k_debug_run, dim3(1), dim3(64), (size_t)nslots * 48, 0, c->tabs, seqs[which], nrounds, nslots, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(image, d, (size_t)nslots * 48, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+}
 #endif
 
 }  // extern "C"

@@ -129,4 +129,17 @@ __global__ void __launch_bounds__(64, 2) k_decompress(VmTables T, const uint32_t
     if (lane < (uint32_t)C::NE && first + lane < n) ok[first + lane] = (uint8_t)(team[(C::OUT + NOUT * lane + 2 * DEG) * 12] & 1u);
 }
 
+#ifdef BLSGPU_STAMPS
+// diagnostic build only: see blsgpu_debug_run
+__global__ void __launch_bounds__(64) k_debug_run(VmTables T, const uint2* seq, uint32_t nrounds, uint32_t nslots, uint32_t* image) {
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = lane; i < nslots * 12; i += 64) team[i] = image[i];
+    wave_fence();
+    run_rounds(T, seq, nrounds, 0, lane);
+    wave_fence();
+    for (uint32_t i = lane; i < nslots * 12; i += 64) image[i] = team[i];
+}
+#endif
+
 }  // namespace blsgpu

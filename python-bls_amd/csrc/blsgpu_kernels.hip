@@ -212,19 +212,23 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
 #else
 #define BLSGPU_SLOTMASK 1023u
 #endif
-            if (K > 0) lds_load12(S[0], base16 + (BLSGPU_UOP(0) & BLSGPU_SLOTMASK) * 3u);
+            // K >= 1 (emit.py).  The loop leaves through `break`, so every use of an
+            // operand buffer is dominated by its load (no register shuffling between
+            // steps); the look-ahead load past the last micro-op reads slot 0.
+            lds_load12(S[0], base16 + (BLSGPU_UOP(0) & BLSGPU_SLOTMASK) * 3u);
 #pragma unroll
             for (int p = 0; p < 4 * LIN_CHUNKS - 2; p++) {
-                if ((uint32_t)p < K) {
-                    if (p + 1 < 4 * LIN_CHUNKS - 2 && (uint32_t)(p + 1) < K)
-                        lds_load12(S[(p + 1) & 1], base16 + (BLSGPU_UOP(p + 1) & BLSGPU_SLOTMASK) * 3u);
-                    const uint32_t u = BLSGPU_UOP(p);
-#if defined(BLSGPU_EXP) && (BLSGPU_EXP & 16)
-                    for (int j = 0; j < 12; j++) acc[j] ^= S[p & 1][j];          // timing experiment only
-#else
-                    bls::fat_mac(acc, S[p & 1], (u >> 10) & 31u, (uint32_t)((int32_t)(u << 16) >> 31));
-#endif
+                if (p + 1 < 4 * LIN_CHUNKS - 2) {
+                    const uint32_t live = ((uint32_t)(p + 1) < K) ? BLSGPU_SLOTMASK : 0u;
+                    lds_load12(S[(p + 1) & 1], base16 + (BLSGPU_UOP(p + 1) & live) * 3u);
                 }
+                const uint32_t u = BLSGPU_UOP(p);
+#if defined(BLSGPU_EXP) && (BLSGPU_EXP & 16)
+                for (int j = 0; j < 12; j++) acc[j] ^= S[p & 1][j];          // timing experiment only
+#else
+                bls::fat_mac(acc, S[p & 1], (u >> 10) & 31u, (uint32_t)((int32_t)(u << 16) >> 31));
+#endif
+                if ((uint32_t)(p + 1) >= K) break;
             }
 #undef BLSGPU_UOP
             const uint32_t w1 = ch[0].x >> 16;               // N | absorb1 << 14 | absorb2 << 15
