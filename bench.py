@@ -238,8 +238,11 @@ def main():
                          "hbm_peak_GBps": PEAK_HBM_GBS},
             "single_verification": {"pairs": n, "latency_ms": min(one_ms), "pairings_per_s": n / (min(one_ms) * 1e-3)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             cb, cpu_out = cpu_baseline(mine[0][0], mine[0][1], n)
+            if cpu_out != per[0]:
+                raise SystemExit("CPU oracle and GPU disagree -- bench invalid")
+            cb["matches_gpu"] = True
             line["cpu_baseline"] = cb
         print(json.dumps(line))
     if dist:
