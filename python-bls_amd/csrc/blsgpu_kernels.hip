@@ -42,7 +42,7 @@ struct VmTables {
     unsigned long long* stamps;   // diagnostic builds only (-DBLSGPU_STAMPS), else unused
 };
 
-constexpr int LIN_CHUNKS = 6;                           // a LIN record holds <= 22 micro-ops
+constexpr int LIN_CHUNKS = 8;                           // a LIN record holds <= 30 micro-ops
 static_assert(BLSVM_MAX_LIN_K <= 4 * LIN_CHUNKS - 2, "LIN record too long");
 constexpr int TEAM_DW = BLSVM_TEAM_SLOTS * 12;           // dwords per team
 constexpr int TEAM_BYTES = TEAM_DW * 4;

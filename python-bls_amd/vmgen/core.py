@@ -148,7 +148,7 @@ class Builder:
 
 # ---------------------------------------------------------------------------
 MAX_COEF = 31          # a micro-op adds coef * x, x = slot or its 384-bit complement
-MAX_LIN_MAG = 120      # sum of |coefficients| per linear combination
+MAX_LIN_MAG = 160      # sum of |coefficients| per linear combination
 K1_SLOT = None         # set by programs.py: slot holding -(2^384 - 1) mod q
 
 

@@ -445,17 +445,25 @@ def final_exp_script():
 
 
 # ------------------------------------------------------------- build all ----
+def lazy_cfg(cfg):
+    """Fq2 products left unmaterialised: their post-additions are folded into the next
+    LIN level (fewer, longer LIN rounds -- the emitter splits long ones over lanes).
+    Costs a few more live temporaries, so the rare chord-step bodies keep cfg."""
+    return tw.Cfg(m2=cfg.m2, s2=cfg.s2, mat2=False)
+
+
 def build_all(cfg=None, verbose=False):
     """Returns (segments by name, miller script, final-exp script)."""
     cfg = cfg or tw.Cfg()
+    lazy = lazy_cfg(cfg)
     mscript, first_add = miller_script()
-    builders = [seg_init(cfg, first_add)]
+    builders = [seg_init(lazy, first_add)]
     for name in sorted(set(mscript[1:])):
-        builders.append(seg_body(cfg, int(name[5]), int(name[6])))
+        builders.append(seg_body(lazy, int(name[5]), int(name[6])))
     fscript = final_exp_script()
     extra = ["from_mont_1_0", "to_mont_0_1", "to_mont_1_1", "set_one_0", "mul_0_1", "copy_0_1", "copy_1_0"]
     for name in sorted(set(fscript + extra)):
-        builders.append(seg_by_name(cfg, name))
+        builders.append(seg_by_name(lazy if name.startswith("mul_") else cfg, name))
     segs = {}
     for b in builders:
         segs[b.name] = schedule(b, temp_base=TEMP0, verbose=verbose)
@@ -466,10 +474,12 @@ def build_multi(cfg=None, G=MP_G, verbose=False):
     """Miller-loop programs for G pairs per team sharing one accumulator:
     returns (segments by name, script)."""
     cfg = cfg or tw.Cfg()
+    lazy = lazy_cfg(cfg)
     script, first_add = miller_script("mp_init", "mp_body")
-    builders = [seg_init(cfg, first_add, G, "mp_init")]
+    builders = [seg_init(lazy, first_add, G, "mp_init")]
     for name in sorted(set(script[1:])):
-        builders.append(seg_body(cfg, int(name[-2]), int(name[-1]), G, "mp_body"))
+        cur_add, nxt = int(name[-2]), int(name[-1])
+        builders.append(seg_body(lazy if (cur_add, nxt) in ((0, 0), (0, 2)) else cfg, cur_add, nxt, G, "mp_body"))
     segs = {}
     for b in builders:
         segs[b.name] = schedule(b, temp_base=mp_temp0(G), verbose=verbose)
