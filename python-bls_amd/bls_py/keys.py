@@ -6,7 +6,7 @@ from random import SystemRandom
 from . import hostmath as H
 from .aggregation_info import AggregationInfo
 from .bls12381 import n as GROUP_ORDER
-from .ec import (JacobianPoint, default_ec, generator_Fq, hash_to_point_Fq2,
+from .ec import (JacobianPoint, default_ec, default_ec_twist, generator_Fq, hash_to_point_Fq2,
                  hash_to_point_prehashed_Fq2)
 from .fields import Fq
 from .signature import Signature
@@ -107,6 +107,36 @@ class PrivateKey:
     def sign(self, m):
         r = hash_to_point_Fq2(m).to_jacobian()
         return Signature.from_g2(self.value * r, AggregationInfo.from_msg(self.get_public_key(), m))
+
+    @staticmethod
+    def sign_batch(private_keys, messages):
+        """[sk.sign(m) for sk, m in zip(private_keys, messages)] with the three heavy steps
+        batched on the GPU: public keys sk*G1 (one group sum per key), H(m) (hash to G2)
+        and sk*H(m) (one G2 group sum per message).  Same objects as keys.py:123-126 builds."""
+        from . import backend
+        from .ec import hash_to_points_prehashed_Fq2
+        from .util import hash256
+        sks = list(private_keys)
+        hashes = [hash256(m) for m in messages]
+        if len(sks) != len(hashes):
+            raise ValueError("one message per key")
+        if not sks:
+            return []
+        n = len(sks)
+        prov = backend.get()
+        g1 = H.g1_affine_bytes(H.G1_GEN)
+        pk_bytes, pk_inf = prov.g1_msm(g1 * n, [sk.value for sk in sks], 1, n)
+        Hm = hash_to_points_prehashed_Fq2(hashes)
+        pts = b"".join(H.g2_affine_bytes(q._aff()) for q in Hm)
+        sig_bytes, sig_inf = prov.g2_msm(pts, [sk.value for sk in sks], 1, n)
+        out = []
+        for i in range(n):
+            pk = PublicKey.from_g1(JacobianPoint._from(
+                H.F1, None if pk_inf[i] else H.aff_to_jac(H.F1, H.g1_from_abi(pk_bytes[96 * i:96 * (i + 1)])), default_ec))
+            sig = JacobianPoint._from(
+                H.F2, None if sig_inf[i] else H.aff_to_jac(H.F2, H.g2_from_abi(sig_bytes[192 * i:192 * (i + 1)])), default_ec_twist)
+            out.append(Signature.from_g2(sig, AggregationInfo.from_msg_hash(pk, hashes[i])))
+        return out
 
     def sign_prehashed(self, h):
         r = hash_to_point_prehashed_Fq2(h).to_jacobian()

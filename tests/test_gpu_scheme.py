@@ -69,6 +69,32 @@ def test_sign_aggregate_verify_batch_C2():
     assert BLS.verify(forged) is False
 
 
+def test_sign_aggregate_verify_full_C2():
+    """BASELINE configs[1] at full size: 1024 (sk, msg) signed with the batched GPU
+    helper (checked against the per-key host path on a sample), aggregated, verified =
+    1025 pairings + 1024 hashes to G2 + 1024 key foldings on the GPU; a flipped message fails."""
+    import hashlib
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    n = 1024
+    order = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    sks = [PrivateKey(int.from_bytes(hashlib.sha256(b"blsgpu/a" + (1).to_bytes(4, "big") + i.to_bytes(4, "big")).digest(), "big")
+                      % (order - 1) + 1) for i in range(n)]
+    msgs = [i.to_bytes(4, "big") for i in range(n)]
+    sigs = PrivateKey.sign_batch(sks, msgs)
+    for i in (0, 511, 1023):
+        one = sks[i].sign(msgs[i])
+        assert one.serialize() == sigs[i].serialize()
+        assert one.aggregation_info.public_keys[0].serialize() == sigs[i].aggregation_info.public_keys[0].serialize()
+    agg = BLS.aggregate_sigs(sigs)
+    assert len(agg.aggregation_info.public_keys) == n
+    assert BLS.verify(agg) is True
+    sigs[7] = sks[7].sign(b"\xff\xff\xff\xff")
+    forged = BLS.aggregate_sigs_simple(sigs)
+    forged.set_aggregation_info(agg.aggregation_info)
+    assert BLS.verify(forged) is False
+
+
 def test_threshold_combine_and_verify_C4(golden):
     from bls_py.aggregation_info import AggregationInfo
     from bls_py.bls import BLS
