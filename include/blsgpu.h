@@ -127,6 +127,13 @@ int blsgpu_g2_msm_dev(blsgpu_ctx *ctx, const void *d_pts, const void *d_scalars,
 int blsgpu_map_to_g2(blsgpu_ctx *ctx, const uint8_t *t, size_t n, uint8_t *out);
 int blsgpu_map_to_g2_dev(blsgpu_ctx *ctx, const void *d_t, size_t n, void *d_out, void *stream);
 
+/* The whole hash_to_point_prehashed_Fq2(m) (ec.py:528-550) for n 32-byte messages m
+ * (the message hashes of AggregationInfo, bls.py:194-195): the four hash512 values
+ * (util.py:13-16, SHA-256 on the GPU) reduced mod q, then as blsgpu_map_to_g2.
+ * msg_hashes: n x 32 bytes; out: n x 192 bytes affine G2. */
+int blsgpu_hash_to_g2(blsgpu_ctx *ctx, const uint8_t *msg_hashes, size_t n, uint8_t *out);
+int blsgpu_hash_to_g2_dev(blsgpu_ctx *ctx, const void *d_msg_hashes, size_t n, void *d_out, void *stream);
+
 /* Batched point decompression: PublicKey.from_bytes (keys.py:28-40) and
  * Signature.from_bytes (signature.py:21-38) from the serialised bytes: mask the top
  * three bits (`& 0x1f`), y_for_x (ec.py:255-269; square roots fields.py:199-205 and

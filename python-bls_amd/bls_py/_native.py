@@ -21,6 +21,7 @@ SYMBOLS = (
     "blsgpu_map_to_g2", "blsgpu_map_to_g2_dev",
     "blsgpu_miller_product_batch_dev", "blsgpu_final_exp_product_batch_dev",
     "blsgpu_g1_decompress", "blsgpu_g2_decompress", "blsgpu_g1_decompress_dev", "blsgpu_g2_decompress_dev",
+    "blsgpu_hash_to_g2", "blsgpu_hash_to_g2_dev",
 )
 
 _lib = None
@@ -77,6 +78,8 @@ def load_library(path=None):
         L.blsgpu_g2_decompress.argtypes = [vp, cp, sz, cp, cp]
         L.blsgpu_g1_decompress_dev.argtypes = [vp, vp, sz, vp, vp, vp]
         L.blsgpu_g2_decompress_dev.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.blsgpu_hash_to_g2.argtypes = [vp, cp, sz, cp]
+        L.blsgpu_hash_to_g2_dev.argtypes = [vp, vp, sz, vp, vp]
         L.blsgpu_map_to_g2.argtypes = [vp, cp, sz, cp]
         L.blsgpu_map_to_g2_dev.argtypes = [vp, vp, sz, vp, vp]
         L.blsgpu_timing_enable.argtypes = [vp, ctypes.c_int]
@@ -169,6 +172,14 @@ class Engine:
     def g2_decompress(self, data: bytes):
         """n x 96 bytes -> (n x 192 bytes affine, [accepted])."""
         return self._decompress(self.lib.blsgpu_g2_decompress, "blsgpu_g2_decompress", 96, data)
+
+    def hash_to_g2(self, msg_hashes: bytes) -> bytes:
+        """n x 32-byte message hashes -> n x 192 bytes affine G2 (SHA-256 chain on the GPU too)."""
+        if len(msg_hashes) % 32:
+            raise ValueError("need n x 32 bytes")
+        out = ctypes.create_string_buffer(max(1, 6 * len(msg_hashes)))
+        self._check(self.lib.blsgpu_hash_to_g2(self.h, msg_hashes, len(msg_hashes) // 32, out), "blsgpu_hash_to_g2")
+        return out.raw[:6 * len(msg_hashes)]
 
     def map_to_g2(self, t: bytes) -> bytes:
         """t: n x 192 bytes (t0.c0, t0.c1, t1.c0, t1.c1) -> n x 192 bytes affine G2."""

@@ -28,6 +28,9 @@ class HipProvider:
     def map_to_g2(self, t: bytes) -> bytes:
         return self._eng.map_to_g2(t)
 
+    def hash_to_g2(self, msg_hashes: bytes) -> bytes:
+        return self._eng.hash_to_g2(msg_hashes)
+
     def g1_decompress(self, data: bytes):
         return self._eng.g1_decompress(data)
 

@@ -212,7 +212,11 @@ def hash_to_points_prehashed_Fq2(ms, ec=default_ec_twist):
     ms = [_as_bytes(m) for m in ms]
     if not ms:
         return []
-    out = backend.get().map_to_g2(b"".join(H.g2_hash_field_elements(m, hash512) for m in ms))
+    prov = backend.get()
+    if all(len(m) == 32 for m in ms) and hasattr(prov, "hash_to_g2"):
+        out = prov.hash_to_g2(b"".join(ms))                 # 32-byte message hashes: SHA-256 chain on the GPU too
+    else:
+        out = prov.map_to_g2(b"".join(H.g2_hash_field_elements(m, hash512) for m in ms))
     return [AffinePoint._from(H.F2, H.g2_from_abi(out[192 * i:192 * (i + 1)]), ec) for i in range(len(ms))]
 
 

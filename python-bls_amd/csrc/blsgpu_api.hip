@@ -236,7 +236,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     size_t o_m = 0;
     size_t o_mp = o_m + al(sizeof(BLSVM_MILLER_FLAT));
     size_t o_h1 = o_mp + al(sizeof(BLSVM_MP_FLAT));
-    size_t o_h2 = o_h1 + al(sizeof(BLSVM_H1_FLAT));
+    size_t o_h1w = o_h1 + al(sizeof(BLSVM_H1_FLAT));
+    size_t o_h2 = o_h1w + al(sizeof(BLSVM_H1W_FLAT));
     size_t o_d1 = o_h2 + al(sizeof(BLSVM_H2_FLAT));
     size_t o_d2 = o_d1 + al(sizeof(BLSVM_D1_FLAT));
     size_t o_f = o_d2 + al(sizeof(BLSVM_D2_FLAT));
@@ -251,7 +252,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     char* base = (char*)c->d_tables;
     struct { size_t off; const void* src; size_t len; } parts[] = {
         {o_m, BLSVM_MILLER_FLAT, sizeof(BLSVM_MILLER_FLAT)}, {o_mp, BLSVM_MP_FLAT, sizeof(BLSVM_MP_FLAT)},
-        {o_h1, BLSVM_H1_FLAT, sizeof(BLSVM_H1_FLAT)},        {o_h2, BLSVM_H2_FLAT, sizeof(BLSVM_H2_FLAT)},
+        {o_h1, BLSVM_H1_FLAT, sizeof(BLSVM_H1_FLAT)},        {o_h1w, BLSVM_H1W_FLAT, sizeof(BLSVM_H1W_FLAT)},        {o_h2, BLSVM_H2_FLAT, sizeof(BLSVM_H2_FLAT)},
         {o_d1, BLSVM_D1_FLAT, sizeof(BLSVM_D1_FLAT)},        {o_d2, BLSVM_D2_FLAT, sizeof(BLSVM_D2_FLAT)},
         {o_f, BLSVM_FEXP_FLAT, sizeof(BLSVM_FEXP_FLAT)},
         {o_s, BLSVM_SEG_FLAT, sizeof(BLSVM_SEG_FLAT)},       {o_data, BLSVM_DATA, sizeof(BLSVM_DATA)},
@@ -266,6 +267,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     c->tabs.mflat = (const uint2*)(base + o_m);
     c->tabs.mpflat = (const uint2*)(base + o_mp);
     c->tabs.h1flat = (const uint2*)(base + o_h1);
+    c->tabs.h1wflat = (const uint2*)(base + o_h1w);
     c->tabs.h2flat = (const uint2*)(base + o_h2);
     c->tabs.d1flat = (const uint2*)(base + o_d1);
     c->tabs.d2flat = (const uint2*)(base + o_d2);
@@ -290,7 +292,9 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
                               MILLER_WAVES * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize,
                               REDUCE_WAVES * blsgpu::TEAM_BYTES);
-    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_encode, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_encode<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              blsgpu::H1_TEAM_DW * 4);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_encode<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               blsgpu::H1_TEAM_DW * 4);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_clear, hipFuncAttributeMaxDynamicSharedMemorySize,
                               blsgpu::H2_TEAM_DW * 4);
@@ -628,13 +632,11 @@ BLSGPU_EXPORT int blsgpu_g2_msm_dev(blsgpu_ctx* c, const void* d_pts, const void
 // ------------------------------------------------------------ hash to G2 -----
 // t: n x 192 bytes = (t0.c0, t0.c1, t1.c0, t1.c1) canonical big-endian, the four
 // hash512 values of ec.py:531-534 reduced mod q; out: n x 192 bytes affine G2.
-BLSGPU_EXPORT int blsgpu_map_to_g2_dev(blsgpu_ctx* c, const void* d_t, size_t n, void* d_out, void* stream) {
-    if (!c || (n && (!d_t || !d_out))) return fail(-EINVAL, "NULL argument");
+// wide = 0: d_in = t values (n x 192 bytes); wide = 1: d_in = message hashes (n x 32 bytes)
+static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out, hipStream_t st, bool from_hashes) {
     if (n == 0) return 0;
-    if (n > 0x3FFFFFF0ull) return fail(-EINVAL, "batch too large");
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
-    size_t need = 2 * n * 60;                       // Montgomery (x, y, z.c0) per encoding, u32
+    if (n > 0x0FFFFFF0ull) return fail(-EINVAL, "batch too large");
+    size_t need = 2 * n * 60 + (from_hashes ? n * 64 : 0);     // encodings (+ digests), u32
     if (need > c->msm_part_cap) {
         if (c->d_msm_part) (void)hipFree(c->d_msm_part);
         c->d_msm_part = nullptr;
@@ -642,14 +644,58 @@ BLSGPU_EXPORT int blsgpu_map_to_g2_dev(blsgpu_ctx* c, const void* d_t, size_t n,
         HIP_TRY(hipMalloc((void**)&c->d_msm_part, need * sizeof(uint32_t)));
         c->msm_part_cap = need;
     }
+    uint32_t* d_enc = c->d_msm_part;
     unsigned b1 = (unsigned)((2 * n + BLSVM_H1_NE - 1) / BLSVM_H1_NE);
-    hipLaunchKernelGGL(blsgpu::k_h2c_encode, dim3(b1), dim3(64), (size_t)blsgpu::H1_TEAM_DW * 4, st, c->tabs,
-                       (const uint32_t*)d_t, (uint32_t)(2 * n), c->d_msm_part);
+    if (from_hashes) {
+        uint32_t* d_dig = c->d_msm_part + 2 * n * 60;
+        hipLaunchKernelGGL(blsgpu::k_h2c_hash, dim3((unsigned)((8 * n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_in,
+                           (uint32_t)n, d_dig);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(blsgpu::k_h2c_encode<1>, dim3(b1), dim3(64), (size_t)blsgpu::H1_TEAM_DW * 4, st, c->tabs,
+                           (const uint32_t*)d_dig, (uint32_t)(2 * n), d_enc);
+    } else {
+        hipLaunchKernelGGL(blsgpu::k_h2c_encode<0>, dim3(b1), dim3(64), (size_t)blsgpu::H1_TEAM_DW * 4, st, c->tabs,
+                           (const uint32_t*)d_in, (uint32_t)(2 * n), d_enc);
+    }
     HIP_TRY(hipGetLastError());
     unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);
-    hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs,
-                       c->d_msm_part, (uint32_t)n, (uint32_t*)d_out);
+    hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, d_enc, (uint32_t)n,
+                       (uint32_t*)d_out);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+BLSGPU_EXPORT int blsgpu_map_to_g2_dev(blsgpu_ctx* c, const void* d_t, size_t n, void* d_out, void* stream) {
+    if (!c || (n && (!d_t || !d_out))) return fail(-EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return map_to_g2_impl(c, d_t, n, d_out, (hipStream_t)stream, false);
+}
+
+// The whole hash_to_point_prehashed_Fq2 (ec.py:528-550) for 32-byte message hashes.
+BLSGPU_EXPORT int blsgpu_hash_to_g2_dev(blsgpu_ctx* c, const void* d_msg_hashes, size_t n, void* d_out, void* stream) {
+    if (!c || (n && (!d_msg_hashes || !d_out))) return fail(-EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return map_to_g2_impl(c, d_msg_hashes, n, d_out, (hipStream_t)stream, true);
+}
+
+BLSGPU_EXPORT int blsgpu_hash_to_g2(blsgpu_ctx* c, const uint8_t* msg_hashes, size_t n, uint8_t* out) {
+    if (!c || (n && (!msg_hashes || !out))) return fail(-EINVAL, "NULL argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t need = n * (32 + 192) + 64;
+    if (need > c->io_cap) {
+        if (c->d_io) (void)hipFree(c->d_io);
+        c->d_io = nullptr;
+        c->io_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_io, need));
+        c->io_cap = need;
+    }
+    char* din = (char*)c->d_io;
+    char* dout = din + ((n * 32 + 63) & ~(size_t)63);
+    HIP_TRY(hipMemcpy(din, msg_hashes, n * 32, hipMemcpyHostToDevice));
+    int rc = map_to_g2_impl(c, din, n, dout, nullptr, true);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, dout, n * 192, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -15,22 +15,98 @@ __device__ __forceinline__ void team_init_consts_h2c(const VmTables& T, uint32_t
     for (uint32_t i = lane; i < BLSVM_NCONST_H2C * 12; i += 64) team[i] = T.consts[i];
 }
 
-// Kernel H1: one team = BLSVM_H1_NE encodings.  t: n_enc x 96 bytes (c0 || c1,
-// big-endian canonical); out: n_enc x 60 u32 = (x, y, z.c0) in Montgomery limbs, z = 0 for infinity.
+// SHA-256 (FIPS 180-4) of one 40-byte message = one block, for the hash512 chain of
+// ec.py:531-534 / util.py:7-16:  hash512(m) = sha256(m || 00) || sha256(m || 01) with
+// m = message hash (32 bytes) || "G2_j_ck" (7 bytes).
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__device__ void sha256_block(const uint32_t w_in[16], uint32_t out[8]) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+        0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+        0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+        0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+        0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = w_in[i];
+#pragma unroll
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        uint32_t s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = 0x6a09e667, b = 0xbb67ae85, c = 0x3c6ef372, d = 0xa54ff53a, e = 0x510e527f, f = 0x9b05688c, g = 0x1f83d9ab,
+             hh = 0x5be0cd19;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = hh + S1 + ch + K[i] + w[i];
+        uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    out[0] = a + 0x6a09e667; out[1] = b + 0xbb67ae85; out[2] = c + 0x3c6ef372; out[3] = d + 0xa54ff53a;
+    out[4] = e + 0x510e527f; out[5] = f + 0x9b05688c; out[6] = g + 0x1f83d9ab; out[7] = hh + 0x5be0cd19;
+}
+
+// One thread per SHA-256: thread t of message i computes half (t & 1) of hash512 number
+// (t >> 1) in {G2_0_c0, G2_0_c1, G2_1_c0, G2_1_c1}.  msg: n x 32 bytes; digests:
+// n x 4 x 64 bytes, the big-endian 512-bit values of ec.py:531-534 before `% q`.
+__global__ void __launch_bounds__(256) k_h2c_hash(const uint32_t* __restrict__ msg, uint32_t n, uint32_t* __restrict__ digests) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 3, t = gid & 7u;
+    if (i >= n) return;
+    const uint32_t j = t >> 2, c = (t >> 1) & 1u, half = t & 1u;
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = bswap32(msg[(size_t)i * 8 + k]);
+    // "G2_" j "_c" c  then the hash512 selector byte, then the 0x80 padding byte
+    w[8] = 0x47325F00u | (0x30u + j);                       // 'G' '2' '_' ('0' + j)
+    w[9] = 0x5F630000u | ((0x30u + c) << 8) | half;         // '_' 'c' ('0' + c) selector
+    w[10] = 0x80000000u;
+    w[11] = 0; w[12] = 0; w[13] = 0; w[14] = 0;
+    w[15] = 320;                                            // message length in bits
+    uint32_t d[8];
+    sha256_block(w, d);
+#pragma unroll
+    for (int k = 0; k < 8; k++) digests[((size_t)i * 4 + (t >> 1)) * 16 + half * 8 + k] = bswap32(d[k]);
+}
+
+// Kernel H1: one team = BLSVM_H1_NE encodings.  WIDE = 0: t is n_enc x 96 bytes (c0 || c1,
+// big-endian, < 2^384); WIDE = 1: t is n_enc x 128 bytes (two 512-bit big-endian hash
+// values, reduced mod q here).  out: n_enc x 60 u32 = (x, y, z.c0) in Montgomery limbs,
+// z = 0 for infinity.
+template <int WIDE>
 __global__ void __launch_bounds__(64, 2) k_h2c_encode(VmTables T, const uint32_t* __restrict__ t, uint32_t n_enc,
                                                       uint32_t* __restrict__ out) {
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t first = blockIdx.x * BLSVM_H1_NE;
     team_init_consts_h2c(T, team, lane);
-    for (uint32_t d = lane; d < BLSVM_H1_NE * 24; d += 64) {
-        uint32_t e = d / 24, o = d % 24, c = o / 12, w = o % 12;
-        // encodings past the end run on t = (1, 0); their results are dropped
-        uint32_t v = (first + e < n_enc) ? bswap32(t[(size_t)(first + e) * 24 + o]) : ((c == 0 && w == 11) ? 1u : 0u);
-        team[(BLSVM_H1_T + 2 * e + c) * 12 + (11 - w)] = v;
+    if (WIDE) {
+        for (uint32_t d = lane; d < BLSVM_H1_NE * 24; d += 64) team[BLSVM_H1_TH * 12 + d] = 0u;
+        wave_fence();
+        for (uint32_t d = lane; d < BLSVM_H1_NE * 32; d += 64) {
+            const uint32_t e = d / 32, o = d % 32, c = o / 16, w = o % 16;     // dword w of the 64-byte value, MSB first
+            // encodings past the end run on t = (1, 0); their results are dropped
+            uint32_t v = (first + e < n_enc) ? bswap32(t[(size_t)(first + e) * 32 + o]) : ((c == 0 && w == 15) ? 1u : 0u);
+            if (w < 4) team[(BLSVM_H1_TH + 2 * e + c) * 12 + (3 - w)] = v;     // bits 384..511
+            else team[(BLSVM_H1_T + 2 * e + c) * 12 + (15 - w)] = v;           // bits 0..383
+        }
+    } else {
+        for (uint32_t d = lane; d < BLSVM_H1_NE * 24; d += 64) {
+            uint32_t e = d / 24, o = d % 24, c = o / 12, w = o % 12;
+            uint32_t v = (first + e < n_enc) ? bswap32(t[(size_t)(first + e) * 24 + o]) : ((c == 0 && w == 11) ? 1u : 0u);
+            team[(BLSVM_H1_T + 2 * e + c) * 12 + (11 - w)] = v;
+        }
     }
     wave_fence();
-    run_rounds(T, T.h1flat, BLSVM_H1_FLAT_LEN, 0, lane);
+    if (WIDE) run_rounds(T, T.h1wflat, BLSVM_H1W_FLAT_LEN, 0, lane);
+    else run_rounds(T, T.h1flat, BLSVM_H1_FLAT_LEN, 0, lane);
     for (uint32_t d = lane; d < BLSVM_H1_NE * 60; d += 64) {
         uint32_t e = d / 60;
         if (first + e < n_enc) out[(size_t)first * 60 + d] = team[BLSVM_H1_S * 12 + d];

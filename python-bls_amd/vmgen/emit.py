@@ -164,6 +164,9 @@ def build_tables(verbose=False):
         msm[deg] = (msegs, lay)
         segs.update(msegs)
     h1segs, h1lay, h1script = HP.build_h1(H1_NE, verbose=verbose)
+    h1wsegs, _, h1wscript = HP.build_h1(H1_NE, verbose=verbose, wide=True)
+    segs["h1w_a"] = h1wsegs["h1w_a"]
+    h1segs = dict(h1segs, h1w_a=h1wsegs["h1w_a"])
     h2segs, h2lay, h2script = HP.build_h2(H2_NM, verbose=verbose)
     segs.update(h1segs)
     segs.update(h2segs)
@@ -174,7 +177,7 @@ def build_tables(verbose=False):
     order = sorted(segs)
     seg_rounds, data = pack(segs, order)
     return dict(segs=segs, mscript=mscript, fscript=fscript, mpsegs=mpsegs, mpscript=mpscript, msm=msm,
-                h1=(h1segs, h1lay, h1script), h2=(h2segs, h2lay, h2script),
+                h1=(h1segs, h1lay, h1script), h1w=(h1segs, h1lay, h1wscript), h2=(h2segs, h2lay, h2script),
                 d1=(d1segs, d1lay, d1script), d2=(d2segs, d2lay, d2script), order=order,
                 seg_rounds=seg_rounds, data=data)
 
@@ -213,13 +216,14 @@ def generate(path=None, verbose=False):
     flat("BLSVM_MP_FLAT", [r for n in mpscript for r in seg_rounds[n]])
     w("#define BLSVM_H1_NE %d\n#define BLSVM_H1_SLOTS %d\n" % (H1_NE, h1lay.TEMP0 + max(s.ntemp for s in h1segs.values())))
     w("#define BLSVM_H2_NM %d\n#define BLSVM_H2_SLOTS %d\n" % (H2_NM, h2lay.TEMP0 + max(s.ntemp for s in h2segs.values())))
-    w("#define BLSVM_H1_T %d\n#define BLSVM_H1_S %d\n#define BLSVM_H2_S %d\n#define BLSVM_H2_OUT %d\n" % (h1lay.T, h1lay.S, h2lay.S, h2lay.OUT))
+    w("#define BLSVM_H1_T %d\n#define BLSVM_H1_TH %d\n#define BLSVM_H1_S %d\n#define BLSVM_H2_S %d\n#define BLSVM_H2_OUT %d\n" % (h1lay.T, h1lay.TH, h1lay.S, h2lay.S, h2lay.OUT))
     w("#define BLSVM_NCONST_H2C %d\n" % HP.HC_END)
     for tag, ne, (dsegs, dlay, dscript) in (("D1", D1_NE, tb["d1"]), ("D2", D2_NE, tb["d2"])):
         w("#define BLSVM_%s_NE %d\n#define BLSVM_%s_SLOTS %d\n" % (tag, ne, tag, dlay.TEMP0 + max(s.ntemp for s in dsegs.values())))
         w("#define BLSVM_%s_X %d\n#define BLSVM_%s_BIG %d\n#define BLSVM_%s_OUT %d\n" % (tag, dlay.X, tag, dlay.BIG, tag, dlay.OUT))
         flat("BLSVM_%s_FLAT" % tag, [r for n in dscript for r in seg_rounds[n]])
     flat("BLSVM_H1_FLAT", [r for n in h1script for r in seg_rounds[n]])
+    flat("BLSVM_H1W_FLAT", [r for n in tb["h1w"][2] for r in seg_rounds[n]])
     flat("BLSVM_H2_FLAT", [r for n in h2script for r in seg_rounds[n]])
     flat("BLSVM_MILLER_FLAT", mflat)
     flat("BLSVM_FEXP_FLAT", fflat)

@@ -37,7 +37,8 @@ assert (SQRT_N3 * SQRT_N3 + 3) % Q == 0 and (2 * SQRT_N3M1O2 + 1 - SQRT_N3) % Q 
 # extra constants, placed right after the shared constant slots
 HC_S3, HC_H, HC_SINV, HC_INV2 = NCONST, NCONST + 1, NCONST + 2, NCONST + 3
 HC_PSIX, HC_PSIY = NCONST + 4, NCONST + 6           # Fq2 each
-HC_END = NCONST + 8
+HC_R3 = NCONST + 8                                  # content R^3: raw x -> x R^2 (the 2^384 place of a wide input)
+HC_END = NCONST + 9
 EXP_E = (Q - 3) // 4                                  # n^E: sqrt candidate n^E n, symbol n^E (n^E n)
 
 
@@ -49,7 +50,7 @@ def h2c_const_table():
         return (a[0] * f % Q, -a[1] * f % Q)
     px, py = inv2(g2), inv2(g3)                       # w^(2-2q), w^(3-3q)  (ec.py:440-444)
     vals = [SQRT_N3, SQRT_N3M1O2, pow(SQRT_N3, Q - 2, Q), pow(2, Q - 2, Q), px[0], px[1], py[0], py[1]]
-    return [to_m(v) for v in vals]
+    return [to_m(v) for v in vals] + [pow(1 << 384, 3, Q)]
 
 
 class H1Layout:
@@ -59,6 +60,7 @@ class H1Layout:
         self.NE = NE
         o = HC_END
         self.T = o; o += 2 * NE            # raw t (c0, c1), later Montgomery
+        self.TH = o; o += 2 * NE           # wide inputs: bits 384.. of the 512-bit hash value
         self.PAR = o; o += NE              # parity flag of t
         self.X = o; o += 6 * NE            # x1, x2, x3 (Fq2 each); later X[0:2] = chosen x
         self.U = o; o += 6 * NE            # u_i = x_i^3 + b
@@ -94,7 +96,10 @@ def _sel(c, A, Bv):
     return tuple((y + c * (x - y)) for x, y in zip(A, Bv))
 
 
-def build_h1(NE, cfg=None, verbose=False):
+def build_h1(NE, cfg=None, verbose=False, wide=False):
+    """wide: t comes as the 512-bit hash512 value itself (ec.py:531-534 reduce it with
+    `% q`): low 384 bits in T, the rest in TH; t R = lo R + hi R^2 = MUL(lo, R^2) + MUL(hi, R^3).
+    Only the first segment differs (h1w_a); the others are shared with the narrow form."""
     cfg = cfg or tw.Cfg()
     L = H1Layout(NE)
     segs = {}
@@ -102,11 +107,16 @@ def build_h1(NE, cfg=None, verbose=False):
     def done(b):
         segs[b.name] = schedule(b, temp_base=L.TEMP0, verbose=verbose)
     # ---- a: candidates and their norms
-    b = Builder("h1_a")
+    b0name = "h1w_a" if wide else "h1_a"
+    b = Builder(b0name)
     r2, one, zero = b.inp(C_R2), b.inp(C_ONE), b.inp(C_ZERO)
     s3, hh, sinv = b.inp(HC_S3), b.inp(HC_H), b.inp(HC_SINV)
+    r3 = b.inp(HC_R3) if wide else None
     for e in range(NE):
-        t = ((b.inp(L.T + 2 * e) * r2).mat(), (b.inp(L.T + 2 * e + 1) * r2).mat())
+        if wide:
+            t = tuple((b.inp(L.T + 2 * e + c) * r2 + b.inp(L.TH + 2 * e + c) * r3).mat() for c in range(2))
+        else:
+            t = ((b.inp(L.T + 2 * e) * r2).mat(), (b.inp(L.T + 2 * e + 1) * r2).mat())
         b.out(t[0], L.T + 2 * e), b.out(t[1], L.T + 2 * e + 1)
         b.out(t[1].sgn(), L.PAR + e)                              # parity: t.c1 > (-t).c1
         tt = cfg.sqr2(t)
@@ -204,7 +214,7 @@ def build_h1(NE, cfg=None, verbose=False):
             if ch == "1":
                 sc.append("h1_mul" + tag)
         return sc
-    script = ["h1_a"] + exp_script("3") + ["h1_b"] + exp_script("2") + ["h1_c"]
+    script = [b0name] + exp_script("3") + ["h1_b"] + exp_script("2") + ["h1_c"]
     return segs, L, script
 
 

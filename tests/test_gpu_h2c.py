@@ -18,6 +18,22 @@ def test_reference_vectors(engine, golden):
     assert [out[192 * i:192 * (i + 1)].hex() for i in range(len(vec))] == [r["point"] for r in vec]
 
 
+def test_whole_hash_from_message_hashes(engine, golden):
+    """blsgpu_hash_to_g2: SHA-256 chain + reduction mod q on the GPU as well -- reference
+    vectors, then seeded batches against the host implementation."""
+    vec = golden("hash_to_curve.json")["hash_to_g2"]
+    out = engine.hash_to_g2(b"".join(bytes.fromhex(r["msg_hash"]) for r in vec))
+    assert [out[192 * i:192 * (i + 1)].hex() for i in range(len(vec))] == [r["point"] for r in vec]
+    for n in (1, 13, 300):
+        msgs = [hashlib.sha256(b"whole-%d-%d" % (n, i)).digest() for i in range(n)]
+        out = engine.hash_to_g2(b"".join(msgs))
+        t = b"".join(H.g2_hash_field_elements(m, hash512) for m in msgs)
+        assert out == engine.map_to_g2(t)
+        for i in (0, n // 2, n - 1):
+            assert out[192 * i:192 * (i + 1)] == H.g2_affine_bytes(H.hash_to_g2_prehashed(msgs[i], hash512))
+    assert engine.hash_to_g2(b"") == b""
+
+
 def test_sw_encode_vectors_through_the_map(engine, golden):
     """t1 = 0 encodes to infinity, so the map returns clear_cofactor(sw_encode(t0))."""
     vec = golden("hash_to_curve.json")["sw_encode_fq2"]

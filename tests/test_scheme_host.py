@@ -57,6 +57,11 @@ def oracle_provider(oracle):
                     ok.append(False)
             return out, ok
 
+        def hash_to_g2(self, msg_hashes):
+            from bls_py import hostmath as H, util
+            return b"".join(H.g2_affine_bytes(H.hash_to_g2_prehashed(msg_hashes[32 * i:32 * (i + 1)], util.hash512))
+                            for i in range(len(msg_hashes) // 32))
+
         def map_to_g2(self, t):
             # stand-in for the GPU map: the host integer implementation, pinned to the
             # reference by test_hash_to_curve_and_sw_encode below
@@ -186,6 +191,7 @@ def test_verify4_inputs_match_reference(golden):
         g1_msm = staticmethod(inner.g1_msm)
         g2_msm = staticmethod(inner.g2_msm)
         map_to_g2 = staticmethod(inner.map_to_g2)
+        hash_to_g2 = staticmethod(inner.hash_to_g2)
 
         def pairing_multi(self, g1, g2, n):
             seen["g1"], seen["g2"], seen["n"] = g1, g2, n
