@@ -19,7 +19,9 @@ template <> struct MsmCfg<1> {
                          STEP_OFF = BLSVM_SEGF_G1_STEP_OFF, STEP_LEN = BLSVM_SEGF_G1_STEP_LEN,
                          FOLD_OFF = BLSVM_SEGF_G1_FOLD_OFF, FOLD_LEN = BLSVM_SEGF_G1_FOLD_LEN,
                          PADD_OFF = BLSVM_SEGF_G1_PADD_OFF, PADD_LEN = BLSVM_SEGF_G1_PADD_LEN,
-                         AFF_OFF = BLSVM_SEGF_G1_AFFINE_OFF, AFF_LEN = BLSVM_SEGF_G1_AFFINE_LEN;
+                         AFF_OFF = BLSVM_SEGF_G1_AFFINE_OFF, AFF_LEN = BLSVM_SEGF_G1_AFFINE_LEN,
+                         ACC_OFF = BLSVM_SEGF_G1_ACC_OFF, ACC_LEN = BLSVM_SEGF_G1_ACC_LEN,
+                         DBL_OFF = BLSVM_SEGF_G1_DBL_OFF, DBL_LEN = BLSVM_SEGF_G1_DBL_LEN;
 };
 template <> struct MsmCfg<2> {
     static constexpr int NP = BLSVM_MSM2_NP, IN = BLSVM_MSM2_IN, R = BLSVM_MSM2_R, A = BLSVM_MSM2_A,
@@ -28,7 +30,9 @@ template <> struct MsmCfg<2> {
                          STEP_OFF = BLSVM_SEGF_G2_STEP_OFF, STEP_LEN = BLSVM_SEGF_G2_STEP_LEN,
                          FOLD_OFF = BLSVM_SEGF_G2_FOLD_OFF, FOLD_LEN = BLSVM_SEGF_G2_FOLD_LEN,
                          PADD_OFF = BLSVM_SEGF_G2_PADD_OFF, PADD_LEN = BLSVM_SEGF_G2_PADD_LEN,
-                         AFF_OFF = BLSVM_SEGF_G2_AFFINE_OFF, AFF_LEN = BLSVM_SEGF_G2_AFFINE_LEN;
+                         AFF_OFF = BLSVM_SEGF_G2_AFFINE_OFF, AFF_LEN = BLSVM_SEGF_G2_AFFINE_LEN,
+                         ACC_OFF = BLSVM_SEGF_G2_ACC_OFF, ACC_LEN = BLSVM_SEGF_G2_ACC_LEN,
+                         DBL_OFF = BLSVM_SEGF_G2_DBL_OFF, DBL_LEN = BLSVM_SEGF_G2_DBL_LEN;
 };
 
 // dword k (0 .. 36*DEG-1) of the projective point at infinity (0 : 1 : 0), Montgomery
@@ -178,6 +182,211 @@ __global__ void __launch_bounds__(256) k_msm_finish(VmTables T, const uint32_t* 
     }
     const uint64_t nz = __ballot(any != 0);
     if (out_inf && lane == 0) out_inf[g] = (nz == 0) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// Bucket method (Pippenger) for one large sum  sum_i s_i P_i  (BLS.aggregate_pub_keys at
+// scale, BASELINE config "1 M-point G1 multi-scalar-mul, Pippenger buckets in LDS").
+// Same value as the double-and-add of fields_t.py:705-740 summed over i (parity is on
+// the affine result).  Scalars are cut into PIP_W windows of PIP_C bits.
+//
+// k_msm_pip: block (chunk, window) owns, per lane group p < NP, 2^PIP_C buckets in LDS
+// (bucket 0 collects the zero digits and is dropped).  Every step adds NP points to
+// the buckets their digits select: the kernel copies bucket -> R_p, point (converted once by
+// k_msm_prep) -> S_p, runs
+// the static program g*_acc (R_p += S_p, complete formulas) and copies R_p back.
+// Then sum_j j B_j by the running-sum trick (2 (2^PIP_C - 1) more g*_acc runs), the NP
+// group totals are folded and the window partial of this chunk is written.
+// k_msm_pip_windows: one team per window adds the chunk partials.
+// k_msm_pip_horner: result = sum_w 2^(PIP_C w) W_w, affine, canonical bytes.
+constexpr int PIP_C = 4;
+constexpr int PIP_W = 64;                                    // 256 / PIP_C
+constexpr int PIP_NB = 1 << PIP_C;
+
+template <int DEG> struct PipCfg {
+    using C = MsmCfg<DEG>;
+    static constexpr int BUCKET0 = BLSVM_TEAM_SLOTS;         // above every program's temporaries
+    static constexpr int SLOTS = BUCKET0 + C::NP * PIP_NB * 3 * DEG;
+};
+
+// affine big-endian points -> projective Montgomery triples (36*DEG u32 each, (0:1:0) for
+// the (0,0) encoding of infinity), once, so that the 64 window passes need no conversion
+template <int DEG>
+__global__ void __launch_bounds__(256, 3) k_msm_prep(VmTables T, const uint32_t* __restrict__ pts, uint32_t k, uint32_t* __restrict__ prep) {
+    using C = MsmCfg<DEG>;
+    constexpr uint32_t PT_DW = 24 * DEG, PJ_DW = 36 * DEG;
+    uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* team = smem + wave * TEAM_DW;
+    const uint32_t base16 = wave * (TEAM_BYTES / 16);
+    const uint32_t first = (blockIdx.x * (blockDim.x >> 6) + wave) * C::NP;
+    if (first >= k) return;                                   // no workgroup barrier below
+    const uint32_t cnt = min((uint32_t)C::NP, k - first);
+    team_init_consts(T, team, lane);
+    for (uint32_t d = lane; d < C::NP * PT_DW; d += 64) {
+        uint32_t p = d / PT_DW, o = d % PT_DW, e = o / 12, w = o % 12;
+        uint32_t v = (p < cnt) ? bswap32(pts[(size_t)(first + p) * PT_DW + o]) : 0u;
+        team[(C::IN + p * 2 * DEG + e) * 12 + (11 - w)] = v;
+    }
+    wave_fence();
+    run_rounds<true>(T, T.segflat + C::LOAD_OFF, C::LOAD_LEN, base16, lane);
+    uint32_t zero_in = 0;
+    if (lane < C::NP) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < 2u * DEG * 12u; i++) acc |= team[(C::IN + lane * 2 * DEG) * 12 + i];
+        zero_in = (acc == 0u);
+    }
+    const uint64_t zmask = __ballot(zero_in != 0);
+    for (uint32_t d = lane; d < cnt * PJ_DW; d += 64) {
+        const uint32_t p = d / PJ_DW;
+        prep[(size_t)first * PJ_DW + d] = ((zmask >> p) & 1ull) ? inf_dword<DEG>(team, d % PJ_DW) : team[C::A * 12 + d];
+    }
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(64, 2) k_msm_pip(VmTables T, const uint32_t* __restrict__ prep, const uint32_t* __restrict__ scalars,
+                                                   uint32_t k, uint32_t chunk, uint32_t* __restrict__ partials) {
+    using C = MsmCfg<DEG>;
+    using P = PipCfg<DEG>;
+    constexpr uint32_t PJ_DW = 36 * DEG;
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t win = blockIdx.y;
+    const uint32_t lo = blockIdx.x * chunk, hi = min(k, lo + chunk);
+    team_init_consts(T, team, lane);
+    wave_fence();
+    for (uint32_t d = lane; d < C::NP * PIP_NB * PJ_DW; d += 64) team[P::BUCKET0 * 12 + d] = inf_dword<DEG>(team, d % PJ_DW);
+    wave_fence();
+    auto bucket = [&](uint32_t p, uint32_t j) { return (uint32_t)(P::BUCKET0 * 12) + (p * PIP_NB + j) * PJ_DW; };
+    for (uint32_t first = lo; first < hi; first += C::NP) {
+        const uint32_t cnt = min((uint32_t)C::NP, hi - first);
+        // digit of this window: bits [PIP_C win, PIP_C win + PIP_C) of the big-endian scalar
+        uint32_t dig = 0;
+        if (lane < cnt) {
+            if (scalars) {
+                const uint32_t word = bswap32(scalars[(size_t)(first + lane) * 8 + (7 - win / 8)]);
+                dig = (word >> (4 * (win % 8))) & 15u;
+            } else {
+                dig = (win == 0) ? 1u : 0u;
+            }
+        }
+        // S_p = the point (infinity for (0,0) and past the end), R_p = its bucket
+        uint32_t digs[C::NP];
+#pragma unroll
+        for (int p = 0; p < C::NP; p++) digs[p] = __builtin_amdgcn_readlane(dig, p);
+        for (uint32_t d = lane; d < C::NP * PJ_DW; d += 64) {
+            const uint32_t p = d / PJ_DW, o = d % PJ_DW;
+            uint32_t dp = 0;
+#pragma unroll
+            for (int q = 0; q < C::NP; q++) dp = (p == (uint32_t)q) ? digs[q] : dp;
+            team[C::S * 12 + d] = (p < cnt) ? prep[(size_t)first * PJ_DW + d] : inf_dword<DEG>(team, o);
+            team[C::R * 12 + d] = team[bucket(p, dp) + o];
+        }
+        wave_fence();
+        run_rounds<true>(T, T.segflat + C::ACC_OFF, C::ACC_LEN, 0, lane);
+        for (uint32_t d = lane; d < C::NP * PJ_DW; d += 64) {
+            const uint32_t p = d / PJ_DW, o = d % PJ_DW;
+            uint32_t dp = 0;
+#pragma unroll
+            for (int q = 0; q < C::NP; q++) dp = (p == (uint32_t)q) ? digs[q] : dp;
+            team[bucket(p, dp) + o] = team[C::R * 12 + d];
+        }
+        wave_fence();
+    }
+    // sum_j j B_j: acc (kept in A_p) runs down the buckets, tot (kept in bucket 0) adds acc every time
+    for (uint32_t d = lane; d < C::NP * PJ_DW; d += 64) {
+        const uint32_t p = d / PJ_DW, o = d % PJ_DW;
+        team[C::A * 12 + d] = inf_dword<DEG>(team, o);
+        team[bucket(p, 0) + o] = inf_dword<DEG>(team, o);
+    }
+    wave_fence();
+    for (int j = PIP_NB - 1; j >= 1; j--) {
+        for (uint32_t d = lane; d < C::NP * PJ_DW; d += 64) {
+            const uint32_t p = d / PJ_DW, o = d % PJ_DW;
+            team[C::R * 12 + d] = team[C::A * 12 + d];
+            team[C::S * 12 + d] = team[bucket(p, (uint32_t)j) + o];
+        }
+        wave_fence();
+        run_rounds<true>(T, T.segflat + C::ACC_OFF, C::ACC_LEN, 0, lane);
+        for (uint32_t d = lane; d < C::NP * PJ_DW; d += 64) {
+            const uint32_t p = d / PJ_DW, o = d % PJ_DW;
+            const uint32_t r = team[C::R * 12 + d];
+            team[C::A * 12 + d] = r;                          // acc
+            team[C::S * 12 + d] = r;
+            team[C::R * 12 + d] = team[bucket(p, 0) + o];     // tot
+        }
+        wave_fence();
+        run_rounds<true>(T, T.segflat + C::ACC_OFF, C::ACC_LEN, 0, lane);
+        for (uint32_t d = lane; d < C::NP * PJ_DW; d += 64) {
+            const uint32_t p = d / PJ_DW, o = d % PJ_DW;
+            team[bucket(p, 0) + o] = team[C::R * 12 + d];
+        }
+        wave_fence();
+    }
+    // R_p = tot_p already; fold the NP totals
+    run_rounds<true>(T, T.segflat + C::FOLD_OFF, C::FOLD_LEN, 0, lane);
+    uint32_t* dst = partials + ((size_t)win * gridDim.x + blockIdx.x) * PJ_DW;
+    for (uint32_t i = lane; i < PJ_DW; i += 64) dst[i] = team[C::PR0 * 12 + i];
+}
+
+// W_w = sum over chunks of partial[w][chunk]; one team per window
+template <int DEG>
+__global__ void __launch_bounds__(64) k_msm_pip_windows(VmTables T, const uint32_t* __restrict__ partials, uint32_t chunks,
+                                                        uint32_t* __restrict__ winsums) {
+    using C = MsmCfg<DEG>;
+    constexpr uint32_t PJ_DW = 36 * DEG;
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t win = blockIdx.x;
+    team_init_consts(T, team, lane);
+    wave_fence();
+    for (uint32_t i = 0; i < chunks; i++) {
+        const uint32_t* src = partials + ((size_t)win * chunks + i) * PJ_DW;
+        const uint32_t dst = (i == 0) ? C::PR0 : C::PR1;
+        for (uint32_t d = lane; d < PJ_DW; d += 64) team[dst * 12 + d] = src[d];
+        wave_fence();
+        if (i) run_rounds<true>(T, T.segflat + C::PADD_OFF, C::PADD_LEN, 0, lane);
+    }
+    wave_fence();
+    for (uint32_t d = lane; d < PJ_DW; d += 64) winsums[(size_t)win * PJ_DW + d] = team[C::PR0 * 12 + d];
+}
+
+// result = sum_w 2^(PIP_C w) W_w  (Horner from the top window), affine canonical bytes
+template <int DEG>
+__global__ void __launch_bounds__(64) k_msm_pip_horner(VmTables T, const uint32_t* __restrict__ winsums, uint32_t* __restrict__ out,
+                                                       uint8_t* __restrict__ out_inf) {
+    using C = MsmCfg<DEG>;
+    constexpr uint32_t PJ_DW = 36 * DEG, PT_DW = 24 * DEG;
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    team_init_consts(T, team, lane);
+    wave_fence();
+    for (uint32_t d = lane; d < PJ_DW; d += 64) team[C::PR0 * 12 + d] = winsums[(size_t)(PIP_W - 1) * PJ_DW + d];
+    wave_fence();
+    for (int w = PIP_W - 2; w >= 0; w--) {
+        for (int s = 0; s < PIP_C; s++) run_rounds<true>(T, T.segflat + C::DBL_OFF, C::DBL_LEN, 0, lane);
+        for (uint32_t d = lane; d < PJ_DW; d += 64) team[C::PR1 * 12 + d] = winsums[(size_t)w * PJ_DW + d];
+        wave_fence();
+        run_rounds<true>(T, T.segflat + C::PADD_OFF, C::PADD_LEN, 0, lane);
+    }
+    run_rounds(T, T.segflat + C::AFF_OFF, C::AFF_LEN, 0, lane);
+    if (lane < 2u * DEG) {
+        uint32_t X[12];
+        lds_load12(X, (C::OUT + lane) * 3);
+        bls::fq_canon(X);
+        lds_store12(X, (C::OUT + lane) * 3);
+    }
+    wave_fence();
+    uint32_t any = 0;
+    for (uint32_t d = lane; d < PT_DW; d += 64) {
+        uint32_t e = d / 12, w = d % 12;
+        uint32_t v = team[(C::OUT + e) * 12 + (11 - w)];
+        any |= v;
+        out[d] = bswap32(v);
+    }
+    const uint64_t nz = __ballot(any != 0);
+    if (out_inf && lane == 0) out_inf[0] = (nz == 0) ? 1 : 0;
 }
 
 }  // namespace blsgpu

@@ -143,6 +143,18 @@ def build(deg, NP, cfg=None, verbose=False):
         _out_pt(b, lay, padd(F, R, S), lay.R, p, zero)
         _out_pt(b, lay, pdbl(F, A), lay.A, p, zero)
     builders.append(b)
+    # bucket method: R_p <- R_p + S_p for the NP points (no doubling)
+    b = Builder(tag + "_acc")
+    zero = b.inp(C_ZERO)
+    for p in range(NP):
+        R, S = _in_pt(b, lay, lay.R, p), _in_pt(b, lay, lay.S, p)
+        _out_pt(b, lay, padd(F, R, S), lay.R, p, zero)
+    builders.append(b)
+    # PR0 <- 2 PR0 (window shifts of the bucket method)
+    b = Builder(tag + "_dbl")
+    zero = b.inp(C_ZERO)
+    _out_pt(b, lay, pdbl(F, _in_pt(b, lay, lay.PR0)), lay.PR0, 0, zero)
+    builders.append(b)
     # R_0 <- R_0 + R_1 + ... (balanced tree)
     b = Builder(tag + "_fold")
     zero = b.inp(C_ZERO)

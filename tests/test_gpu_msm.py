@@ -107,3 +107,62 @@ def test_threshold_combine_batched(engine, golden):
     small = golden("threshold.json")["3_of_5"]
     out, _ = engine.g2_msm(cat(small["unit_sigs_affine"]), [int(x, 16) for x in small["lambdas"]], 3)
     assert out.hex() == small["combined_affine"]
+
+
+@pytest.fixture(scope="module")
+def pip_engine():
+    """An engine whose single sums use the bucket method from 1 point on."""
+    import os
+    from bls_py import _native
+    old = os.environ.get("BLSGPU_PIP_THRESHOLD")
+    os.environ["BLSGPU_PIP_THRESHOLD"] = "1"
+    try:
+        e = _native.Engine(0)
+    finally:
+        if old is None:
+            del os.environ["BLSGPU_PIP_THRESHOLD"]
+        else:
+            os.environ["BLSGPU_PIP_THRESHOLD"] = old
+    return e
+
+
+@pytest.mark.parametrize("k", [1, 5, 6, 7, 383, 384, 385, 1000])
+def test_bucket_method_vs_oracle(pip_engine, oracle, seeded_pairs, k):
+    """k_msm_pip (Pippenger, buckets in LDS) on ragged sizes (chunk = 384 points at these
+    sizes): full-range, short, zero and maximal scalars; G1 and (up to 385) G2."""
+    g1, g2 = seeded_pairs
+    rnd = random.Random(k)
+    pts1 = (g1 * 2)[96 * 3:96 * (3 + k)]
+    sc = [rnd.choice([rnd.randrange(N), rnd.randrange(1 << 40), 0, N - 1, 1, (1 << 255) - 19]) for _ in range(k)]
+    out1, inf1 = pip_engine.g1_msm(pts1, sc, k)
+    w1, _ = oracle.g1_msm(pts1, sc, k)
+    assert out1 == w1 and inf1 == [w1 == bytes(96)]
+    if k <= 385:
+        pts2 = (g2 * 2)[192 * 3:192 * (3 + k)]
+        out2, _ = pip_engine.g2_msm(pts2, sc, k)
+        assert out2 == oracle.g2_msm(pts2, sc, k)[0]
+
+
+def test_bucket_method_degenerate(pip_engine, engine, golden):
+    p = golden("points.json")
+    P = bytes.fromhex(p["g1"][3]["p"])
+    negP = P[:48] + ((Q - int.from_bytes(P[48:], "big")) % Q).to_bytes(48, "big")
+    assert pip_engine.g1_msm(P + negP, None, 2) == (bytes(96), [True])                  # plain sum, P + (-P)
+    assert pip_engine.g1_msm(P * 3, [0, 0, 0], 3) == (bytes(96), [True])                # all-zero scalars
+    assert pip_engine.g1_msm(P + bytes(96), [7, 9], 2) == engine.g1_msm(P, [7], 1)      # (0,0) input = infinity
+    assert pip_engine.g1_msm(P * 40, [5] * 40, 40) == engine.g1_msm(P, [200], 1)        # one bucket, many points
+    assert pip_engine.g1_msm(P * 7, None, 7) == engine.g1_msm(P, [7], 1)
+
+
+def test_aggregate_pub_keys_1024_bucket_method(pip_engine, golden):
+    """The reference's aggregate_pub_keys vector (bls.py:203-223) through the bucket method."""
+    rec = golden("msm.json")["1024"]
+    g = bytes.fromhex(golden("points.json")["g1"][0]["p"])
+    n = 1024
+    sks = [prf(b"blsgpu/a", 1, i) for i in range(n)]
+    pks, _ = pip_engine.g1_msm(g * n, sks, 1, n)
+    pts = sorted((pks[96 * i:96 * (i + 1)] for i in range(n)), key=_compress_g1)
+    digest = hashlib.sha256(b"".join(_compress_g1(p) for p in pts)).digest()
+    ts = [int.from_bytes(hashlib.sha256(i.to_bytes(4, "big") + digest).digest(), "big") % N for i in range(n)]
+    assert pip_engine.g1_msm(b"".join(pts), ts, n)[0].hex() == rec["secure_affine"]
+    assert pip_engine.g1_msm(b"".join(pts), None, n)[0].hex() == rec["simple_affine"]
