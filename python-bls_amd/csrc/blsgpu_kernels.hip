@@ -213,9 +213,11 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
 #else
 #define BLSGPU_SLOTMASK 1023u
 #endif
-            // K >= 1 (emit.py).  The loop leaves through `break`, so every use of an
-            // operand buffer is dominated by its load (no register shuffling between
-            // steps); the look-ahead load past the last micro-op reads slot 0.
+            // K >= 1 (emit.py).  Micro-ops 0 .. MN-1 are the negative terms (summed as plain
+            // products), then every lane flips the sign of its accumulators, then the positive
+            // terms.  The loop leaves through `break`, so every use of an operand buffer is
+            // dominated by its load; the look-ahead load past the last micro-op reads slot 0.
+            const uint32_t MN = (meta >> 18) & 0xFFu;
             lds_load12(S[0], base16 + (BLSGPU_UOP(0) & BLSGPU_SLOTMASK) * 3u);
 #pragma unroll
             for (int p = 0; p < 4 * LIN_CHUNKS - 2; p++) {
@@ -223,17 +225,18 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
                     const uint32_t live = ((uint32_t)(p + 1) < K) ? BLSGPU_SLOTMASK : 0u;
                     lds_load12(S[(p + 1) & 1], base16 + (BLSGPU_UOP(p + 1) & live) * 3u);
                 }
+                if (p > 0 && (uint32_t)p == MN) bls::fat_flip(acc);
                 const uint32_t u = BLSGPU_UOP(p);
 #if defined(BLSGPU_EXP) && (BLSGPU_EXP & 16)
                 for (int j = 0; j < 12; j++) acc[j] ^= S[p & 1][j];          // timing experiment only
 #else
-                bls::fat_mac(acc, S[p & 1], (u >> 10) & 31u, (uint32_t)((int32_t)(u << 16) >> 31));
+                bls::fat_mac_plain(acc, S[p & 1], (u >> 10) & 31u);
 #endif
                 if ((uint32_t)(p + 1) >= K) break;
             }
+            if (MN == K) bls::fat_flip(acc);
 #undef BLSGPU_UOP
-            const uint32_t w1 = ch[0].x >> 16;               // N | absorb1 << 14 | absorb2 << 15
-            bls::fat_compensate(acc, w1 & 0x3FFFu);          // N * K1 for the lane's N complemented units
+            const uint32_t w1 = ch[0].x >> 16;               // absorb1 << 14 | absorb2 << 15
             // a combination split over 2 or 4 adjacent lanes: the flagged lanes add their
             // neighbours' partial limb accumulators (exact 64-bit integer adds)
             const uint32_t levels = (meta >> 16) & 3u;

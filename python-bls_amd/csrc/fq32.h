@@ -296,26 +296,33 @@ BLS_HD void acc_reduce_relaxed(uint32_t* __restrict__ out, const uint32_t* __res
 #define BLS_QC_LIMBS /* 2^384 - q */ \
     {0x00005555u, 0x46010000u, 0x4eac0000u, 0xe1540001u, 0x094f09dbu, 0x98cf2d5fu, 0x0c7aed40u, 0x9b88b47bu, 0xbcb45328u, 0xb4e45849u, 0xc6801965u, 0xe5feee15u}
 
-#define BLS_K1_LIMBS /* -(2^384 - 1) mod q: cancels the surplus of one complemented term */ \
-    {0xfffcaaafu, 0x43f5ffffu, 0xed47fffdu, 0x32b7fff2u, 0xa2e99d69u, 0x07e83a49u, 0x8332bb7au, 0xeca8f331u, 0xa0f4c069u, 0xef148d1eu, 0x3eff0206u, 0x040ab326u}
-// acc += n * K1
-BLS_HD void fat_compensate(uint64_t* __restrict__ acc, uint32_t n) {
-    const uint32_t k1[12] = BLS_K1_LIMBS;
+#define BLS_BIAS1_FAT /* BIAS + 1 per 64-bit limb; BIAS = 0 mod q, every limb 2^40 + (32-bit digit) */ \
+    {0x00000100fcb7adf4ull, 0x00000100a026ff00ull, 0x000001004433fc4full, 0x000001000bcbf221ull, 0x0000010054a7e8b3ull, 0x000001002fca321eull, 0x0000010019759de0ull, 0x000001005ac6af43ull, 0x00000100b439141dull, 0x00000100a35690ddull, 0x000001003c85e46eull, 0x0000010014896a91ull}
+// acc <- BIAS - acc limb by limb (every acc[j] < 2^40): the sum of the negative terms changes sign
+BLS_HD void fat_flip(uint64_t* __restrict__ acc) {
+    const uint64_t b1[12] = BLS_BIAS1_FAT;
 #pragma unroll
-    for (int j = 0; j < 12; j++) acc[j] += (uint64_t)k1[j] * n;
+    for (int j = 0; j < 12; j++) acc[j] = b1[j] + ~acc[j];
+}
+// acc[j] += cf * s[j]
+BLS_HD void fat_mac_plain(uint64_t* __restrict__ acc, const uint32_t* __restrict__ s, uint32_t cf) {
+#pragma unroll
+    for (int j = 0; j < 12; j++) acc[j] += (uint64_t)s[j] * cf;
 }
 // acc[j] += cf * (s[j] ^ negmask),  negmask = 0 or 0xffffffff
 BLS_HD void fat_mac(uint64_t* __restrict__ acc, const uint32_t* __restrict__ s, uint32_t cf, uint32_t negmask) {
 #pragma unroll
     for (int j = 0; j < 12; j++) acc[j] += (uint64_t)(s[j] ^ negmask) * cf;
 }
-// out = V mod q with 0 <= out < 2q, V = sum acc[j] 2^(32 j) < 2^392
+// out = V mod q with 0 <= out < 2q, V = sum acc[j] 2^(32 j) < 2^396 (every acc[j] < 2^44)
 BLS_HD void fat_reduce(uint32_t* __restrict__ out, const uint64_t* __restrict__ acc) {
     const uint32_t qc[12] = BLS_QC_LIMBS;
-    // V / q to within 2e-4 from the top fat limb; k = floor(. - 1e-3) is k* or k* - 1
-    float hf = (float)(uint32_t)(acc[11] >> 32) * 4294967296.0f + (float)(uint32_t)acc[11];
-    float e = hf * (1.0f / 436277738.0f) - 0.001f;      // q >> 352 = 0x1a0111ea
-    uint32_t k = (e > 0.0f) ? (uint32_t)e : 0u;
+    // V / q from the top fat limb in double precision (exact conversion; what is ignored
+    // -- the lower limbs and the low bits of q -- is worth < 2e-4): k = floor(. - 1e-3) is
+    // floor(V / q) or one less
+    double hf = (double)(uint32_t)(acc[11] >> 32) * 4294967296.0 + (double)(uint32_t)acc[11];
+    double e = hf * (1.0 / 436277738.0) - 0.001;        // q >> 352 = 0x1a0111ea
+    uint32_t k = (e > 0.0) ? (uint32_t)e : 0u;
     // (V + k (2^384 - q)) mod 2^384 = V - k q
     uint64_t c = 0;
 #pragma unroll

@@ -34,61 +34,73 @@ def sref(slot):
 
 
 def kpad(K):
-    """u16 per lane record of a LIN round: destination, compensation count, K micro-ops"""
+    """u16 per lane record of a LIN round: destination, merge flags, K micro-ops"""
     return (K + 2 + 3) & ~3
 
 
-def plan_lin_round(lanes):
-    """Lane records of one LIN round: [(dst | None, negsum, uops)], K, levels.
+FLIP_COST, LEVEL_COST = 2.5, 3.0          # in micro-op steps (15 VALU each): sign flip ~40, merge level ~48 VALU
 
-    * The compensation micro-ops N * K1 of core.lower_lin are folded into a per-lane
-      count N (the kernel adds N * K1 after the loop from constants).
-    * A long combination is split over 2 or 4 ADJACENT lanes (aligned), each summing a
-      share of the micro-ops into its own 64-bit limb accumulators; the kernel adds
-      the accumulators across the group (DPP, `levels` steps) and the group's first
-      lane reduces and stores.  Splitting is free of rounding: the accumulators are
-      exact integers.  Chosen to minimise K + levels, K = longest share."""
+
+def plan_lin_round(lanes):
+    """Lane records of one LIN round: ([(dst | None, flags, negatives, positives)], MN, MP, levels).
+
+    * Every lane first sums its NEGATIVE terms (as plain products), then all lanes flip
+      the sign of their accumulators at the same step (acc <- BIAS - acc, BIAS = 0 mod q
+      with every 64-bit limb above any partial sum), then sum the positive terms: no
+      per-term complement, no compensation constants.  MN / MP = longest negative /
+      positive share of the round; shorter shares are padded with zero micro-ops.
+      (The compensation micro-ops of core.lower_lin are dropped here.)
+    * A long combination is split over 2 or 4 ADJACENT lanes (aligned), negatives and
+      positives dealt out evenly; the kernel adds the partial accumulators across the
+      group (DPP, `levels` steps) and the group's first lane reduces and stores.  Exact:
+      the accumulators are integers and each flipped share adds one BIAS.
+      flags: bit 14 = add the odd neighbour at level 1, bit 15 = add two lanes up at level 2.
+    Chosen to minimise MN + MP + FLIP_COST [MN > 0] + LEVEL_COST levels."""
     ops = []
     for uops, d in lanes:
         real = [u for u in uops if u[2] != P.C_K1]
-        nsum = sum(cf for neg, cf, s in real if neg)
-        assert nsum == sum(cf for neg, cf, s in uops if s == P.C_K1), "compensation does not match"
-        ops.append((d, real))
-    base = max(1, max(len(u) for _, u in ops))
-    best = (base, 0, [1] * len(ops))
-    for lv in (1, 2):
+        assert sum(cf for neg, cf, s in real if neg) == sum(cf for neg, cf, s in uops if s == P.C_K1), "compensation does not match"
+        ops.append((d, [u for u in real if u[0]], [u for u in real if not u[0]]))
+
+    def cost(mn, mp, lv):
+        return mn + mp + (FLIP_COST if mn else 0) + LEVEL_COST * lv
+    best = None
+    nmax = max(len(n) for _, n, _ in ops)
+    pmax = max(len(p) for _, _, p in ops)
+    for lv in (0, 1, 2):
         gmax = 1 << lv
-        for T in range(1, base):
-            if T + 1.5 * lv >= best[0] + 1.5 * best[1]:
-                break
-            gs, tot = [], 0
-            for _, u in ops:
-                g = 1
-                while -(-len(u) // g) > T and g < gmax:
-                    g *= 2
-                if -(-len(u) // g) > T:
-                    tot = None
+        for tn in range(0, nmax + 1):
+            for tp in range(0, pmax + 1):
+                if best is not None and cost(tn, tp, lv) >= best[0]:
                     break
-                gs.append(g)
-                tot += g
-            if tot is not None and tot <= LANES:
-                best = (T, lv, gs)
-                break
-    T, lv, gs = best
+                gs, tot = [], 0
+                for _, n, p in ops:
+                    g = 1
+                    while (-(-len(n) // g) > tn or -(-len(p) // g) > tp) and g < gmax:
+                        g *= 2
+                    if -(-len(n) // g) > tn or -(-len(p) // g) > tp:
+                        tot = None
+                        break
+                    gs.append(g)
+                    tot += g
+                if tot is not None and tot <= LANES:
+                    best = (cost(tn, tp, lv), lv, gs)
+                    break
+    assert best is not None
+    _, lv, gs = best
     plan = []
     for g in (4, 2, 1):                                   # widest groups first keeps every group aligned
-        for (d, u), gg in zip(ops, gs):
+        for (d, n, p), gg in zip(ops, gs):
             if gg != g:
                 continue
-            share = -(-len(u) // g) if u else 0
             for part in range(g):
-                mine = u[part * share:(part + 1) * share]
                 flags = (1 << 14 if g >= 2 and part % 2 == 0 else 0) | (1 << 15 if g == 4 and part == 0 else 0)
-                nsum = sum(cf for neg, cf, s in mine if neg)
-                assert nsum < (1 << 14)
-                plan.append((d if part == 0 else None, nsum | flags, mine))
-    K = max(1, max(len(m) for _, _, m in plan))
-    return plan, K, lv
+                plan.append((d if part == 0 else None, flags, n[part::g], p[part::g]))
+    mn = max(len(x[2]) for x in plan)
+    mp = max(len(x[3]) for x in plan)
+    if mn + mp == 0:
+        mp = 1
+    return plan, mn, mp, lv
 
 
 def pack(segs, order):
@@ -121,22 +133,24 @@ def pack(segs, order):
                     else:
                         data += [0, 0, INACTIVE, 0]
             else:
-                plan, K, lv = plan_lin_round(lanes)
+                plan, mn, mp, lv = plan_lin_round(lanes)
+                K = mn + mp
                 assert K < 256 and len(plan) <= LANES
                 kp = kpad(K)
                 for ln in range(LANES):
                     rec = [0] * kp
                     if ln < len(plan):
-                        d, nsum, uops = plan[ln]
+                        d, flags, negs, poss = plan[ln]
                         rec[0] = sref(mv(d)) if d is not None else INACTIVE
-                        rec[1] = nsum
-                        for k, (neg, cf, s) in enumerate(uops):
-                            assert 0 < cf < 32 and 0 <= s < 1024
-                            rec[2 + k] = (neg << 15) | (cf << 10) | mv(s)
+                        rec[1] = flags
+                        for base, lst_ in ((2, negs), (2 + mn, poss)):
+                            for k, (neg, cf, s) in enumerate(lst_):
+                                assert 0 < cf < 32 and 0 <= s < 1024
+                                rec[base + k] = (cf << 10) | mv(s)
                     else:
                         rec[0] = INACTIVE
                     data += rec
-                lst.append((off, KIND[kind] | (K << 8) | (lv << 16)))
+                lst.append((off, KIND[kind] | (K << 8) | (lv << 16) | (mn << 18)))
                 continue
             lst.append((off, KIND[kind]))
         seg_rounds[name] = lst
@@ -200,7 +214,7 @@ def generate(path=None, verbose=False):
     w = out.append
     w("/* generated by python-bls_amd/vmgen/emit.py -- do not edit */\n#pragma once\n#include <stdint.h>\n")
     w("#define BLSVM_NDATA %d\n" % len(data))
-    maxk = max(plan_lin_round(r["lanes"])[1] for s in segs.values() for r in s.rounds if r["kind"] == "lin")
+    maxk = max(sum(plan_lin_round(r["lanes"])[1:3]) for s in segs.values() for r in s.rounds if r["kind"] == "lin")
     w("#define BLSVM_MAX_LIN_K %d\n" % maxk)
     w("#define BLSVM_TEAM_SLOTS %d\n#define BLSVM_NCONST %d\n" % (team_slots, P.NCONST))
     for nm in ("PX", "PY", "QX0", "TX", "LD", "LA", "NPX3", "REG0", "NREG", "TEMP0", "C_ZERO", "C_ONE", "C_R2", "C_RAW1", "C_K1"):

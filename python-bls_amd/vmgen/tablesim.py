@@ -1,27 +1,29 @@
 """Interpreter for the PACKED tables (the u16 records and round headers that go into
 csrc/vm_tables.h), mirroring the kernel's decoding in csrc/blsgpu_kernels.hip
-run_rounds: record layout, compensation counts, combinations split over adjacent
-lanes and their DPP-style merge.  Values are residues mod q as in vmgen.sim; what
+run_rounds: record layout, negative-then-positive phases with the sign flip,
+combinations split over adjacent lanes and their DPP-style merge.  Values are residues mod q as in vmgen.sim; what
 this adds over vmgen.sim is a CPU check of emit.py's encoding."""
 from .emit import INACTIVE, kpad
 from .sim import Q, R, RINV, to_m, from_m
 
+T0 = sum((1 << 40) << (32 * j) for j in range(12))
+BIAS = T0 + (-T0) % Q           # = 0 mod q; every 64-bit limb is 2^40 + (a 32-bit digit)
+assert BIAS % Q == 0
 PERM_L1 = (1, 1, 3, 3)          # quad_perm 0xF5
 PERM_L2 = (2, 2, 2, 2)          # quad_perm 0xAA
 
 
 class TableMachine:
-    def __init__(self, consts, nslots, data, k1_slot):
+    def __init__(self, consts, nslots, data, k1_slot=None):
         self.team = [0] * nslots
         for i, c in enumerate(consts):
             self.team[i] = c
         self.data = data
-        self.k1 = consts[k1_slot]
 
     def run(self, rounds):
         d16, team = self.data, self.team
         for off, meta in rounds:
-            kind, K, levels = meta & 3, (meta >> 8) & 0xFF, (meta >> 16) & 3
+            kind, K, levels, mn = meta & 3, (meta >> 8) & 0xFF, (meta >> 16) & 3, (meta >> 18) & 0xFF
             writes = []
             if kind != 1:
                 for lane in range(64):
@@ -46,17 +48,21 @@ class TableMachine:
                     w1s.append(rec[1])
                     t = 0
                     for p in range(K):
+                        if p == mn and mn:
+                            t = BIAS - t                      # the kernel's in-place sign flip
+                            assert t >= 0
                         u = rec[2 + p]
-                        cf, s = (u >> 10) & 31, u & 1023
-                        x = team[s]
-                        t += cf * ((R - 1 - x) if (u >> 15) else x)
-                    acc.append(t + (rec[1] & 0x3FFF) * self.k1)
+                        assert u < (1 << 15)
+                        t += ((u >> 10) & 31) * team[u & 1023]
+                    if mn == K:
+                        t = BIAS - t
+                    acc.append(t)
                 for lv, perm, bit in ((1, PERM_L1, 14), (2, PERM_L2, 15)):
                     if levels >= lv:
                         acc = [acc[l] + (acc[(l & ~3) + perm[l & 3]] if (w1s[l] >> bit) & 1 else 0) for l in range(64)]
                 for lane in range(64):
                     if dst[lane] != INACTIVE:
-                        assert dst[lane] % 3 == 0 and 0 <= acc[lane] < (1 << 392)
+                        assert dst[lane] % 3 == 0 and 0 <= acc[lane] < (1 << 396)
                         writes.append((dst[lane] // 3, acc[lane] % Q))
             for d, val in writes:
                 team[d] = val
