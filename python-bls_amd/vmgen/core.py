@@ -274,8 +274,15 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
             if not rl:
                 break
             rl.sort(key=lambda v: -prio[v.id])
-            for i in range(0, len(rl), lanes):
-                emit("lin", rl[i:i + lanes])
+            if len(rl) <= lanes:
+                emit("lin", rl)
+            else:
+                # more ops than lanes: deal them out by length so that every round of the
+                # level keeps free lanes for splitting its long combinations (emit.py)
+                nr = (len(rl) + lanes - 1) // lanes
+                by_len = sorted(rl, key=lambda v: -len(v.terms))
+                for r in range(nr):
+                    emit("lin", by_len[r::nr])
         if not pending:
             break
         level += 1
