@@ -48,6 +48,7 @@ struct blsgpu_ctx {
     uint32_t* d_out = nullptr;         // 576-byte result staging
     size_t mp_threshold = 4096;        // pairs from which k_miller_mp is used
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
+    size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
     uint32_t* d_msm_part = nullptr;    // MSM partials
     size_t msm_part_cap = 0;           // in u32
     // optional per-kernel timing (blsgpu_timing_enable): HIP events recorded on
@@ -150,16 +151,17 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
         return 0;
     }
     if (k > 0x7FFFFFFFull || groups > 0x7FFFFFFFull || k * groups > 0xFFFFFFF0ull) return fail(-EINVAL, "msm too large");
-    if (groups == 1 && k >= c->pip_threshold) {
-        // one large sum: bucket method.  chunk: a multiple of NP giving about 256 chunks
+    if ((groups == 1 && k >= c->pip_threshold) || (groups > 1 && groups <= 65535 && k >= c->pip_group_threshold)) {
+        // bucket method: one large sum is cut into about 256 chunks; a batch of sums uses one chunk per group
         using P = blsgpu::PipCfg<DEG>;
         size_t want = 256;
         if (const char* e = getenv("BLSGPU_PIP_CHUNKS")) want = (size_t)strtoull(e, nullptr, 10);
-        size_t chunk = (k + want - 1) / want;
-        if (chunk < 64 * (size_t)C::NP) chunk = 64 * (size_t)C::NP;
+        size_t chunk = (groups > 1) ? k : (k + want - 1) / want;
+        if (chunk < 64 * (size_t)C::NP && groups == 1) chunk = 64 * (size_t)C::NP;
         chunk = ((chunk + C::NP - 1) / C::NP) * C::NP;
         size_t chunks = (k + chunk - 1) / chunk;
-        size_t need = (chunks + 1) * blsgpu::PIP_W * 36 * DEG + k * 36 * DEG;
+        size_t n = k * groups;
+        size_t need = (chunks + 1) * groups * blsgpu::PIP_W * 36 * DEG + n * 36 * DEG;
         if (need > c->msm_part_cap) {
             if (c->d_msm_part) (void)hipFree(c->d_msm_part);
             c->d_msm_part = nullptr;
@@ -167,19 +169,19 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
             HIP_TRY(hipMalloc((void**)&c->d_msm_part, need * sizeof(uint32_t)));
             c->msm_part_cap = need;
         }
-        uint32_t* d_win = c->d_msm_part + chunks * blsgpu::PIP_W * 36 * DEG;
-        uint32_t* d_prep = d_win + blsgpu::PIP_W * 36 * DEG;
-        size_t pblocks = (k + (size_t)MSM_WAVES * C::NP - 1) / ((size_t)MSM_WAVES * C::NP);
+        uint32_t* d_win = c->d_msm_part + chunks * groups * blsgpu::PIP_W * 36 * DEG;
+        uint32_t* d_prep = d_win + groups * blsgpu::PIP_W * 36 * DEG;
+        size_t pblocks = (n + (size_t)MSM_WAVES * C::NP - 1) / ((size_t)MSM_WAVES * C::NP);
         hipLaunchKernelGGL(blsgpu::k_msm_prep<DEG>, dim3((unsigned)pblocks), dim3(MSM_WAVES * 64), (size_t)MSM_WAVES * blsgpu::TEAM_BYTES,
-                           st, c->tabs, (const uint32_t*)d_pts, (uint32_t)k, d_prep);
+                           st, c->tabs, (const uint32_t*)d_pts, (uint32_t)n, d_prep);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(blsgpu::k_msm_pip<DEG>, dim3((unsigned)chunks, blsgpu::PIP_W), dim3(64), (size_t)P::SLOTS * 48, st,
-                           c->tabs, d_prep, (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, c->d_msm_part);
+        hipLaunchKernelGGL(blsgpu::k_msm_pip<DEG>, dim3((unsigned)chunks, blsgpu::PIP_W, (unsigned)groups), dim3(64), (size_t)P::SLOTS * 48,
+                           st, c->tabs, d_prep, (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, c->d_msm_part);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(blsgpu::k_msm_pip_windows<DEG>, dim3(blsgpu::PIP_W), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs,
-                           c->d_msm_part, (uint32_t)chunks, d_win);
+        hipLaunchKernelGGL(blsgpu::k_msm_pip_windows<DEG>, dim3(blsgpu::PIP_W, (unsigned)groups), dim3(64), (size_t)blsgpu::TEAM_BYTES, st,
+                           c->tabs, c->d_msm_part, (uint32_t)chunks, d_win);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(blsgpu::k_msm_pip_horner<DEG>, dim3(1), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, d_win,
+        hipLaunchKernelGGL(blsgpu::k_msm_pip_horner<DEG>, dim3((unsigned)groups), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, d_win,
                            (uint32_t*)d_out, (uint8_t*)d_out_inf);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -267,6 +269,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     c->device = device;
     c->mp_threshold = default_mp_threshold();
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     // pack all tables into one device allocation (16-byte aligned pieces)
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     size_t o_m = 0;

@@ -253,7 +253,8 @@ __global__ void __launch_bounds__(64, 2) k_msm_pip(VmTables T, const uint32_t* _
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t win = blockIdx.y;
-    const uint32_t lo = blockIdx.x * chunk, hi = min(k, lo + chunk);
+    const uint32_t grp = blockIdx.z;                           // independent sums: group g owns points [g k, (g + 1) k)
+    const uint32_t lo = grp * k + blockIdx.x * chunk, hi = min(grp * k + k, lo + chunk);
     team_init_consts(T, team, lane);
     wave_fence();
     for (uint32_t d = lane; d < C::NP * PIP_NB * PJ_DW; d += 64) team[P::BUCKET0 * 12 + d] = inf_dword<DEG>(team, d % PJ_DW);
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(64, 2) k_msm_pip(VmTables T, const uint32_t* _
     }
     // R_p = tot_p already; fold the NP totals
     run_rounds<true>(T, T.segflat + C::FOLD_OFF, C::FOLD_LEN, 0, lane);
-    uint32_t* dst = partials + ((size_t)win * gridDim.x + blockIdx.x) * PJ_DW;
+    uint32_t* dst = partials + (((size_t)grp * PIP_W + win) * gridDim.x + blockIdx.x) * PJ_DW;
     for (uint32_t i = lane; i < PJ_DW; i += 64) dst[i] = team[C::PR0 * 12 + i];
 }
 
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(64) k_msm_pip_windows(VmTables T, const uint32
     constexpr uint32_t PJ_DW = 36 * DEG;
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t win = blockIdx.x;
+    const uint32_t win = blockIdx.x + blockIdx.y * PIP_W;      // blockIdx.y = group
     team_init_consts(T, team, lane);
     wave_fence();
     for (uint32_t i = 0; i < chunks; i++) {
@@ -362,6 +363,8 @@ __global__ void __launch_bounds__(64) k_msm_pip_horner(VmTables T, const uint32_
     const uint32_t lane = threadIdx.x & 63u;
     team_init_consts(T, team, lane);
     wave_fence();
+    winsums += (size_t)blockIdx.x * PIP_W * PJ_DW;              // blockIdx.x = group
+    out += (size_t)blockIdx.x * PT_DW;
     for (uint32_t d = lane; d < PJ_DW; d += 64) team[C::PR0 * 12 + d] = winsums[(size_t)(PIP_W - 1) * PJ_DW + d];
     wave_fence();
     for (int w = PIP_W - 2; w >= 0; w--) {
@@ -386,7 +389,7 @@ __global__ void __launch_bounds__(64) k_msm_pip_horner(VmTables T, const uint32_
         out[d] = bswap32(v);
     }
     const uint64_t nz = __ballot(any != 0);
-    if (out_inf && lane == 0) out_inf[0] = (nz == 0) ? 1 : 0;
+    if (out_inf && lane == 0) out_inf[blockIdx.x] = (nz == 0) ? 1 : 0;
 }
 
 }  // namespace blsgpu

@@ -114,15 +114,18 @@ def pip_engine():
     """An engine whose single sums use the bucket method from 1 point on."""
     import os
     from bls_py import _native
-    old = os.environ.get("BLSGPU_PIP_THRESHOLD")
-    os.environ["BLSGPU_PIP_THRESHOLD"] = "1"
+    names = ("BLSGPU_PIP_THRESHOLD", "BLSGPU_PIP_GROUP_THRESHOLD")
+    old = {k: os.environ.get(k) for k in names}
+    for k in names:
+        os.environ[k] = "1"
     try:
         e = _native.Engine(0)
     finally:
-        if old is None:
-            del os.environ["BLSGPU_PIP_THRESHOLD"]
-        else:
-            os.environ["BLSGPU_PIP_THRESHOLD"] = old
+        for k in names:
+            if old[k] is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = old[k]
     return e
 
 
@@ -166,3 +169,20 @@ def test_aggregate_pub_keys_1024_bucket_method(pip_engine, golden):
     ts = [int.from_bytes(hashlib.sha256(i.to_bytes(4, "big") + digest).digest(), "big") % N for i in range(n)]
     assert pip_engine.g1_msm(b"".join(pts), ts, n)[0].hex() == rec["secure_affine"]
     assert pip_engine.g1_msm(b"".join(pts), None, n)[0].hex() == rec["simple_affine"]
+
+
+@pytest.mark.parametrize("k,groups", [(1, 3), (5, 4), (7, 2), (67, 3), (100, 2)])
+def test_bucket_method_batches_vs_oracle(pip_engine, oracle, seeded_pairs, k, groups):
+    """Batches of independent sums through the bucket kernels (one chunk per group)."""
+    g1, g2 = seeded_pairs
+    rnd = random.Random(k * 7 + groups)
+    n = k * groups
+    pts1, pts2 = g1[96 * 20:96 * (20 + n)], g2[192 * 20:192 * (20 + n)]
+    sc = [rnd.choice([rnd.randrange(N), rnd.randrange(1 << 40), 0, N - 1]) for _ in range(n)]
+    out1, inf1 = pip_engine.g1_msm(pts1, sc, k, groups)
+    out2, inf2 = pip_engine.g2_msm(pts2, sc, k, groups)
+    for g in range(groups):
+        w1, _ = oracle.g1_msm(pts1[96 * k * g:96 * k * (g + 1)], sc[k * g:k * (g + 1)], k)
+        w2, _ = oracle.g2_msm(pts2[192 * k * g:192 * k * (g + 1)], sc[k * g:k * (g + 1)], k)
+        assert out1[96 * g:96 * (g + 1)] == w1 and inf1[g] == (w1 == bytes(96))
+        assert out2[192 * g:192 * (g + 1)] == w2 and inf2[g] == (w2 == bytes(192))
