@@ -98,16 +98,49 @@ static int ensure_workspace(blsgpu_ctx* c, size_t max_pairs) {
     return 0;
 }
 
+// fixed-exponent powers on a stage image (blsgpu_h2c.hip)
+static int launch_pow(blsgpu_ctx* c, uint32_t* img, uint32_t img_slots, uint32_t base_off, uint32_t acc_off, size_t teams, uint32_t cnt,
+                      hipStream_t st) {
+    size_t total = teams * cnt;
+    hipLaunchKernelGGL(blsgpu::k_pow, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, img_slots, base_off, acc_off, cnt,
+                       (uint32_t)total);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------ decompression --
 namespace {
 template <int DEG>
 int decompress_dev(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out, void* d_ok, hipStream_t st) {
     using C = blsgpu::DecompCfg<DEG>;
     if (n == 0) return 0;
-    if (n > 0x3FFFFFF0ull) return fail(-EINVAL, "batch too large");
-    unsigned blocks = (unsigned)((n + C::NE - 1) / C::NE);
-    hipLaunchKernelGGL(blsgpu::k_decompress<DEG>, dim3(blocks), dim3(64), (size_t)C::SLOTS * 48, st, c->tabs,
-                       (const uint32_t*)d_in, (uint32_t)n, (uint32_t*)d_out, (uint8_t*)d_ok);
+    if (n > 0x0FFFFFF0ull) return fail(-EINVAL, "batch too large");
+    const size_t teams = (n + C::NE - 1) / C::NE;
+    size_t need = teams * C::IMG * 12;
+    if (need > c->msm_part_cap) {
+        if (c->d_msm_part) (void)hipFree(c->d_msm_part);
+        c->d_msm_part = nullptr;
+        c->msm_part_cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_msm_part, need * sizeof(uint32_t)));
+        c->msm_part_cap = need;
+    }
+    uint32_t* img = c->d_msm_part;
+    const size_t lds = (size_t)C::SLOTS * 48;
+    constexpr uint32_t BASE = C::BASE - C::STATE0, ACC = C::ACC - C::STATE0;
+    hipLaunchKernelGGL((blsgpu::k_decompress<DEG, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)d_in,
+                       (uint32_t)n, img, (uint32_t*)d_out, (uint8_t*)d_ok);
+    HIP_TRY(hipGetLastError());
+    int rc = launch_pow(c, img, C::IMG, BASE, ACC, teams, C::NE, st);
+    if (rc) return rc;
+    if (DEG == 2) {
+        hipLaunchKernelGGL((blsgpu::k_decompress<DEG, 1>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)d_in,
+                           (uint32_t)n, img, (uint32_t*)d_out, (uint8_t*)d_ok);
+        HIP_TRY(hipGetLastError());
+        rc = launch_pow(c, img, C::IMG, BASE, ACC, teams, 2 * C::NE, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL((blsgpu::k_decompress<DEG, 2>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)d_in,
+                       (uint32_t)n, img, (uint32_t*)d_out, (uint8_t*)d_ok);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -274,12 +307,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     size_t o_m = 0;
     size_t o_mp = o_m + al(sizeof(BLSVM_MILLER_FLAT));
-    size_t o_h1 = o_mp + al(sizeof(BLSVM_MP_FLAT));
-    size_t o_h1w = o_h1 + al(sizeof(BLSVM_H1_FLAT));
-    size_t o_h2 = o_h1w + al(sizeof(BLSVM_H1W_FLAT));
-    size_t o_d1 = o_h2 + al(sizeof(BLSVM_H2_FLAT));
-    size_t o_d2 = o_d1 + al(sizeof(BLSVM_D1_FLAT));
-    size_t o_f = o_d2 + al(sizeof(BLSVM_D2_FLAT));
+    size_t o_h2 = o_mp + al(sizeof(BLSVM_MP_FLAT));
+    size_t o_f = o_h2 + al(sizeof(BLSVM_H2_FLAT));
     size_t o_s = o_f + al(sizeof(BLSVM_FEXP_FLAT));
     size_t o_data = o_s + al(sizeof(BLSVM_SEG_FLAT));
     size_t o_c = o_data + al(sizeof(BLSVM_DATA));
@@ -291,8 +320,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     char* base = (char*)c->d_tables;
     struct { size_t off; const void* src; size_t len; } parts[] = {
         {o_m, BLSVM_MILLER_FLAT, sizeof(BLSVM_MILLER_FLAT)}, {o_mp, BLSVM_MP_FLAT, sizeof(BLSVM_MP_FLAT)},
-        {o_h1, BLSVM_H1_FLAT, sizeof(BLSVM_H1_FLAT)},        {o_h1w, BLSVM_H1W_FLAT, sizeof(BLSVM_H1W_FLAT)},        {o_h2, BLSVM_H2_FLAT, sizeof(BLSVM_H2_FLAT)},
-        {o_d1, BLSVM_D1_FLAT, sizeof(BLSVM_D1_FLAT)},        {o_d2, BLSVM_D2_FLAT, sizeof(BLSVM_D2_FLAT)},
+        {o_h2, BLSVM_H2_FLAT, sizeof(BLSVM_H2_FLAT)},
         {o_f, BLSVM_FEXP_FLAT, sizeof(BLSVM_FEXP_FLAT)},
         {o_s, BLSVM_SEG_FLAT, sizeof(BLSVM_SEG_FLAT)},       {o_data, BLSVM_DATA, sizeof(BLSVM_DATA)},
         {o_c, BLSVM_CONSTS, sizeof(BLSVM_CONSTS)}};
@@ -305,11 +333,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     }
     c->tabs.mflat = (const uint2*)(base + o_m);
     c->tabs.mpflat = (const uint2*)(base + o_mp);
-    c->tabs.h1flat = (const uint2*)(base + o_h1);
-    c->tabs.h1wflat = (const uint2*)(base + o_h1w);
     c->tabs.h2flat = (const uint2*)(base + o_h2);
-    c->tabs.d1flat = (const uint2*)(base + o_d1);
-    c->tabs.d2flat = (const uint2*)(base + o_d2);
     c->tabs.fflat = (const uint2*)(base + o_f);
     c->tabs.segflat = (const uint2*)(base + o_s);
     c->tabs.data = (const uint16_t*)(base + o_data);
@@ -331,16 +355,17 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
                               MILLER_WAVES * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize,
                               REDUCE_WAVES * blsgpu::TEAM_BYTES);
-    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_encode<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              blsgpu::H1_TEAM_DW * 4);
-    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_encode<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              blsgpu::H1_TEAM_DW * 4);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_stage<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, blsgpu::H1_TEAM_DW * 4);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_stage<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, blsgpu::H1_TEAM_DW * 4);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_stage<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, blsgpu::H1_TEAM_DW * 4);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_stage<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, blsgpu::H1_TEAM_DW * 4);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_h2c_clear, hipFuncAttributeMaxDynamicSharedMemorySize,
                               blsgpu::H2_TEAM_DW * 4);
-    (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              BLSVM_D1_SLOTS * 48);
-    (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              BLSVM_D2_SLOTS * 48);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, BLSVM_D1_SLOTS * 48);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BLSVM_D1_SLOTS * 48);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, BLSVM_D2_SLOTS * 48);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, BLSVM_D2_SLOTS * 48);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BLSVM_D2_SLOTS * 48);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_miller_mp, hipFuncAttributeMaxDynamicSharedMemorySize,
                               blsgpu::MP_TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_final_groups, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -675,11 +700,12 @@ BLSGPU_EXPORT int blsgpu_g2_msm_dev(blsgpu_ctx* c, const void* d_pts, const void
 // ------------------------------------------------------------ hash to G2 -----
 // t: n x 192 bytes = (t0.c0, t0.c1, t1.c0, t1.c1) canonical big-endian, the four
 // hash512 values of ec.py:531-534 reduced mod q; out: n x 192 bytes affine G2.
-// wide = 0: d_in = t values (n x 192 bytes); wide = 1: d_in = message hashes (n x 32 bytes)
+// from_hashes: d_in = message hashes (n x 32 bytes), else t values (n x 192 bytes)
 static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out, hipStream_t st, bool from_hashes) {
     if (n == 0) return 0;
-    if (n > 0x0FFFFFF0ull) return fail(-EINVAL, "batch too large");
-    size_t need = 2 * n * 60 + (from_hashes ? n * 64 : 0);     // encodings (+ digests), u32
+    if (n > 0x03FFFFF0ull) return fail(-EINVAL, "batch too large");
+    const size_t teams = (2 * n + BLSVM_H1_NE - 1) / BLSVM_H1_NE;
+    size_t need = teams * blsgpu::H1_IMG * 12 + (from_hashes ? n * 64 : 0);     // stage image (+ digests), u32
     if (need > c->msm_part_cap) {
         if (c->d_msm_part) (void)hipFree(c->d_msm_part);
         c->d_msm_part = nullptr;
@@ -687,22 +713,33 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
         HIP_TRY(hipMalloc((void**)&c->d_msm_part, need * sizeof(uint32_t)));
         c->msm_part_cap = need;
     }
-    uint32_t* d_enc = c->d_msm_part;
-    unsigned b1 = (unsigned)((2 * n + BLSVM_H1_NE - 1) / BLSVM_H1_NE);
+    uint32_t* img = c->d_msm_part;
+    const size_t lds = (size_t)blsgpu::H1_TEAM_DW * 4;
+    constexpr uint32_t BASE = BLSVM_H1_BASE - BLSVM_H1_STATE0, ACC = BLSVM_H1_ACC - BLSVM_H1_STATE0;
     if (from_hashes) {
-        uint32_t* d_dig = c->d_msm_part + 2 * n * 60;
+        uint32_t* d_dig = img + teams * blsgpu::H1_IMG * 12;
         hipLaunchKernelGGL(blsgpu::k_h2c_hash, dim3((unsigned)((8 * n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_in,
                            (uint32_t)n, d_dig);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(blsgpu::k_h2c_encode<1>, dim3(b1), dim3(64), (size_t)blsgpu::H1_TEAM_DW * 4, st, c->tabs,
-                           (const uint32_t*)d_dig, (uint32_t)(2 * n), d_enc);
+        hipLaunchKernelGGL((blsgpu::k_h2c_stage<0, 1>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)d_dig,
+                           (uint32_t)(2 * n), img);
     } else {
-        hipLaunchKernelGGL(blsgpu::k_h2c_encode<0>, dim3(b1), dim3(64), (size_t)blsgpu::H1_TEAM_DW * 4, st, c->tabs,
-                           (const uint32_t*)d_in, (uint32_t)(2 * n), d_enc);
+        hipLaunchKernelGGL((blsgpu::k_h2c_stage<0, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)d_in,
+                           (uint32_t)(2 * n), img);
     }
     HIP_TRY(hipGetLastError());
+    int rc = launch_pow(c, img, blsgpu::H1_IMG, BASE, ACC, teams, 3 * BLSVM_H1_NE, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((blsgpu::k_h2c_stage<1, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,
+                       (uint32_t)(2 * n), img);
+    HIP_TRY(hipGetLastError());
+    rc = launch_pow(c, img, blsgpu::H1_IMG, BASE, ACC, teams, 2 * BLSVM_H1_NE, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((blsgpu::k_h2c_stage<2, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,
+                       (uint32_t)(2 * n), img);
+    HIP_TRY(hipGetLastError());
     unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);
-    hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, d_enc, (uint32_t)n,
+    hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, img, (uint32_t)n,
                        (uint32_t*)d_out);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -791,13 +828,13 @@ BLSGPU_EXPORT int blsgpu_debug_stamps(blsgpu_ctx* c, unsigned long long out[9]) 
     return 0;
 }
 // diagnostic build: load a whole scratchpad image (nslots x 12 u32), run the first `nrounds`
-// rounds of flat program `which` (0 miller, 1 multi-pair, 2 final exp, 3 h1, 4 h2, 5 d1, 6 d2)
+// rounds of flat program `which` (0 miller, 1 multi-pair, 2 final exp, 3 h2)
 // on one team and copy the image back -- lets tools/trace_rounds.py bisect a wrong result
 // against vmgen/tablesim.py round by round
 BLSGPU_EXPORT int blsgpu_debug_run(blsgpu_ctx* c, int which, unsigned nrounds, unsigned nslots, uint32_t* image) {
     if (!c || !image || nslots == 0 || nslots > 1023) return fail(-EINVAL, "bad argument");
-    const uint2* seqs[7] = {c->tabs.mflat, c->tabs.mpflat, c->tabs.fflat, c->tabs.h1flat, c->tabs.h2flat, c->tabs.d1flat, c->tabs.d2flat};
-    if (which < 0 || which > 6) return fail(-EINVAL, "bad program");
+    const uint2* seqs[4] = {c->tabs.mflat, c->tabs.mpflat, c->tabs.fflat, c->tabs.h2flat};
+    if (which < 0 || which > 3) return fail(-EINVAL, "bad program");
     uint32_t* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, (size_t)nslots * 48));
     HIP_TRY(hipMemcpy(d, image, (size_t)nslots * 48, hipMemcpyHostToDevice));

@@ -76,45 +76,99 @@ __global__ void __launch_bounds__(256) k_h2c_hash(const uint32_t* __restrict__ m
     for (int k = 0; k < 8; k++) digests[((size_t)i * 4 + (t >> 1)) * 16 + half * 8 + k] = bswap32(d[k]);
 }
 
-// Kernel H1: one team = BLSVM_H1_NE encodings.  WIDE = 0: t is n_enc x 96 bytes (c0 || c1,
-// big-endian, < 2^384); WIDE = 1: t is n_enc x 128 bytes (two 512-bit big-endian hash
-// values, reduced mod q here).  out: n_enc x 60 u32 = (x, y, z.c0) in Montgomery limbs,
-// z = 0 for infinity.
-template <int WIDE>
-__global__ void __launch_bounds__(64, 2) k_h2c_encode(VmTables T, const uint32_t* __restrict__ t, uint32_t n_enc,
-                                                      uint32_t* __restrict__ out) {
+// ---------------------------------------------------------------------------
+// Fixed-exponent powers x^((q-3)/4) -- the square-root / Legendre-symbol exponent of
+// vmgen/h2c_programs.py and decomp_programs.py -- in registers, one value per lane: 379
+// squarings + 190 products with no table, no LDS.  The VM programs around it are cut into
+// stages that hand their scratchpad state over through an image in HBM:
+//   stage kernel (few rounds) -> k_pow on the image's BASE slots -> next stage kernel ...
+// image: per team the slots [STATE0, STATE1) of its scratchpad, 12 u32 each.
+// k_pow: value v = (team v / cnt, index v % cnt): ACC[index] <- BASE[index]^E (Montgomery, < 2q).
+__global__ void __launch_bounds__(256) k_pow(uint32_t* __restrict__ img, uint32_t img_slots, uint32_t base_off, uint32_t acc_off,
+                                             uint32_t cnt, uint32_t total) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= total) return;
+    const uint32_t team = v / cnt, k = v % cnt;
+    const uint32_t* src = img + ((size_t)team * img_slots + base_off + k) * 12;
+    uint32_t* dst = img + ((size_t)team * img_slots + acc_off + k) * 12;
+    uint32_t b[12], a[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { b[j] = src[j]; a[j] = b[j]; }
+    const uint32_t e[12] = {BLSVM_POW_E[0], BLSVM_POW_E[1], BLSVM_POW_E[2],  BLSVM_POW_E[3],  BLSVM_POW_E[4], BLSVM_POW_E[5],
+                            BLSVM_POW_E[6], BLSVM_POW_E[7], BLSVM_POW_E[8],  BLSVM_POW_E[9],  BLSVM_POW_E[10], BLSVM_POW_E[11]};
+#pragma unroll 1
+    for (int bit = BLSVM_POW_E_BITS - 2; bit >= 0; bit--) {
+        uint32_t t[12];
+        bls::fq_mul_relaxed(t, a, a);
+        if ((e[bit >> 5] >> (bit & 31)) & 1u) bls::fq_mul_relaxed(a, t, b);
+        else {
+#pragma unroll
+            for (int j = 0; j < 12; j++) a[j] = t[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) dst[j] = a[j];
+}
+
+__device__ __forceinline__ void img_load(uint32_t* team, const uint32_t* __restrict__ img, uint32_t state0, uint32_t nslots, uint32_t lane) {
+    for (uint32_t d = lane; d < nslots * 12; d += 64) team[state0 * 12 + d] = img[d];
+}
+__device__ __forceinline__ void img_store(const uint32_t* team, uint32_t* __restrict__ img, uint32_t state0, uint32_t nslots, uint32_t lane) {
+    for (uint32_t d = lane; d < nslots * 12; d += 64) img[d] = team[state0 * 12 + d];
+}
+
+constexpr uint32_t H1_IMG = BLSVM_H1_STATE1 - BLSVM_H1_STATE0;       // image slots per team
+
+// Hash-to-G2 stage STAGE of the encodings (one team = BLSVM_H1_NE encodings):
+//   0: inputs -> h1_a / h1w_a (candidates, norms)         -> image   [then k_pow on 3 NE values]
+//   1: image -> h1_b (pick the candidate, delta+-)         -> image   [then k_pow on 2 NE values]
+//   2: image -> h1_c (root, sign, result S)                -> image   (k_h2c_clear reads S from it)
+// WIDE = 0: t is n_enc x 96 bytes (c0 || c1, big-endian, < 2^384); WIDE = 1: n_enc x 128
+// bytes (two 512-bit big-endian hash values, reduced mod q in h1w_a).
+template <int STAGE, int WIDE>
+__global__ void __launch_bounds__(64, 2) k_h2c_stage(VmTables T, const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t* __restrict__ img) {
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t first = blockIdx.x * BLSVM_H1_NE;
+    uint32_t* my = img + (size_t)blockIdx.x * H1_IMG * 12;
     team_init_consts_h2c(T, team, lane);
-    if (WIDE) {
-        for (uint32_t d = lane; d < BLSVM_H1_NE * 24; d += 64) team[BLSVM_H1_TH * 12 + d] = 0u;
-        wave_fence();
-        for (uint32_t d = lane; d < BLSVM_H1_NE * 32; d += 64) {
-            const uint32_t e = d / 32, o = d % 32, c = o / 16, w = o % 16;     // dword w of the 64-byte value, MSB first
-            // encodings past the end run on t = (1, 0); their results are dropped
-            uint32_t v = (first + e < n_enc) ? bswap32(t[(size_t)(first + e) * 32 + o]) : ((c == 0 && w == 15) ? 1u : 0u);
-            if (w < 4) team[(BLSVM_H1_TH + 2 * e + c) * 12 + (3 - w)] = v;     // bits 384..511
-            else team[(BLSVM_H1_T + 2 * e + c) * 12 + (15 - w)] = v;           // bits 0..383
+    if (STAGE == 0) {
+        if (WIDE) {
+            for (uint32_t d = lane; d < BLSVM_H1_NE * 24; d += 64) team[BLSVM_H1_TH * 12 + d] = 0u;
+            wave_fence();
+            for (uint32_t d = lane; d < BLSVM_H1_NE * 32; d += 64) {
+                const uint32_t e = d / 32, o = d % 32, c = o / 16, w = o % 16;     // dword w of the 64-byte value, MSB first
+                // encodings past the end run on t = (1, 0); their results are dropped
+                uint32_t v = (first + e < n_enc) ? bswap32(t[(size_t)(first + e) * 32 + o]) : ((c == 0 && w == 15) ? 1u : 0u);
+                if (w < 4) team[(BLSVM_H1_TH + 2 * e + c) * 12 + (3 - w)] = v;     // bits 384..511
+                else team[(BLSVM_H1_T + 2 * e + c) * 12 + (15 - w)] = v;           // bits 0..383
+            }
+        } else {
+            for (uint32_t d = lane; d < BLSVM_H1_NE * 24; d += 64) {
+                uint32_t e = d / 24, o = d % 24, c = o / 12, w = o % 12;
+                uint32_t v = (first + e < n_enc) ? bswap32(t[(size_t)(first + e) * 24 + o]) : ((c == 0 && w == 11) ? 1u : 0u);
+                team[(BLSVM_H1_T + 2 * e + c) * 12 + (11 - w)] = v;
+            }
         }
     } else {
-        for (uint32_t d = lane; d < BLSVM_H1_NE * 24; d += 64) {
-            uint32_t e = d / 24, o = d % 24, c = o / 12, w = o % 12;
-            uint32_t v = (first + e < n_enc) ? bswap32(t[(size_t)(first + e) * 24 + o]) : ((c == 0 && w == 11) ? 1u : 0u);
-            team[(BLSVM_H1_T + 2 * e + c) * 12 + (11 - w)] = v;
-        }
+        img_load(team, my, BLSVM_H1_STATE0, H1_IMG, lane);
     }
     wave_fence();
-    if (WIDE) run_rounds(T, T.h1wflat, BLSVM_H1W_FLAT_LEN, 0, lane);
-    else run_rounds(T, T.h1flat, BLSVM_H1_FLAT_LEN, 0, lane);
-    for (uint32_t d = lane; d < BLSVM_H1_NE * 60; d += 64) {
-        uint32_t e = d / 60;
-        if (first + e < n_enc) out[(size_t)first * 60 + d] = team[BLSVM_H1_S * 12 + d];
+    if (STAGE == 0) {
+        if (WIDE) run_rounds(T, T.segflat + BLSVM_SEGF_H1W_A_OFF, BLSVM_SEGF_H1W_A_LEN, 0, lane);
+        else run_rounds(T, T.segflat + BLSVM_SEGF_H1_A_OFF, BLSVM_SEGF_H1_A_LEN, 0, lane);
+    } else if (STAGE == 1) {
+        run_rounds<true>(T, T.segflat + BLSVM_SEGF_H1_B_OFF, BLSVM_SEGF_H1_B_LEN, 0, lane);
+    } else {
+        run_rounds(T, T.segflat + BLSVM_SEGF_H1_C_OFF, BLSVM_SEGF_H1_C_LEN, 0, lane);
     }
+    wave_fence();
+    img_store(team, my, BLSVM_H1_STATE0, H1_IMG, lane);
 }
 
 // Kernel H2: one team = BLSVM_H2_NM messages: P = S0 + S1, cofactor clearing,
 // canonical affine bytes (x.c0 || x.c1 || y.c0 || y.c1, 192 B per message).
+// enc = the stage image: encoding e sits in team e / NE, slots S + 5 (e % NE) .. + 5.
 __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg,
                                                      uint32_t* __restrict__ out) {
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
@@ -124,7 +178,8 @@ __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t*
     for (uint32_t d = lane; d < BLSVM_H2_NM * 120; d += 64) {
         uint32_t m = d / 120;
         uint32_t src_m = (first + m < n_msg) ? first + m : first;       // pad with a valid message
-        team[BLSVM_H2_S * 12 + d] = enc[(size_t)src_m * 120 + (d % 120)];
+        const uint32_t e = 2 * src_m + (d % 120) / 60;                             // encoding index
+        team[BLSVM_H2_S * 12 + d] = enc[((size_t)(e / BLSVM_H1_NE) * H1_IMG + (BLSVM_H1_S - BLSVM_H1_STATE0) + 5 * (e % BLSVM_H1_NE)) * 12 + d % 60];
     }
     wave_fence();
     run_rounds(T, T.h2flat, BLSVM_H2_FLAT_LEN, 0, lane);
@@ -151,46 +206,64 @@ __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t*
 template <int DEG> struct DecompCfg;
 template <> struct DecompCfg<1> {
     static constexpr int NE = BLSVM_D1_NE, SLOTS = BLSVM_D1_SLOTS, X = BLSVM_D1_X, BIG = BLSVM_D1_BIG, OUT = BLSVM_D1_OUT,
-                         LEN = BLSVM_D1_FLAT_LEN;
-    static __device__ __forceinline__ const uint2* flat(const VmTables& T) { return T.d1flat; }
+                         ACC = BLSVM_D1_ACC, BASE = BLSVM_D1_BASE, STATE0 = BLSVM_D1_STATE0, IMG = BLSVM_D1_STATE1 - BLSVM_D1_STATE0;
+    static __host__ __device__ constexpr uint32_t seg_off(int stage) { return stage == 0 ? BLSVM_SEGF_D1_A_OFF : BLSVM_SEGF_D1_C_OFF; }
+    static __host__ __device__ constexpr uint32_t seg_len(int stage) { return stage == 0 ? BLSVM_SEGF_D1_A_LEN : BLSVM_SEGF_D1_C_LEN; }
 };
 template <> struct DecompCfg<2> {
     static constexpr int NE = BLSVM_D2_NE, SLOTS = BLSVM_D2_SLOTS, X = BLSVM_D2_X, BIG = BLSVM_D2_BIG, OUT = BLSVM_D2_OUT,
-                         LEN = BLSVM_D2_FLAT_LEN;
-    static __device__ __forceinline__ const uint2* flat(const VmTables& T) { return T.d2flat; }
+                         ACC = BLSVM_D2_ACC, BASE = BLSVM_D2_BASE, STATE0 = BLSVM_D2_STATE0, IMG = BLSVM_D2_STATE1 - BLSVM_D2_STATE0;
+    static __host__ __device__ constexpr uint32_t seg_off(int stage) {
+        return stage == 0 ? BLSVM_SEGF_D2_A_OFF : (stage == 1 ? BLSVM_SEGF_D2_B_OFF : BLSVM_SEGF_D2_C_OFF);
+    }
+    static __host__ __device__ constexpr uint32_t seg_len(int stage) {
+        return stage == 0 ? BLSVM_SEGF_D2_A_LEN : (stage == 1 ? BLSVM_SEGF_D2_B_LEN : BLSVM_SEGF_D2_C_LEN);
+    }
 };
 
-template <int DEG>
-__global__ void __launch_bounds__(64, 2) k_decompress(VmTables T, const uint32_t* __restrict__ in, uint32_t n,
+// Stages: 0: bytes -> d*_a -> image [k_pow]; (DEG 2 only) 1: image -> d2_b -> image [k_pow];
+// 2: image -> d*_c -> canonical bytes + accept flags.
+template <int DEG, int STAGE>
+__global__ void __launch_bounds__(64, 2) k_decompress(VmTables T, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ img,
                                                       uint32_t* __restrict__ out, uint8_t* __restrict__ ok) {
     using C = DecompCfg<DEG>;
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t first = blockIdx.x * C::NE;
+    uint32_t* my = img + (size_t)blockIdx.x * C::IMG * 12;
     team_init_consts_h2c(T, team, lane);
     wave_fence();
-    constexpr uint32_t DW_IN = 12 * DEG;                       // dwords per encoded point
-    for (uint32_t d = lane; d < C::NE * DW_IN; d += 64) {
-        const uint32_t e = d / DW_IN, o = d % DW_IN, c = o / 12, w = o % 12;
-        // points past the end decode x = 0 (any value would do; their results are dropped)
-        uint32_t v = (first + e < n) ? bswap32(in[(size_t)(first + e) * DW_IN + o]) : 0u;
-        if (o == 0) {                                          // byte 0 carries the flags
-            team[(C::BIG + e) * 12] = (v >> 31) ? 1u : 0u;     // raw 1 / 0, made Montgomery below
-            v &= 0x1FFFFFFFu;
+    if (STAGE == 0) {
+        constexpr uint32_t DW_IN = 12 * DEG;                       // dwords per encoded point
+        for (uint32_t d = lane; d < C::NE * DW_IN; d += 64) {
+            const uint32_t e = d / DW_IN, o = d % DW_IN, c = o / 12, w = o % 12;
+            // points past the end decode x = 0 (any value would do; their results are dropped)
+            uint32_t v = (first + e < n) ? bswap32(in[(size_t)(first + e) * DW_IN + o]) : 0u;
+            if (o == 0) {                                          // byte 0 carries the flags
+                team[(C::BIG + e) * 12] = (v >> 31) ? 1u : 0u;     // raw 1 / 0, made Montgomery below
+                v &= 0x1FFFFFFFu;
+            }
+            team[(C::X + DEG * e + c) * 12 + (11 - w)] = v;
         }
-        team[(C::X + DEG * e + c) * 12 + (11 - w)] = v;
+        for (uint32_t d = lane; d < C::NE * 11; d += 64) team[(C::BIG + d / 11) * 12 + 1 + d % 11] = 0u;
+        wave_fence();
+        if (lane < (uint32_t)C::NE) {                              // flag -> Montgomery 0 / 1
+            const uint32_t onem[12] = BLS_ONE_MONT_LIMBS;
+            const bool big = team[(C::BIG + lane) * 12] != 0u;
+            for (int j = 0; j < 12; j++) team[(C::BIG + lane) * 12 + j] = big ? onem[j] : 0u;
+        }
+    } else {
+        img_load(team, my, C::STATE0, C::IMG, lane);
     }
-    for (uint32_t d = lane; d < C::NE * 11; d += 64) team[(C::BIG + d / 11) * 12 + 1 + d % 11] = 0u;
     wave_fence();
-    if (lane < (uint32_t)C::NE) {                              // flag -> Montgomery 0 / 1
-        const uint32_t onem[12] = BLS_ONE_MONT_LIMBS;
-        const bool big = team[(C::BIG + lane) * 12] != 0u;
-        for (int j = 0; j < 12; j++) team[(C::BIG + lane) * 12 + j] = big ? onem[j] : 0u;
+    run_rounds(T, T.segflat + C::seg_off(STAGE), C::seg_len(STAGE), 0, lane);
+    wave_fence();
+    if (STAGE != 2) {
+        img_store(team, my, C::STATE0, C::IMG, lane);
+        return;
     }
-    wave_fence();
-    run_rounds(T, C::flat(T), C::LEN, 0, lane);
-    constexpr uint32_t NOUT = 2 * DEG + 1;                     // x, y coordinates and the flag
-    for (uint32_t d = lane; d < C::NE * NOUT; d += 64) {       // relaxed -> canonical residues
+    constexpr uint32_t NOUT = 2 * DEG + 1;                         // x, y coordinates and the flag
+    for (uint32_t d = lane; d < C::NE * NOUT; d += 64) {           // relaxed -> canonical residues
         uint32_t X[12];
         lds_load12(X, (C::OUT + d) * 3);
         bls::fq_canon(X);

@@ -31,11 +31,7 @@ namespace blsgpu {
 struct VmTables {
     const uint2* mflat;       // Miller loop: flat round sequence {data_off, meta}
     const uint2* mpflat;      // Miller loop, BLSVM_MP_G pairs per team
-    const uint2* h1flat;      // hash to G2: the two SW encodings
-    const uint2* h1wflat;     // same, from 512-bit hash values
     const uint2* h2flat;      // hash to G2: sum + cofactor clearing
-    const uint2* d1flat;      // G1 decompression
-    const uint2* d2flat;      // G2 decompression
     const uint2* fflat;       // final exponentiation
     const uint2* segflat;     // directly called segments (BLSVM_SEGF_*)
     const uint16_t* data;

@@ -424,33 +424,136 @@ BLS_HD void fq_sub_mod(uint32_t* x, const uint32_t* y) {
 
 // Montgomery inverse: content a = x R  ->  content x^-1 R ; 0 -> 0 (the
 // reference's fq_invert returns 0 for 0, fields_t.py:47-55).
-// Binary extended Euclid on the content (plain inverse c^-1), then one
-// Montgomery product by R^3 to land back in the domain.
+//
+// Plain inverse of the content by Bernstein-Yang "safegcd" division steps (eprint 2019/266),
+// branch-free: 37 batches of 30 divsteps on the low words, each batch applied to the full
+// (f, g) and (d, e) as a 2x2 integer matrix.  1110 >= floor((49 * 381 + 57) / 17) = 1101
+// divsteps suffice for 381-bit inputs (theorem 11.2 of the paper, delta = 1).  Every lane
+// runs the same instruction sequence -- what a lock-step wavefront needs; the binary
+// Euclid it replaces diverged at every step.  Then one Montgomery product by R^3.
+// Numbers are 13 signed limbs of 30 bits.
+#define BLS_Q30_LIMBS {0x3fffaaab, 0x27fbffff, 0x153ffffb, 0x2affffac, 0x30f6241e, 0x034a83da, 0x112bf673, 0x12e13ce1, 0x2cd76477, 0x1ed90d2e, 0x29a4b1ba, 0x3a8e5ff9, 0x001a0111}
+#define BLS_Q_INV30 0x00030003u   /* q^-1 mod 2^30 */
+
+struct inv_trans { int32_t u, v, q, r; };
+
+// 30 division steps on the low words; returns the new eta = -delta; t maps (f, g) to 2^30 (f', g')
+BLS_HD int32_t inv_divsteps30(int32_t eta, uint32_t f0, uint32_t g0, inv_trans& t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+#pragma unroll
+    for (int i = 0; i < 30; i++) {
+        uint32_t c1 = (uint32_t)(eta >> 31);          // delta > 0
+        const uint32_t c2 = 0u - (g & 1u);            // g odd
+        const uint32_t x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+        g += x & c2; q += y & c2; r += z & c2;
+        c1 &= c2;
+        eta = (int32_t)(((uint32_t)eta ^ c1) - (c1 + 1u));
+        f += g & c1; u += q & c1; v += r & c1;
+        g >>= 1; u <<= 1; v <<= 1;
+    }
+    t.u = (int32_t)u; t.v = (int32_t)v; t.q = (int32_t)q; t.r = (int32_t)r;
+    return eta;
+}
+// (f, g) <- t (f, g) / 2^30 (exact)
+BLS_HD void inv_update_fg(int32_t* f, int32_t* g, const inv_trans& t) {
+    const int32_t M30 = 0x3FFFFFFF;
+    int64_t cf = (int64_t)t.u * f[0] + (int64_t)t.v * g[0];
+    int64_t cg = (int64_t)t.q * f[0] + (int64_t)t.r * g[0];
+    cf >>= 30; cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < 13; i++) {
+        cf += (int64_t)t.u * f[i] + (int64_t)t.v * g[i];
+        cg += (int64_t)t.q * f[i] + (int64_t)t.r * g[i];
+        f[i - 1] = (int32_t)cf & M30; cf >>= 30;
+        g[i - 1] = (int32_t)cg & M30; cg >>= 30;
+    }
+    f[12] = (int32_t)cf; g[12] = (int32_t)cg;
+}
+// (d, e) <- t (d, e) / 2^30 mod q, both kept in (-2q, q)
+BLS_HD void inv_update_de(int32_t* d, int32_t* e, const inv_trans& t) {
+    const int32_t M30 = 0x3FFFFFFF;
+    const int32_t m[13] = BLS_Q30_LIMBS;
+    const int32_t sd = d[12] >> 31, se = e[12] >> 31;
+    int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
+    int64_t cd = (int64_t)t.u * d[0] + (int64_t)t.v * e[0];
+    int64_t ce = (int64_t)t.q * d[0] + (int64_t)t.r * e[0];
+    md -= (int32_t)((BLS_Q_INV30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+    me -= (int32_t)((BLS_Q_INV30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+    cd += (int64_t)m[0] * md; ce += (int64_t)m[0] * me;
+    cd >>= 30; ce >>= 30;
+#pragma unroll
+    for (int i = 1; i < 13; i++) {
+        cd += (int64_t)t.u * d[i] + (int64_t)t.v * e[i] + (int64_t)m[i] * md;
+        ce += (int64_t)t.q * d[i] + (int64_t)t.r * e[i] + (int64_t)m[i] * me;
+        d[i - 1] = (int32_t)cd & M30; cd >>= 30;
+        e[i - 1] = (int32_t)ce & M30; ce >>= 30;
+    }
+    d[12] = (int32_t)cd; e[12] = (int32_t)ce;
+}
+// r in (-2q, q), sign < 0 means negate: -> canonical [0, q)
+BLS_HD void inv_normalize(int32_t* r, int32_t sign) {
+    const int32_t M30 = 0x3FFFFFFF;
+    const int32_t m[13] = BLS_Q30_LIMBS;
+    int32_t cond_add = r[12] >> 31;
+    const int32_t cond_neg = sign >> 31;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        int32_t x = r[i] + (m[i] & cond_add);
+        x = (x ^ cond_neg) - cond_neg;
+        x += c;
+        c = x >> 30;
+        r[i] = (i < 12) ? (x & M30) : x;
+    }
+    cond_add = r[12] >> 31;
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        int32_t x = r[i] + (m[i] & cond_add) + c;
+        c = x >> 30;
+        r[i] = (i < 12) ? (x & M30) : x;
+    }
+}
+
 BLS_HD void fq_inv(uint32_t* __restrict__ r, const uint32_t* __restrict__ a) {
-    const uint32_t q[12] = BLS_Q_LIMBS;
     const uint32_t r3[12] = BLS_R3_LIMBS;
-    uint32_t u[12], v[12], x1[12], x2[12];
+    const int32_t m[13] = BLS_Q30_LIMBS;
+    uint32_t x[12];
 #pragma unroll
-    for (int j = 0; j < 12; j++) { u[j] = a[j]; v[j] = q[j]; x1[j] = 0; x2[j] = 0; }
-    fq_canon(u);                      // the VM hands over a relaxed value (< 2q)
-    x1[0] = 1;
-    if (fq_is_zero(u)) {
+    for (int j = 0; j < 12; j++) x[j] = a[j];
+    fq_canon(x);                      // the VM hands over a relaxed value (< 2q)
+    // 12 x 32 bits -> 13 x 30 bits
+    int32_t f[13], g[13], d[13], e[13];
 #pragma unroll
-        for (int j = 0; j < 12; j++) r[j] = 0;
-        return;
+    for (int i = 0; i < 13; i++) {
+        const int bit = 30 * i, w = bit >> 5, s = bit & 31;
+        uint32_t lo = x[w] >> s;
+        if (s > 2 && w + 1 < 12) lo |= x[w + 1] << (32 - s);
+        g[i] = (int32_t)(lo & 0x3FFFFFFFu);
+        f[i] = m[i]; d[i] = 0; e[i] = 0;
     }
-    // invariant: x1 * a == u, x2 * a == v (mod q)
-    while (!big_is_one(u) && !big_is_one(v)) {
-        while (!(u[0] & 1u)) { big_shr1(u, 0); fq_half(x1); }
-        while (!(v[0] & 1u)) { big_shr1(v, 0); fq_half(x2); }
-        if (big_geq(u, v)) { big_sub(u, v); fq_sub_mod(x1, x2); }
-        else { big_sub(v, u); fq_sub_mod(x2, x1); }
+    e[0] = 1;
+    int32_t eta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 37; it++) {
+        inv_trans t;
+        eta = inv_divsteps30(eta, (uint32_t)f[0], (uint32_t)g[0], t);
+        inv_update_de(d, e, t);
+        inv_update_fg(f, g, t);
     }
-    const bool from_u = big_is_one(u);
-    uint32_t tmp[12];
+    // now g = 0 and f = +-gcd = +-1 (or f = +-q when the input was 0: then d = 0)
+    inv_normalize(d, f[12]);
+    // 13 x 30 bits -> 12 x 32 bits
+    uint32_t y[12];
 #pragma unroll
-    for (int j = 0; j < 12; j++) tmp[j] = from_u ? x1[j] : x2[j];
-    fq_mul(r, tmp, r3);
+    for (int w = 0; w < 12; w++) {
+        const int bit = 32 * w, i = bit / 30, s = bit - 30 * i;
+        uint32_t v = (uint32_t)d[i] >> s;
+        v |= (uint32_t)d[i + 1] << (30 - s);
+        if (60 - s < 32 && i + 2 < 13) v |= (uint32_t)d[i + 2] << (60 - s);
+        y[w] = v;
+    }
+    fq_mul(r, y, r3);
 }
 
 }  // namespace bls

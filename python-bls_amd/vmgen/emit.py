@@ -15,6 +15,7 @@ Layout consumed by csrc/blsgpu_kernels.hip:
   BLSVM_CONSTS: Montgomery contents of the constant slots, 12 LE u32 limbs each
 """
 import hashlib
+import re
 import os
 
 from . import decomp_programs as DP
@@ -161,7 +162,9 @@ def limbs32(v):
     return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(12)]
 
 
-DIRECT_SEGS = ["mul_0_1", "from_mont_1_0", "to_mont_0_1", "copy_1_0"]   # called by name from the kernels
+DIRECT_SEGS = ["mul_0_1", "from_mont_1_0", "to_mont_0_1", "copy_1_0",     # called by name from the kernels
+               "h1_a", "h1w_a", "h1_b", "h1_c", "d1_a", "d1_c", "d2_a", "d2_b", "d2_c"]
+POW_SEG = re.compile(r"^(h1_(sqr|mul)[23]|d1_(sqr|mul)|d2[pq]_(sqr|mul))$")
 MSM_NP = {1: 6, 2: 2}                                         # points per team in the MSM kernels
 H1_NE, H2_NM = 12, 2                                          # encodings / messages per team (hash to G2)
 D1_NE, D2_NE = 32, 16                                         # points per team (decompression)
@@ -188,7 +191,9 @@ def build_tables(verbose=False):
     d2segs, d2lay, d2script = DP.build_d2(D2_NE, verbose=verbose)
     segs.update(d1segs)
     segs.update(d2segs)
-    order = sorted(segs)
+    # the fixed-exponent powers run in a register kernel (k_pow), not in the VM: their
+    # squaring / multiplication segments stay out of the packed tables
+    order = sorted(n for n in segs if not POW_SEG.match(n))
     seg_rounds, data = pack(segs, order)
     return dict(segs=segs, mscript=mscript, fscript=fscript, mpsegs=mpsegs, mpscript=mpscript, msm=msm,
                 h1=(h1segs, h1lay, h1script), h1w=(h1segs, h1lay, h1wscript), h2=(h2segs, h2lay, h2script),
@@ -231,13 +236,14 @@ def generate(path=None, verbose=False):
     w("#define BLSVM_H1_NE %d\n#define BLSVM_H1_SLOTS %d\n" % (H1_NE, h1lay.TEMP0 + max(s.ntemp for s in h1segs.values())))
     w("#define BLSVM_H2_NM %d\n#define BLSVM_H2_SLOTS %d\n" % (H2_NM, h2lay.TEMP0 + max(s.ntemp for s in h2segs.values())))
     w("#define BLSVM_H1_T %d\n#define BLSVM_H1_TH %d\n#define BLSVM_H1_S %d\n#define BLSVM_H2_S %d\n#define BLSVM_H2_OUT %d\n" % (h1lay.T, h1lay.TH, h1lay.S, h2lay.S, h2lay.OUT))
+    w("#define BLSVM_H1_ACC %d\n#define BLSVM_H1_BASE %d\n#define BLSVM_H1_STATE0 %d\n#define BLSVM_H1_STATE1 %d\n" % (h1lay.ACC, h1lay.BASE, h1lay.T, h1lay.TEMP0))
     w("#define BLSVM_NCONST_H2C %d\n" % HP.HC_END)
     for tag, ne, (dsegs, dlay, dscript) in (("D1", D1_NE, tb["d1"]), ("D2", D2_NE, tb["d2"])):
         w("#define BLSVM_%s_NE %d\n#define BLSVM_%s_SLOTS %d\n" % (tag, ne, tag, dlay.TEMP0 + max(s.ntemp for s in dsegs.values())))
         w("#define BLSVM_%s_X %d\n#define BLSVM_%s_BIG %d\n#define BLSVM_%s_OUT %d\n" % (tag, dlay.X, tag, dlay.BIG, tag, dlay.OUT))
-        flat("BLSVM_%s_FLAT" % tag, [r for n in dscript for r in seg_rounds[n]])
-    flat("BLSVM_H1_FLAT", [r for n in h1script for r in seg_rounds[n]])
-    flat("BLSVM_H1W_FLAT", [r for n in tb["h1w"][2] for r in seg_rounds[n]])
+        w("#define BLSVM_%s_ACC %d\n#define BLSVM_%s_BASE %d\n#define BLSVM_%s_STATE0 %d\n#define BLSVM_%s_STATE1 %d\n" % (tag, dlay.ACC, tag, dlay.BASE, tag, dlay.X, tag, dlay.TEMP0))
+    w("static const uint32_t BLSVM_POW_E[12] = {%s};   /* (q - 3) / 4 */\n#define BLSVM_POW_E_BITS %d\n" % (
+        ", ".join("0x%08xu" % ((HP.EXP_E >> (32 * i)) & 0xFFFFFFFF) for i in range(12)), HP.EXP_E.bit_length()))
     flat("BLSVM_H2_FLAT", [r for n in h2script for r in seg_rounds[n]])
     flat("BLSVM_MILLER_FLAT", mflat)
     flat("BLSVM_FEXP_FLAT", fflat)

@@ -71,6 +71,13 @@ def test_fq32_host_build_matches_python_ints(tmp_path):
             inp.append("%s %096x %096x" % (op, a, b))
             exp.append({"mul": a * b * Ri % Q, "add": (a + b) % Q, "sub": (a - b) % Q,
                         "inv": (pow(a, -1, Q) * R * R) % Q if a else 0}[op])
+    # the inversion (safegcd division steps) on many more values, also relaxed ones (q <= a < 2q)
+    # and values with long runs of zero / one bits
+    more = [rnd.randrange(Q) for _ in range(3000)] + [Q + rnd.randrange(Q) for _ in range(200)]
+    more += [(1 << k) % Q for k in range(0, 384, 7)] + [(Q - (1 << k)) % Q for k in range(0, 380, 11)] + [Q, Q + 1, 2 * Q - 1]
+    for a in more:
+        inp.append("inv %096x %096x" % (a, 0))
+        exp.append((pow(a % Q, -1, Q) * R * R) % Q if a % Q else 0)
     out = subprocess.run([str(exe)], input="\n".join(inp) + "\n", capture_output=True, text=True).stdout.split()
     assert len(out) == len(exp)
     assert [int(o, 16) for o in out] == exp

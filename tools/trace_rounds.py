@@ -12,7 +12,7 @@ e = _native.Engine(0)
 e.lib.blsgpu_debug_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint32)]
 tb = emit.build_tables()
 sr, data = tb["seg_rounds"], tb["data"]
-which = {"miller": (0, "mscript"), "fexp": (2, "fscript")}
+which = {"miller": (0, "mscript"), "mp": (1, "mpscript"), "fexp": (2, "fscript")}
 prog = sys.argv[1] if len(sys.argv) > 1 else "d1"
 if prog in ("d1", "d2", "h1", "h2"):
     segs, lay, script = tb[prog]
