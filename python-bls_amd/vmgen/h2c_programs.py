@@ -232,7 +232,7 @@ def _out_pt(b, P, base, m, zero):
 
 
 def build_h2(NM, cfg=None, verbose=False):
-    cfg = cfg or tw.Cfg()
+    cfg = cfg or tw.Cfg(mat2=False)        # unmaterialised Fq2 products: 437 instead of 718 LIN rounds
     F = FA(2, cfg)
     L = H2Layout(NM)
     segs = {}

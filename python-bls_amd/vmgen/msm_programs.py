@@ -118,7 +118,7 @@ def _out_pt(b, lay, P, base, p=0, zero=None):
 
 
 def build(deg, NP, cfg=None, verbose=False):
-    cfg = cfg or tw.Cfg()
+    cfg = cfg or tw.Cfg(mat2=False)
     F = FA(deg, cfg)
     lay = Layout(deg, NP)
     c = deg
