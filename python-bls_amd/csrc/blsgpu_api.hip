@@ -502,6 +502,17 @@ static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size
 // Miller loops + per-group product; final exponentiation iff d_out_bytes
 static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t gsz, size_t groups, uint32_t* d_out_partial,
                            void* d_out_bytes, hipStream_t st) {
+    constexpr size_t MAX_GROUPS = 32768;               // groups ride on gridDim.y: larger batches go in slices
+    if (groups > MAX_GROUPS) {
+        for (size_t g0 = 0; g0 < groups; g0 += MAX_GROUPS) {
+            const size_t gn = groups - g0 < MAX_GROUPS ? groups - g0 : MAX_GROUPS;
+            int rc = grouped_pairing(c, (const char*)d_g1 + g0 * gsz * BLSGPU_G1_BYTES, (const char*)d_g2 + g0 * gsz * BLSGPU_G2_BYTES, gsz,
+                                     gn, d_out_partial ? d_out_partial + g0 * 144 : nullptr,
+                                     d_out_bytes ? (char*)d_out_bytes + g0 * BLSGPU_FQ12_BYTES : nullptr, st);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     size_t need_pairs = (gsz + 3) * groups;            // every group rounds its team count up
     if ((need_pairs + 2) / 3 + (need_pairs + MILLER_WAVES - 1) / MILLER_WAVES + 1 > c->part_cap) {
         int rc = ensure_workspace(c, need_pairs);

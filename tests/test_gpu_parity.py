@@ -196,3 +196,15 @@ def test_batched_sharded_form(engine, golden, seeded_pairs):
     want = golden("pairing.json")["seeded"]["1025"]["out"]     # a rotation does not change the product
     for g in range(groups):
         assert bytes(out[g].cpu().numpy()).hex() == want
+
+
+def test_batched_many_groups_sliced(engine, golden):
+    """More groups than one launch carries (slices of 32768): 40000 groups of 24 pairs, all the
+    same pairs, so every result must equal the first (itself checked against blsgpu_pairing_multi)."""
+    v = golden("pairing.json")["small4"]
+    a = cat(v["g1"]) * 6
+    b = cat(v["g2"]) * 6
+    groups = 40000
+    out = engine.pairing_multi_batch(a * groups, b * groups, 24, groups)
+    one = engine.pairing_multi(a, b, 24)
+    assert out == one * groups
