@@ -38,6 +38,26 @@ class OracleShardBackend:
             acc = self.o.field_op(12, "mul", acc, bytes(t.numpy()))
         return self.o.final_exp(acc)
 
+    def miller_partials_batch(self, g1, g2, gsz, groups):
+        parts = [self.miller_partial(g1[96 * gsz * g:96 * gsz * (g + 1)], g2[192 * gsz * g:192 * gsz * (g + 1)], gsz)
+                 for g in range(groups)]
+        return torch.cat(parts)
+
+    def all_gather_batch(self, parts, groups, group=None):
+        world = dist.get_world_size(group)
+        outs = [torch.zeros(576 * groups, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(outs, parts, group=group)
+        return outs, world                                            # [rank][group]
+
+    def final_batch(self, gathered, world, groups):
+        res = []
+        for g in range(groups):
+            acc = self.ONE
+            for r in range(world):
+                acc = self.o.field_op(12, "mul", acc, bytes(gathered[r][576 * g:576 * (g + 1)].numpy()))
+            res.append(self.o.final_exp(acc))
+        return res
+
 
 def _worker(rank, world, port, n, q):
     for p in (os.path.join(ROOT, "python-bls_amd"), os.path.join(ROOT, "oracle")):
@@ -50,6 +70,14 @@ def _worker(rank, world, port, n, q):
     g1 = open(os.path.join(ROOT, "tests/golden/pairs_seed1_g1.bin"), "rb").read()[:96 * n]
     g2 = open(os.path.join(ROOT, "tests/golden/pairs_seed1_g2.bin"), "rb").read()[:192 * n]
     out = pairing_multi_sharded(OracleShardBackend(O), g1, g2, n, rank, world)
+    # three verifications at once: rotations of the batch (same product) and a shorter-by-swap variant
+    from bls_py.dist import pairing_multi_batch_sharded
+    rot = lambda b, sz, k: b[sz * k:] + b[:sz * k]                   # noqa: E731
+    g1s = [g1, rot(g1, 96, 3), g1[96:] + g1[:96]]
+    g2s = [g2, rot(g2, 192, 3), g2[:192 * (n - 1)] + g2[192 * (n - 1):]]          # last one: pairs mismatched on purpose
+    batch = pairing_multi_batch_sharded(OracleShardBackend(O), g1s, g2s, rank, world)
+    want = [O.pairing_multi(a, b, n) for a, b in zip(g1s, g2s)]
+    assert batch == want and batch[0] == batch[1] == out and batch[2] != out
     q.put((rank, out.hex()))
     dist.barrier()
     dist.destroy_process_group()
