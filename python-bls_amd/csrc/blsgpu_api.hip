@@ -49,6 +49,7 @@ struct blsgpu_ctx {
     size_t mp_threshold = 4096;        // pairs from which k_miller_mp is used
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
+    size_t h2c_reg_threshold = 32768;  // messages from which cofactor clearing runs one message per lane
     uint32_t* d_msm_part = nullptr;    // MSM partials
     size_t msm_part_cap = 0;           // in u32
     // optional per-kernel timing (blsgpu_timing_enable): HIP events recorded on
@@ -303,6 +304,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     c->mp_threshold = default_mp_threshold();
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
     // pack all tables into one device allocation (16-byte aligned pieces)
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     size_t o_m = 0;
@@ -749,9 +751,14 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
     hipLaunchKernelGGL((blsgpu::k_h2c_stage<2, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,
                        (uint32_t)(2 * n), img);
     HIP_TRY(hipGetLastError());
-    unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);
-    hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, img, (uint32_t)n,
-                       (uint32_t*)d_out);
+    if (n < c->h2c_reg_threshold) {        // few messages: the 2-messages-per-wavefront VM form fills the chip better
+        unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);
+        hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, img, (uint32_t)n,
+                           (uint32_t*)d_out);
+    } else {
+        hipLaunchKernelGGL(blsgpu::k_h2c_clear_reg, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->tabs, img, (uint32_t)n,
+                           (uint32_t*)d_out);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -197,6 +197,126 @@ __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t*
 }
 
 // ---------------------------------------------------------------------------
+// Cofactor clearing with ONE MESSAGE PER LANE, everything in registers (the same
+// formulas as vmgen/h2c_programs.build_h2: complete projective addition / doubling
+// of Renes-Costello-Batina for a = 0, the endomorphism psi, ec.py:536-550).  The
+// point arithmetic of one message is strictly sequential (two double-and-add chains
+// by |x|), so the 64-lane VM kept two messages per wavefront busy at ~35 % of its
+// lanes; here every lane carries a message and nothing but products and modular
+// additions is executed.  The field product is a real function call (s_swappc, operands
+// by value in VGPRs): inlining 36 products per point addition would not fit the
+// instruction cache.
+namespace reg {
+struct fe { uint32_t v[12]; };                              // Montgomery, canonical (< q)
+struct fe2 { fe a, b; };
+struct pt { fe2 X, Y, Z; };
+
+__device__ __attribute__((noinline)) fe fe_mul(fe x, fe y) {
+    fe r;
+    bls::fq_mul(r.v, x.v, y.v);
+    return r;
+}
+__device__ __forceinline__ fe fe_add(fe x, const fe& y) { bls::fq_add_mod(x.v, y.v); return x; }
+__device__ __forceinline__ fe fe_sub(fe x, const fe& y) { bls::fq_sub_mod(x.v, y.v); return x; }
+__device__ __forceinline__ fe fe_zero() { fe r; for (int j = 0; j < 12; j++) r.v[j] = 0; return r; }
+__device__ __forceinline__ fe fe_neg(const fe& x) { return fe_sub(fe_zero(), x); }
+__device__ __forceinline__ fe2 f2_add(const fe2& x, const fe2& y) { return {fe_add(x.a, y.a), fe_add(x.b, y.b)}; }
+__device__ __forceinline__ fe2 f2_sub(const fe2& x, const fe2& y) { return {fe_sub(x.a, y.a), fe_sub(x.b, y.b)}; }
+__device__ __forceinline__ fe2 f2_neg(const fe2& x) { return {fe_neg(x.a), fe_neg(x.b)}; }
+__device__ __forceinline__ fe2 f2_dbl(const fe2& x) { return f2_add(x, x); }
+__device__ __forceinline__ fe2 f2_conj(const fe2& x) { return {x.a, fe_neg(x.b)}; }
+__device__ __forceinline__ fe2 f2_mul_xi(const fe2& x) { return {fe_sub(x.a, x.b), fe_add(x.a, x.b)}; }   // (1 + u) x
+__device__ fe2 f2_mul(const fe2& x, const fe2& y) {
+    fe t0 = fe_mul(x.a, y.a), t1 = fe_mul(x.b, y.b), t2 = fe_mul(fe_add(x.a, x.b), fe_add(y.a, y.b));
+    return {fe_sub(t0, t1), fe_sub(fe_sub(t2, t0), t1)};
+}
+__device__ fe2 f2_sqr(const fe2& x) {
+    fe m = fe_mul(x.a, x.b);
+    return {fe_mul(fe_add(x.a, x.b), fe_sub(x.a, x.b)), fe_add(m, m)};
+}
+__device__ __forceinline__ fe2 f2_x3(const fe2& x) { return f2_add(f2_dbl(x), x); }
+__device__ __forceinline__ fe2 f2_x8(const fe2& x) { return f2_dbl(f2_dbl(f2_dbl(x))); }
+__device__ __forceinline__ fe2 f2_b3(const fe2& x) {        // 3 b' x, b' = 4 (1 + u)
+    fe2 t = f2_dbl(f2_dbl(f2_mul_xi(x)));                    // 4 xi x
+    return f2_add(f2_dbl(t), t);                             // 12 xi x
+}
+// complete addition, RCB algorithm 7 (a = 0) -- msm_programs.padd
+__device__ pt padd(const pt& P, const pt& Q) {
+    fe2 t0 = f2_mul(P.X, Q.X), t1 = f2_mul(P.Y, Q.Y), t2 = f2_mul(P.Z, Q.Z);
+    fe2 t3 = f2_sub(f2_sub(f2_mul(f2_add(P.X, P.Y), f2_add(Q.X, Q.Y)), t0), t1);
+    fe2 t4 = f2_sub(f2_sub(f2_mul(f2_add(P.Y, P.Z), f2_add(Q.Y, Q.Z)), t1), t2);
+    fe2 t5 = f2_sub(f2_sub(f2_mul(f2_add(P.X, P.Z), f2_add(Q.X, Q.Z)), t0), t2);
+    fe2 x3 = f2_x3(t0), bz = f2_b3(t2);
+    fe2 z3 = f2_add(t1, bz), t1m = f2_sub(t1, bz), y3 = f2_b3(t5);
+    pt R;
+    R.X = f2_sub(f2_mul(t3, t1m), f2_mul(t4, y3));
+    R.Y = f2_add(f2_mul(t1m, z3), f2_mul(y3, x3));
+    R.Z = f2_add(f2_mul(z3, t4), f2_mul(x3, t3));
+    return R;
+}
+// complete doubling, RCB algorithm 9 (a = 0) -- msm_programs.pdbl
+__device__ pt pdbl(const pt& P) {
+    fe2 t0 = f2_sqr(P.Y), t1 = f2_mul(P.Y, P.Z), t2 = f2_b3(f2_sqr(P.Z)), txy = f2_mul(P.X, P.Y);
+    fe2 z8 = f2_x8(t0), d = f2_sub(t0, f2_x3(t2));
+    pt R;
+    R.X = f2_dbl(f2_mul(d, txy));
+    R.Y = f2_add(f2_mul(t2, z8), f2_mul(d, f2_add(t0, t2)));
+    R.Z = f2_mul(t1, z8);
+    return R;
+}
+__device__ __forceinline__ pt pneg(const pt& P) { return {P.X, f2_neg(P.Y), P.Z}; }
+__device__ pt mul_x(const pt& P) {                           // [|x|] P, |x| = 0xd201000000010000
+    pt A = P;
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; bit--) {
+        A = pdbl(A);
+        if ((0xd201000000010000ull >> bit) & 1ull) A = padd(A, P);
+    }
+    return A;
+}
+}  // namespace reg
+
+// enc = the stage image (see k_h2c_stage): encoding e sits in team e / NE, slots S + 5 (e % NE) .. + 5.
+// out: n_msg x 192 bytes canonical affine (x.c0 || x.c1 || y.c0 || y.c1), (0,0) for infinity.
+__global__ void __launch_bounds__(64) k_h2c_clear_reg(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg,
+                                                      uint32_t* __restrict__ out) {
+    using namespace reg;
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_msg) return;
+    auto cfe = [&](uint32_t slot) { fe r; for (int j = 0; j < 12; j++) r.v[j] = T.consts[slot * 12 + j]; return r; };
+    pt S[2];
+    for (int s = 0; s < 2; s++) {
+        const uint32_t e = 2 * m + s;
+        const uint32_t* src = enc + ((size_t)(e / BLSVM_H1_NE) * H1_IMG + (BLSVM_H1_S - BLSVM_H1_STATE0) + 5 * (e % BLSVM_H1_NE)) * 12;
+        fe c[5];
+        for (int k = 0; k < 5; k++) {
+            for (int j = 0; j < 12; j++) c[k].v[j] = src[k * 12 + j];
+            bls::fq_canon(c[k].v);                               // the VM leaves values < 2q
+        }
+        S[s] = {{c[0], c[1]}, {c[2], c[3]}, {c[4], fe_zero()}};
+    }
+    const fe2 psix = {cfe(BLSVM_HC_PSIX), cfe(BLSVM_HC_PSIX + 1)}, psiy = {cfe(BLSVM_HC_PSIY), cfe(BLSVM_HC_PSIY + 1)};
+    auto psi = [&](const pt& P) { return pt{f2_mul(f2_conj(P.X), psix), f2_mul(f2_conj(P.Y), psiy), f2_conj(P.Z)}; };
+    const pt P = padd(S[0], S[1]);
+    const pt T0 = mul_x(P);                                      // [x] P       (ec.py:540-550)
+    const pt T1 = mul_x(T0);                                     // [x^2] P
+    const pt t2 = padd(padd(T1, T0), pneg(P));
+    const pt t3 = psi(padd(T0, P));
+    const pt p2 = psi(psi(pdbl(P)));
+    const pt R = padd(padd(t2, pneg(t3)), p2);
+    // affine: (X, Y) / Z with 1 / Z = conj(Z) / N(Z); Z = 0 gives (0, 0)
+    fe n = fe_add(fe_mul(R.Z.a, R.Z.a), fe_mul(R.Z.b, R.Z.b)), ninv;
+    bls::fq_inv(ninv.v, n.v);
+    const fe2 zi = {fe_mul(R.Z.a, ninv), fe_neg(fe_mul(R.Z.b, ninv))};
+    const fe2 xa = f2_mul(R.X, zi), ya = f2_mul(R.Y, zi);
+    fe raw1 = fe_zero();
+    raw1.v[0] = 1;                                               // content 1: x R -> x
+    const fe o[4] = {fe_mul(xa.a, raw1), fe_mul(xa.b, raw1), fe_mul(ya.a, raw1), fe_mul(ya.b, raw1)};
+    for (int k = 0; k < 4; k++)
+        for (int w = 0; w < 12; w++) out[(size_t)m * 48 + k * 12 + w] = bswap32(o[k].v[11 - w]);
+}
+
+// ---------------------------------------------------------------------------
 // Point decompression: PublicKey.from_bytes (keys.py:28-40, DEG 1)
 // and Signature.from_bytes (signature.py:21-38, DEG 2) for a batch.  in: n x 48*DEG
 // bytes as serialised (bit 0x80 of byte 0 = "the larger y", top three bits masked as

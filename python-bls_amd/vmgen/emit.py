@@ -237,7 +237,7 @@ def generate(path=None, verbose=False):
     w("#define BLSVM_H2_NM %d\n#define BLSVM_H2_SLOTS %d\n" % (H2_NM, h2lay.TEMP0 + max(s.ntemp for s in h2segs.values())))
     w("#define BLSVM_H1_T %d\n#define BLSVM_H1_TH %d\n#define BLSVM_H1_S %d\n#define BLSVM_H2_S %d\n#define BLSVM_H2_OUT %d\n" % (h1lay.T, h1lay.TH, h1lay.S, h2lay.S, h2lay.OUT))
     w("#define BLSVM_H1_ACC %d\n#define BLSVM_H1_BASE %d\n#define BLSVM_H1_STATE0 %d\n#define BLSVM_H1_STATE1 %d\n" % (h1lay.ACC, h1lay.BASE, h1lay.T, h1lay.TEMP0))
-    w("#define BLSVM_NCONST_H2C %d\n" % HP.HC_END)
+    w("#define BLSVM_NCONST_H2C %d\n#define BLSVM_HC_PSIX %d\n#define BLSVM_HC_PSIY %d\n" % (HP.HC_END, HP.HC_PSIX, HP.HC_PSIY))
     for tag, ne, (dsegs, dlay, dscript) in (("D1", D1_NE, tb["d1"]), ("D2", D2_NE, tb["d2"])):
         w("#define BLSVM_%s_NE %d\n#define BLSVM_%s_SLOTS %d\n" % (tag, ne, tag, dlay.TEMP0 + max(s.ntemp for s in dsegs.values())))
         w("#define BLSVM_%s_X %d\n#define BLSVM_%s_BIG %d\n#define BLSVM_%s_OUT %d\n" % (tag, dlay.X, tag, dlay.BIG, tag, dlay.OUT))

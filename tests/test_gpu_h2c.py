@@ -73,3 +73,31 @@ def test_large_batch_properties(engine):
         assert pts[i] == H.g2_affine_bytes(H.hash_to_g2_prehashed(msgs[i], hash512))
     rev = engine.map_to_g2(b"".join(reversed(t)))
     assert [rev[192 * i:192 * (i + 1)] for i in range(n)] == pts[::-1]
+
+
+def test_one_message_per_lane_clearing(golden):
+    """The register form of the cofactor clearing (used from 32768 messages on), forced for a small
+    batch: reference vectors, infinity summands, ragged counts, and equality with the VM form."""
+    import os
+    from bls_py import _native
+    old = os.environ.get("BLSGPU_H2C_REG_THRESHOLD")
+    os.environ["BLSGPU_H2C_REG_THRESHOLD"] = "1"
+    try:
+        e = _native.Engine(0)
+    finally:
+        if old is None:
+            del os.environ["BLSGPU_H2C_REG_THRESHOLD"]
+        else:
+            os.environ["BLSGPU_H2C_REG_THRESHOLD"] = old
+    vec = golden("hash_to_curve.json")["hash_to_g2"]
+    out = e.hash_to_g2(b"".join(bytes.fromhex(r["msg_hash"]) for r in vec))
+    assert [out[192 * i:192 * (i + 1)].hex() for i in range(len(vec))] == [r["point"] for r in vec]
+    sw = golden("hash_to_curve.json")["sw_encode_fq2"]
+    tt = bytes.fromhex(sw[1]["t"])
+    neg = b"".join(((H.Q - int.from_bytes(tt[48 * j:48 * j + 48], "big")) % H.Q).to_bytes(48, "big") for j in range(2))
+    assert e.map_to_g2(bytes(192) + tt + neg) == bytes(384)              # infinity + infinity, S + (-S)
+    for n in (1, 63, 64, 65, 200):
+        msgs = b"".join(hashlib.sha256(b"lane-%d-%d" % (n, i)).digest() for i in range(n))
+        got = e.hash_to_g2(msgs)
+        assert got == _native.engine(0).hash_to_g2(msgs)                # the VM form (default engine, small batch)
+        assert got[:192] == H.g2_affine_bytes(H.hash_to_g2_prehashed(msgs[:32], hash512))
