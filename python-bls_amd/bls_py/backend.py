@@ -19,6 +19,9 @@ class HipProvider:
     def final_exp(self, x: bytes) -> bytes:
         return self._eng.final_exp(x)
 
+    def pairing_multi_batch(self, g1: bytes, g2: bytes, gsz: int, groups: int) -> bytes:
+        return self._eng.pairing_multi_batch(g1, g2, gsz, groups)
+
     def g1_msm(self, pts: bytes, scalars, k: int, groups: int = 1):
         return self._eng.g1_msm(pts, scalars, k, groups)
 

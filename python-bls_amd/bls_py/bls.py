@@ -101,6 +101,52 @@ class BLS:
         return res == Fq12.one(default_ec.q)
 
     @staticmethod
+    def verify_batch(signatures):
+        """[BLS.verify(s) for s in signatures] with every GPU step batched across the
+        signatures: one hash-to-G2 call for all distinct (signature, message) pairs, one call
+        for all per-message key sums, and blsgpu_pairing_multi_batch per distinct pair count
+        (independent multi-pairings side by side).  Same results as verify, one by one."""
+        from . import backend
+        prov = backend.get()
+        ONE = Fq12.one(default_ec.q).serialize()
+        results = [None] * len(signatures)
+        plans = []                                        # (index, message hashes, key groups, exponent groups)
+        for i, sig in enumerate(signatures):
+            info = sig.aggregation_info
+            by_message = {}
+            for mh, pk in zip(info.message_hashes, info.public_keys):
+                by_message.setdefault(mh, []).append(pk)
+            kg, eg = [], []
+            try:
+                for mh, keys in by_message.items():
+                    uniq = list(set(keys))
+                    eg.append([info.tree[(mh, pk)] for pk in uniq])
+                    kg.append([pk.value for pk in uniq])
+            except KeyError:
+                results[i] = False                        # bls.py:189-190
+                continue
+            plans.append((i, list(by_message), kg, eg))
+        if not plans:
+            return results
+        all_hashes = [mh for _, mhs, _, _ in plans for mh in mhs]
+        Qs = hash_to_points_prehashed_Fq2(all_hashes)
+        Ps = _g1_sums([g for _, _, kg, _ in plans for g in kg], [e for _, _, _, eg in plans for e in eg])
+        neg_g1 = H.g1_affine_bytes((generator_Fq() * (GROUP_ORDER - 1))._aff())
+        by_size, pos = {}, 0
+        for i, mhs, _, _ in plans:
+            k = len(mhs)
+            g1 = neg_g1 + b"".join(H.g1_affine_bytes(p.to_affine()._aff()) for p in Ps[pos:pos + k])
+            g2 = H.g2_affine_bytes(signatures[i].value.to_affine()._aff()) + \
+                b"".join(H.g2_affine_bytes(q._aff()) for q in Qs[pos:pos + k])
+            pos += k
+            by_size.setdefault(k + 1, []).append((i, g1, g2))
+        for size, items in by_size.items():
+            out = prov.pairing_multi_batch(b"".join(x[1] for x in items), b"".join(x[2] for x in items), size, len(items))
+            for j, (i, _, _) in enumerate(items):
+                results[i] = out[576 * j:576 * (j + 1)] == ONE
+        return results
+
+    @staticmethod
     def aggregate_pub_keys(public_keys, secure):
         if len(public_keys) < 1:
             raise Exception("Invalid number of keys")

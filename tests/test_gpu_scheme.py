@@ -108,3 +108,28 @@ def test_threshold_combine_and_verify_C4(golden):
     comb.set_aggregation_info(AggregationInfo.from_msg(PublicKey.from_bytes(bytes.fromhex(rec["master_pk"])),
                                                        bytes.fromhex(rec["msg"])))
     assert BLS.verify(comb) is True
+
+
+def test_verify_batch_on_gpu():
+    """BLS.verify_batch through the HIP engine: 6 aggregates of 40 signatures each (one forged)
+    plus single signatures -> the booleans of BLS.verify one by one."""
+    import hashlib
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    order = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    sks = [PrivateKey(int.from_bytes(hashlib.sha256(b"vb%d" % i).digest(), "big") % (order - 1) + 1) for i in range(40)]
+    aggs = []
+    for a in range(6):
+        sigs = PrivateKey.sign_batch(sks, [b"agg%d-%d" % (a, i) for i in range(40)])
+        if a == 4:
+            sigs[7] = sks[7].sign(b"forged")
+            forged = BLS.aggregate_sigs_simple(sigs)
+            forged.set_aggregation_info(BLS.aggregate_sigs(PrivateKey.sign_batch(sks, [b"agg4-%d" % i for i in range(40)])).aggregation_info)
+            aggs.append(forged)
+        else:
+            aggs.append(BLS.aggregate_sigs(sigs))
+    singles = [sks[0].sign(b"one"), sks[1].sign(b"two")]
+    batch = aggs + singles
+    got = BLS.verify_batch(batch)
+    assert got == [True, True, True, True, False, True, True, True]
+    assert got == [BLS.verify(s) for s in batch]

@@ -33,6 +33,10 @@ def oracle_provider(oracle):
         def g2_msm(self, pts, scalars, k, groups=1):
             return self._msm(oracle.g2_msm, 192, pts, scalars, k, groups)
 
+        def pairing_multi_batch(self, g1, g2, gsz, groups):
+            return b"".join(oracle.pairing_multi(g1[96 * gsz * g:96 * gsz * (g + 1)], g2[192 * gsz * g:192 * gsz * (g + 1)], gsz)
+                            for g in range(groups))
+
         def g1_decompress(self, data):
             from bls_py import hostmath as H
             out, ok = b"", []
@@ -192,6 +196,7 @@ def test_verify4_inputs_match_reference(golden):
         g2_msm = staticmethod(inner.g2_msm)
         map_to_g2 = staticmethod(inner.map_to_g2)
         hash_to_g2 = staticmethod(inner.hash_to_g2)
+        pairing_multi_batch = staticmethod(inner.pairing_multi_batch)
 
         def pairing_multi(self, g1, g2, n):
             seen["g1"], seen["g2"], seen["n"] = g1, g2, n
@@ -247,3 +252,26 @@ def test_aggregate_pub_keys_vectors(golden):
     assert BLS.aggregate_pub_keys(list(pks), False).serialize().hex() == rec["simple"]
     with pytest.raises(Exception):
         BLS.aggregate_pub_keys([], True)
+
+
+def test_verify_batch_matches_verify_one_by_one(golden, oracle_provider):
+    """BLS.verify_batch: several aggregate signatures of different shapes, one tampered, one with
+    a missing tree entry -> the same booleans as BLS.verify on each."""
+    from bls_py.aggregation_info import AggregationInfo
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    sks = [PrivateKey.from_seed(bytes([i + 1] * 5)) for i in range(4)]
+    msgs = [bytes([i, 100 + i]) for i in range(4)]
+    sigs = [sk.sign(m) for sk, m in zip(sks, msgs)]
+    agg4 = BLS.aggregate_sigs(sigs)
+    agg2 = BLS.aggregate_sigs(sigs[:2])
+    tampered = BLS.aggregate_sigs_simple(sigs[:3])
+    tampered.set_aggregation_info(agg4.aggregation_info)
+    same_msg = BLS.aggregate_sigs([sk.sign(b"same") for sk in sks[:3]])
+    broken = sks[0].sign(b"x")
+    info = broken.aggregation_info
+    broken.set_aggregation_info(AggregationInfo({}, info.message_hashes, info.public_keys))     # tree entry missing
+    batch = [agg4, sigs[0], tampered, agg2, same_msg, broken, sigs[3]]
+    got = BLS.verify_batch(batch)
+    assert got == [BLS.verify(s) for s in batch] == [True, True, False, True, True, False, True]
+    assert BLS.verify_batch([]) == []
