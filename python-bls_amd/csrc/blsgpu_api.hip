@@ -12,6 +12,7 @@
 
 #include "../../include/blsgpu.h"
 #include "blsgpu_kernels.hip"
+#include "blsgpu_reg.hip"
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
 
@@ -50,6 +51,9 @@ struct blsgpu_ctx {
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
     size_t h2c_reg_threshold = 32768;  // messages from which cofactor clearing runs one message per lane
+    size_t msm_lane_threshold = 65536; // points from which the bucket sums run one (group, chunk, window) per lane
+    uint32_t* d_buckets = nullptr;     // their buckets (HBM)
+    size_t bucket_cap = 0;
     uint32_t* d_msm_part = nullptr;    // MSM partials
     size_t msm_part_cap = 0;           // in u32
     // optional per-kernel timing (blsgpu_timing_enable): HIP events recorded on
@@ -188,13 +192,17 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
     if ((groups == 1 && k >= c->pip_threshold) || (groups > 1 && groups <= 65535 && k >= c->pip_group_threshold)) {
         // bucket method: one large sum is cut into about 256 chunks; a batch of sums uses one chunk per group
         using P = blsgpu::PipCfg<DEG>;
-        size_t want = 256;
+        size_t n = k * groups;
+        // enough points for one (group, chunk, window) per lane to fill the chip?  (3 waves per SIMD = 3072 chunks)
+        const bool lane_path = n >= c->msm_lane_threshold;
+        size_t want = lane_path ? 3072 : 256;
         if (const char* e = getenv("BLSGPU_PIP_CHUNKS")) want = (size_t)strtoull(e, nullptr, 10);
         size_t chunk = (groups > 1) ? k : (k + want - 1) / want;
-        if (chunk < 64 * (size_t)C::NP && groups == 1) chunk = 64 * (size_t)C::NP;
-        chunk = ((chunk + C::NP - 1) / C::NP) * C::NP;
+        if (!lane_path && chunk < 64 * (size_t)C::NP && groups == 1) chunk = 64 * (size_t)C::NP;
+        if (!lane_path) chunk = ((chunk + C::NP - 1) / C::NP) * C::NP;
+        if (chunk == 0) chunk = 1;
         size_t chunks = (k + chunk - 1) / chunk;
-        size_t n = k * groups;
+        const size_t fold_n = (lane_path && chunks > 96) ? (chunks + 63) / 64 : 0;
         size_t need = (chunks + 1) * groups * blsgpu::PIP_W * 36 * DEG + n * 36 * DEG;
         if (need > c->msm_part_cap) {
             if (c->d_msm_part) (void)hipFree(c->d_msm_part);
@@ -209,12 +217,43 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
         hipLaunchKernelGGL(blsgpu::k_msm_prep<DEG>, dim3((unsigned)pblocks), dim3(MSM_WAVES * 64), (size_t)MSM_WAVES * blsgpu::TEAM_BYTES,
                            st, c->tabs, (const uint32_t*)d_pts, (uint32_t)n, d_prep);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(blsgpu::k_msm_pip<DEG>, dim3((unsigned)chunks, blsgpu::PIP_W, (unsigned)groups), dim3(64), (size_t)P::SLOTS * 48,
-                           st, c->tabs, d_prep, (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, c->d_msm_part);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(blsgpu::k_msm_pip_windows<DEG>, dim3(blsgpu::PIP_W, (unsigned)groups), dim3(64), (size_t)blsgpu::TEAM_BYTES, st,
-                           c->tabs, c->d_msm_part, (uint32_t)chunks, d_win);
-        HIP_TRY(hipGetLastError());
+        if (lane_path) {
+            // one (group, chunk, window) per lane, buckets in HBM
+            const size_t lanes = groups * chunks * blsgpu::PIP_W;
+            const size_t bneed = lanes * (blsgpu::PIP_NB - 1) * 36 * DEG + fold_n * groups * blsgpu::PIP_W * 36 * DEG;
+            if (bneed > c->bucket_cap) {
+                if (c->d_buckets) (void)hipFree(c->d_buckets);
+                c->d_buckets = nullptr;
+                c->bucket_cap = 0;
+                HIP_TRY(hipMalloc((void**)&c->d_buckets, bneed * sizeof(uint32_t)));
+                c->bucket_cap = bneed;
+            }
+            hipLaunchKernelGGL(blsgpu::k_msm_lane<DEG>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, d_prep,
+                               (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, (uint32_t)chunks, (uint32_t)lanes, c->d_buckets,
+                               c->d_msm_part);
+            HIP_TRY(hipGetLastError());
+            const uint32_t* winsrc = c->d_msm_part;
+            size_t wchunks = chunks;
+            if (fold_n) {                                    // many chunks: fold runs of 64 partials per lane first
+                uint32_t* d_fold = c->d_buckets + lanes * (blsgpu::PIP_NB - 1) * 36 * DEG;
+                const size_t ftotal = groups * blsgpu::PIP_W * fold_n;
+                hipLaunchKernelGGL(blsgpu::k_msm_lane_fold<DEG>, dim3((unsigned)((ftotal + 63) / 64)), dim3(64), 0, st, c->d_msm_part,
+                                   (uint32_t)chunks, 64u, (uint32_t)fold_n, (uint32_t)ftotal, d_fold);
+                HIP_TRY(hipGetLastError());
+                winsrc = d_fold;
+                wchunks = fold_n;
+            }
+            hipLaunchKernelGGL(blsgpu::k_msm_pip_windows<DEG>, dim3(blsgpu::PIP_W, (unsigned)groups), dim3(64), (size_t)blsgpu::TEAM_BYTES, st,
+                               c->tabs, winsrc, (uint32_t)wchunks, d_win);
+            HIP_TRY(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(blsgpu::k_msm_pip<DEG>, dim3((unsigned)chunks, blsgpu::PIP_W, (unsigned)groups), dim3(64), (size_t)P::SLOTS * 48,
+                               st, c->tabs, d_prep, (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, c->d_msm_part);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(blsgpu::k_msm_pip_windows<DEG>, dim3(blsgpu::PIP_W, (unsigned)groups), dim3(64), (size_t)blsgpu::TEAM_BYTES, st,
+                               c->tabs, c->d_msm_part, (uint32_t)chunks, d_win);
+            HIP_TRY(hipGetLastError());
+        }
         hipLaunchKernelGGL(blsgpu::k_msm_pip_horner<DEG>, dim3((unsigned)groups), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, d_win,
                            (uint32_t*)d_out, (uint8_t*)d_out_inf);
         HIP_TRY(hipGetLastError());
@@ -305,6 +344,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_MSM_LANE_THRESHOLD")) c->msm_lane_threshold = (size_t)strtoull(e, nullptr, 10);
     // pack all tables into one device allocation (16-byte aligned pieces)
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     size_t o_m = 0;
@@ -400,6 +440,7 @@ BLSGPU_EXPORT void blsgpu_ctx_destroy(blsgpu_ctx* c) {
     if (c->d_io) (void)hipFree(c->d_io);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_msm_part) (void)hipFree(c->d_msm_part);
+    if (c->d_buckets) (void)hipFree(c->d_buckets);
     if (c->ev0) {
         for (int i = 0; i < blsgpu_ctx::TIMING_SLOTS; i++) { (void)hipEventDestroy(c->ev0[i]); (void)hipEventDestroy(c->ev1[i]); }
         delete[] c->ev0; delete[] c->ev1; delete[] c->ev_kind;

@@ -392,4 +392,94 @@ __global__ void __launch_bounds__(64) k_msm_pip_horner(VmTables T, const uint32_
     if (out_inf && lane == 0) out_inf[blockIdx.x] = (nz == 0) ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------
+// Bucket method with ONE (group, chunk, window) PER LANE (blsgpu_reg.hip): the lanes of a
+// wavefront are the 64 windows of the same chunk of points, so they read the same point
+// (one broadcast load) and add it to the bucket their own digit selects.  The 15 buckets
+// of a lane live in HBM (144 B G1 / 288 B G2 each, read and written once per addition:
+// ~0.3 KB of traffic against ~9 k / 25 k instructions).  Used when a batch offers enough
+// lanes to fill the chip (blsgpu_api.hip); the LDS-bucket kernels above serve the rest.
+template <int DEG> struct LaneElem;
+template <> struct LaneElem<1> { typedef reg::fe E; };
+template <> struct LaneElem<2> { typedef reg::fe2 E; };
+
+__device__ __forceinline__ void lane_ld(reg::fe& x, const uint32_t* p, bool canon) {
+    for (int j = 0; j < 12; j++) x.v[j] = p[j];
+    if (canon) bls::fq_canon(x.v);
+}
+__device__ __forceinline__ void lane_ld(reg::fe2& x, const uint32_t* p, bool canon) { lane_ld(x.a, p, canon); lane_ld(x.b, p + 12, canon); }
+__device__ __forceinline__ void lane_st(const reg::fe& x, uint32_t* p) { for (int j = 0; j < 12; j++) p[j] = x.v[j]; }
+__device__ __forceinline__ void lane_st(const reg::fe2& x, uint32_t* p) { lane_st(x.a, p); lane_st(x.b, p + 12); }
+template <class E> __device__ __forceinline__ reg::ptT<E> lane_ld_pt(const uint32_t* p, bool canon) {
+    reg::ptT<E> r;
+    constexpr int W = sizeof(E) / 4;
+    lane_ld(r.X, p, canon); lane_ld(r.Y, p + W, canon); lane_ld(r.Z, p + 2 * W, canon);
+    return r;
+}
+template <class E> __device__ __forceinline__ void lane_st_pt(const reg::ptT<E>& r, uint32_t* p) {
+    constexpr int W = sizeof(E) / 4;
+    lane_st(r.X, p); lane_st(r.Y, p + W); lane_st(r.Z, p + 2 * W);
+}
+__device__ __forceinline__ void lane_one(reg::fe& x) { const uint32_t o[12] = BLS_ONE_MONT_LIMBS; for (int j = 0; j < 12; j++) x.v[j] = o[j]; }
+__device__ __forceinline__ void lane_one(reg::fe2& x) { lane_one(x.a); x.b = reg::fe_zero(); }
+template <class E> __device__ __forceinline__ reg::ptT<E> lane_inf() {         // (0 : 1 : 0)
+    reg::ptT<E> r;
+    E z;
+    uint32_t* zp = reinterpret_cast<uint32_t*>(&z);
+    for (unsigned j = 0; j < sizeof(E) / 4; j++) zp[j] = 0;
+    r.X = z; r.Z = z; lane_one(r.Y);
+    return r;
+}
+
+// prep: projective Montgomery points of k_msm_prep; partial (win, chunk) of group g is written at
+// partials[((g * PIP_W + win) * chunks + chunk) * PJ_DW] -- the layout k_msm_pip_windows reads.
+template <int DEG>
+__global__ void __launch_bounds__(64) k_msm_lane(const uint32_t* __restrict__ prep, const uint32_t* __restrict__ scalars, uint32_t k,
+                                                 uint32_t chunk, uint32_t chunks, uint32_t total, uint32_t* __restrict__ buckets,
+                                                 uint32_t* __restrict__ partials) {
+    typedef typename LaneElem<DEG>::E E;
+    constexpr uint32_t PJ_DW = 36 * DEG;
+    const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= total) return;
+    const uint32_t win = L & 63u, cidx = (L >> 6) % chunks, grp = (L >> 6) / chunks;
+    const uint32_t lo = grp * k + cidx * chunk, hi = min(grp * k + k, lo + chunk);
+    uint32_t* B = buckets + (size_t)L * (PIP_NB - 1) * PJ_DW;                   // buckets 1 .. 15
+    {
+        const reg::ptT<E> inf = lane_inf<E>();
+        for (int j = 0; j < PIP_NB - 1; j++) lane_st_pt(inf, B + j * PJ_DW);
+    }
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t dig;
+        if (scalars) dig = (bswap32(scalars[(size_t)i * 8 + (7 - win / 8)]) >> (4 * (win % 8))) & 15u;
+        else dig = (win == 0) ? 1u : 0u;
+        if (dig) {
+            uint32_t* b = B + (dig - 1) * PJ_DW;
+            const reg::ptT<E> r = reg::padd(lane_ld_pt<E>(b, false), lane_ld_pt<E>(prep + (size_t)i * PJ_DW, true));
+            lane_st_pt(r, b);
+        }
+    }
+    reg::ptT<E> acc = lane_inf<E>(), tot = lane_inf<E>();                       // sum_j j B_j by running sums
+#pragma unroll 1
+    for (int j = PIP_NB - 2; j >= 0; j--) {
+        acc = reg::padd(acc, lane_ld_pt<E>(B + j * PJ_DW, false));
+        tot = reg::padd(tot, acc);
+    }
+    lane_st_pt(tot, partials + (((size_t)grp * PIP_W + win) * chunks + cidx) * PJ_DW);
+}
+
+// out[w * nfold + f] = sum of partials[w * chunks + f * per .. + per): one run per lane
+template <int DEG>
+__global__ void __launch_bounds__(64) k_msm_lane_fold(const uint32_t* __restrict__ partials, uint32_t chunks, uint32_t per, uint32_t nfold,
+                                                      uint32_t total, uint32_t* __restrict__ out) {
+    typedef typename LaneElem<DEG>::E E;
+    constexpr uint32_t PJ_DW = 36 * DEG;
+    const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= total) return;
+    const uint32_t w = L / nfold, f = L % nfold;
+    const uint32_t lo = f * per, hi = min(chunks, lo + per);
+    reg::ptT<E> acc = lane_inf<E>();
+    for (uint32_t i = lo; i < hi; i++) acc = reg::padd(acc, lane_ld_pt<E>(partials + ((size_t)w * chunks + i) * PJ_DW, false));
+    lane_st_pt(acc, out + ((size_t)w * nfold + f) * PJ_DW);
+}
+
 }  // namespace blsgpu

@@ -109,6 +109,29 @@ def test_threshold_combine_batched(engine, golden):
     assert out.hex() == small["combined_affine"]
 
 
+def _engine_with(names):
+    import os
+    from bls_py import _native
+    old = {k: os.environ.get(k) for k in names}
+    for k in names:
+        os.environ[k] = "1"
+    try:
+        e = _native.Engine(0)
+    finally:
+        for k in names:
+            if old[k] is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = old[k]
+    return e
+
+
+@pytest.fixture(scope="module")
+def lane_engine():
+    """An engine whose sums use the bucket method with one (group, chunk, window) per lane from 1 point on."""
+    return _engine_with(("BLSGPU_PIP_THRESHOLD", "BLSGPU_PIP_GROUP_THRESHOLD", "BLSGPU_MSM_LANE_THRESHOLD"))
+
+
 @pytest.fixture(scope="module")
 def pip_engine():
     """An engine whose single sums use the bucket method from 1 point on."""
@@ -186,3 +209,32 @@ def test_bucket_method_batches_vs_oracle(pip_engine, oracle, seeded_pairs, k, gr
         w2, _ = oracle.g2_msm(pts2[192 * k * g:192 * k * (g + 1)], sc[k * g:k * (g + 1)], k)
         assert out1[96 * g:96 * (g + 1)] == w1 and inf1[g] == (w1 == bytes(96))
         assert out2[192 * g:192 * (g + 1)] == w2 and inf2[g] == (w2 == bytes(192))
+
+
+@pytest.mark.parametrize("k,groups", [(1, 1), (7, 1), (200, 1), (1000, 1), (5, 4), (67, 3)])
+def test_lane_bucket_method_vs_oracle(lane_engine, oracle, seeded_pairs, k, groups):
+    """k_msm_lane (buckets in HBM, one window per lane; chunks of 1 point at these sizes for a
+    single sum, so the chunk fold kernel runs too), G1 and G2."""
+    g1, g2 = seeded_pairs
+    rnd = random.Random(k * 11 + groups)
+    n = k * groups
+    pts1, pts2 = (g1 * 2)[96 * 5:96 * (5 + n)], (g2 * 2)[192 * 5:192 * (5 + n)]
+    sc = [rnd.choice([rnd.randrange(N), rnd.randrange(1 << 40), 0, N - 1, 1]) for _ in range(n)]
+    out1, inf1 = lane_engine.g1_msm(pts1, sc, k, groups)
+    for g in range(groups):
+        w1, _ = oracle.g1_msm(pts1[96 * k * g:96 * k * (g + 1)], sc[k * g:k * (g + 1)], k)
+        assert out1[96 * g:96 * (g + 1)] == w1 and inf1[g] == (w1 == bytes(96))
+    if n <= 400:
+        out2, _ = lane_engine.g2_msm(pts2, sc, k, groups)
+        for g in range(groups):
+            assert out2[192 * g:192 * (g + 1)] == oracle.g2_msm(pts2[192 * k * g:192 * k * (g + 1)], sc[k * g:k * (g + 1)], k)[0]
+
+
+def test_lane_bucket_method_degenerate(lane_engine, engine, golden):
+    p = golden("points.json")
+    P = bytes.fromhex(p["g1"][3]["p"])
+    negP = P[:48] + ((Q - int.from_bytes(P[48:], "big")) % Q).to_bytes(48, "big")
+    assert lane_engine.g1_msm(P + negP, None, 2) == (bytes(96), [True])
+    assert lane_engine.g1_msm(P * 3, [0, 0, 0], 3) == (bytes(96), [True])
+    assert lane_engine.g1_msm(P + bytes(96), [7, 9], 2) == engine.g1_msm(P, [7], 1)
+    assert lane_engine.g1_msm(P * 40, [5] * 40, 40) == engine.g1_msm(P, [200], 1)
