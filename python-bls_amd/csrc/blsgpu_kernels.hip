@@ -69,7 +69,7 @@ __device__ __forceinline__ void lds_store12(const uint32_t* x, uint32_t idx16) {
 // per-lane record length of a round, in u16 units (wave-uniform)
 __device__ __forceinline__ uint32_t rec_len(uint32_t meta) {
     if ((meta & 3u) != 1u) return 4u;
-    return (((meta >> 8) & 0xFFu) + 2u + 3u) & ~3u;      // destination, compensation count, K micro-ops
+    return (((meta >> 8) & 0xFFu) + 2u + 3u) & ~3u;      // destination, merge flags, K micro-ops
 }
 
 // global-address-space views: a pointer taken out of the kernel-argument struct
@@ -198,7 +198,7 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
             uint64_t acc[12];
 #pragma unroll
             for (int j = 0; j < 12; j++) acc[j] = 0;
-            // record: destination, compensation count, micro-ops; micro-op p sits at
+            // record: destination, merge flags, micro-ops; micro-op p sits at
             // position p + 2; operands are fetched one micro-op ahead into two
             // alternating buffers
             uint32_t S[2][12];

@@ -128,109 +128,12 @@ BLS_HD bool fq_is_zero(const uint32_t* a) {
     return t == 0;
 }
 
-// ---- lazy linear combinations -------------------------------------------
-// A LIN op accumulates sum(+/- slot << s) exactly in a 13-limb two's-complement
-// accumulator (|sum| < 128 q) and reduces once.
-#define BLS_128Q_LIMBS \
-    {0xffd55580u, 0xff7fffffu, 0xa9ffffdcu, 0x55ffff58u, 0x587b120fu, 0x9869507bu, 0xc2895fb3u, 0x3ba5c279u, 0xa5d66bb2u, 0x8dd3db21u, 0xbff34d25u, 0x0088f51cu, 0x0000000du}
-
-// acc += s  /  acc -= s   (s: 12 limbs, zero-extended)
-BLS_HD void acc_add(uint32_t* __restrict__ acc, const uint32_t* __restrict__ s) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 12; j++) acc[j] = addc(acc[j], s[j], c);
-    acc[12] += c;
-}
-BLS_HD void acc_sub(uint32_t* __restrict__ acc, const uint32_t* __restrict__ s) {
-    uint32_t br = 0;
-#pragma unroll
-    for (int j = 0; j < 12; j++) acc[j] = subc(acc[j], s[j], br);
-    acc[12] -= br;
-}
-// acc +/-= s << sh  (0 <= sh < 32; sh and neg may differ per lane)
-BLS_HD void acc_add_shifted(uint32_t* __restrict__ acc, const uint32_t* __restrict__ s, uint32_t sh, bool neg) {
-    uint32_t x[13];
-    uint32_t prev = 0;
-#pragma unroll
-    for (int j = 0; j < 12; j++) {
-        x[j] = (uint32_t)(((((uint64_t)s[j]) << 32) | prev) >> (32 - sh));
-        prev = s[j];
-    }
-    x[12] = (uint32_t)(((uint64_t)prev) >> (32 - sh));
-    const uint32_t m = neg ? 0xffffffffu : 0u;
-    uint32_t c = neg ? 1u : 0u;
-#pragma unroll
-    for (int j = 0; j < 13; j++) acc[j] = addc(acc[j], x[j] ^ m, c);
-}
-// acc +/-= 2 s
-BLS_HD void acc_add2(uint32_t* __restrict__ acc, const uint32_t* __restrict__ s) {
-    uint32_t c = 0, prev = 0;
-#pragma unroll
-    for (int j = 0; j < 12; j++) {
-        acc[j] = addc(acc[j], (s[j] << 1) | (prev >> 31), c);
-        prev = s[j];
-    }
-    acc[12] = acc[12] + (prev >> 31) + c;
-}
-BLS_HD void acc_sub2(uint32_t* __restrict__ acc, const uint32_t* __restrict__ s) {
-    uint32_t br = 0, prev = 0;
-#pragma unroll
-    for (int j = 0; j < 12; j++) {
-        acc[j] = subc(acc[j], (s[j] << 1) | (prev >> 31), br);
-        prev = s[j];
-    }
-    acc[12] = acc[12] - (prev >> 31) - br;
-}
-// out = acc mod q, canonical; requires -128q < acc < 128q
-BLS_HD void acc_reduce(uint32_t* __restrict__ out, const uint32_t* __restrict__ acc_in) {
-    const uint32_t q[12] = BLS_Q_LIMBS;
-    const uint32_t off[13] = BLS_128Q_LIMBS;
-    uint32_t a[13];
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 13; j++) a[j] = addc(acc_in[j], off[j], c);
-    // 0 <= a < 256 q < 2^389.  Quotient estimate from the top 40 bits.
-    float hf = (float)a[12] * 4294967296.0f + (float)a[11];
-    float kf = hf * (1.0f / 436277738.0f);          // q >> 352 = 0x1a0111ea
-    uint32_t k = (uint32_t)kf;
-    k = (k > 1u) ? k - 2u : 0u;                     // never above the true quotient
-    // a -= k * q
-    uint64_t mc = 0;
-    uint32_t br = 0;
-#pragma unroll
-    for (int j = 0; j < 12; j++) {
-        mc += (uint64_t)k * q[j];
-        a[j] = subc(a[j], (uint32_t)mc, br);
-        mc >>= 32;
-    }
-    a[12] = a[12] - (uint32_t)mc - br;
-    // now 0 <= a < 4q : conditional subtractions of 2q and q
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        uint32_t d[13];
-        uint32_t b2 = 0;
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            uint32_t qq = pass == 0 ? ((q[j] << 1) | (j ? (q[j - 1] >> 31) : 0u)) : q[j];
-            d[j] = subc(a[j], qq, b2);
-        }
-        d[12] = subc(a[12], pass == 0 ? (q[11] >> 31) : 0u, b2);
-        const bool ge = (b2 == 0);
-#pragma unroll
-        for (int j = 0; j < 13; j++) a[j] = ge ? d[j] : a[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 12; j++) out[j] = a[j];
-}
-
 // ---- relaxed residues ------------------------------------------------------
 // Inside the VM every stored value is only kept below 2q ("relaxed"): the
 // Montgomery product of two values below 3q is below 2q without a final
 // subtraction, and a linear combination is brought back below 2q with one
 // quotient estimate.  Canonical form is restored where it is observable
 // (outputs, the inversion's zero test).
-#define BLS_256Q_LIMBS \
-    {0xffaaab00u, 0xfeffffffu, 0x53ffffb9u, 0xabfffeb1u, 0xb0f6241eu, 0x30d2a0f6u, 0x8512bf67u, 0x774b84f3u, 0x4bacd764u, 0x1ba7b643u, 0x7fe69a4bu, 0x0111ea39u, 0x0000001au}
 
 // r = a * b * R^-1 mod q with r < 2q for a * b < 9 q^2 (host model of fq_mul_dev<false>)
 BLS_HD void fq_mul_relaxed(uint32_t* __restrict__ r, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b) {
@@ -264,35 +167,12 @@ BLS_HD void fq_canon(uint32_t* __restrict__ x) {
 #pragma unroll
     for (int j = 0; j < 12; j++) x[j] = ge ? d[j] : x[j];
 }
-// out = acc mod q with 0 <= out < 2q; requires -256q < acc < 256q
-BLS_HD void acc_reduce_relaxed(uint32_t* __restrict__ out, const uint32_t* __restrict__ acc_in) {
-    const uint32_t q[12] = BLS_Q_LIMBS;
-    const uint32_t off[13] = BLS_256Q_LIMBS;
-    uint32_t a[13];
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 13; j++) a[j] = addc(acc_in[j], off[j], c);
-    // 0 < a < 512 q.  e = a / q to within 1e-4; k = floor(e - 1e-3) is k* or k* - 1,
-    // so a - k q lies in [0, 2q).
-    float hf = (float)a[12] * 4294967296.0f + (float)a[11];
-    float e = hf * (1.0f / 436277738.0f) - 0.001f;      // q >> 352 = 0x1a0111ea
-    uint32_t k = (e > 0.0f) ? (uint32_t)e : 0u;
-    uint64_t mc = 0;
-    uint32_t br = 0;
-#pragma unroll
-    for (int j = 0; j < 12; j++) {
-        mc += (uint64_t)k * q[j];
-        out[j] = subc(a[j], (uint32_t)mc, br);
-        mc >>= 32;
-    }
-}
-
 // ---- carry-free linear combinations (the VM's LIN rounds) --------------------
 // gfx950 needs wait states between a VALU write of VCC and a dependent VALU read,
 // so long v_addc chains are slow.  A linear combination is therefore accumulated
 // limb by limb into 64-bit "fat" limbs with independent v_mad_u64_u32 (no carries,
-// no VCC), negative terms entering through the 384-bit complement (vmgen/core.py
-// lower_lin), and carries are resolved once in fat_reduce.
+// no VCC): first the negative terms as plain sums, one sign flip (fat_flip), then the
+// positive terms (vmgen/emit.py plan_lin_round); carries are resolved once in fat_reduce.
 #define BLS_QC_LIMBS /* 2^384 - q */ \
     {0x00005555u, 0x46010000u, 0x4eac0000u, 0xe1540001u, 0x094f09dbu, 0x98cf2d5fu, 0x0c7aed40u, 0x9b88b47bu, 0xbcb45328u, 0xb4e45849u, 0xc6801965u, 0xe5feee15u}
 
@@ -308,11 +188,6 @@ BLS_HD void fat_flip(uint64_t* __restrict__ acc) {
 BLS_HD void fat_mac_plain(uint64_t* __restrict__ acc, const uint32_t* __restrict__ s, uint32_t cf) {
 #pragma unroll
     for (int j = 0; j < 12; j++) acc[j] += (uint64_t)s[j] * cf;
-}
-// acc[j] += cf * (s[j] ^ negmask),  negmask = 0 or 0xffffffff
-BLS_HD void fat_mac(uint64_t* __restrict__ acc, const uint32_t* __restrict__ s, uint32_t cf, uint32_t negmask) {
-#pragma unroll
-    for (int j = 0; j < 12; j++) acc[j] += (uint64_t)(s[j] ^ negmask) * cf;
 }
 // out = V mod q with 0 <= out < 2q, V = sum acc[j] 2^(32 j) < 2^396 (every acc[j] < 2^44)
 BLS_HD void fat_reduce(uint32_t* __restrict__ out, const uint64_t* __restrict__ acc) {
@@ -355,52 +230,7 @@ BLS_HD void fq_sgn(uint32_t* __restrict__ out, const uint32_t* __restrict__ a) {
     for (int j = 0; j < 12; j++) out[j] = gt ? onem[j] : 0u;
 }
 
-// ---- helpers for the inversion ------------------------------------------
-BLS_HD bool big_is_one(const uint32_t* a) {
-    uint32_t t = a[0] ^ 1u;
-#pragma unroll
-    for (int j = 1; j < 12; j++) t |= a[j];
-    return t == 0;
-}
-BLS_HD bool big_geq(const uint32_t* a, const uint32_t* b) {   // a >= b
-    uint32_t br = 0;
-#pragma unroll
-    for (int j = 0; j < 12; j++) {
-        uint64_t x = (uint64_t)a[j] - b[j] - br;
-        br = (uint32_t)(x >> 63);
-    }
-    return br == 0;
-}
-BLS_HD void big_sub(uint32_t* a, const uint32_t* b) {         // a -= b (a >= b)
-    uint32_t br = 0;
-#pragma unroll
-    for (int j = 0; j < 12; j++) {
-        uint64_t x = (uint64_t)a[j] - b[j] - br;
-        a[j] = (uint32_t)x;
-        br = (uint32_t)(x >> 63);
-    }
-}
-BLS_HD void big_shr1(uint32_t* a, uint32_t top) {             // a = (top:a) >> 1
-#pragma unroll
-    for (int j = 0; j < 11; j++) a[j] = (a[j] >> 1) | (a[j + 1] << 31);
-    a[11] = (a[11] >> 1) | (top << 31);
-}
-// x = x / 2 mod q  (x < q)
-BLS_HD void fq_half(uint32_t* x) {
-    const uint32_t q[12] = BLS_Q_LIMBS;
-    uint32_t carry = 0;
-    if (x[0] & 1u) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            c += (uint64_t)x[j] + q[j];
-            x[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        carry = (uint32_t)c;
-    }
-    big_shr1(x, carry);
-}
+// ---- modular subtraction (register arithmetic of blsgpu_reg.hip) ------------
 // x = (x - y) mod q  (x, y < q)
 BLS_HD void fq_sub_mod(uint32_t* x, const uint32_t* y) {
     const uint32_t q[12] = BLS_Q_LIMBS;

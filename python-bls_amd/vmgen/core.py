@@ -153,12 +153,14 @@ K1_SLOT = None         # set by programs.py: slot holding -(2^384 - 1) mod q
 
 
 def lower_lin(terms):
-    """[(coef, V)] -> list of (neg, coef, V|"K1").
-
-    The GPU accumulates only non-negative quantities: a negative term -c*x is
-    added as c * (2^384 - 1 - x) (limb-wise complement) and the surplus
-    c * (2^384 - 1) is cancelled by one extra micro-op  N * K1,
-    K1 = -(2^384 - 1) mod q, N = sum of the negative coefficients."""
+    """[(coef, V)] -> list of (neg, coef, V|"K1"): the SCHEDULE-LEVEL form of a linear
+    combination, which vmgen/sim.py executes exactly.  It models subtraction with
+    non-negative quantities only: a negative term -c*x is c * (2^384 - 1 - x) (limb-wise
+    complement) and the surplus c * (2^384 - 1) is cancelled by one extra micro-op
+    N * K1, K1 = -(2^384 - 1) mod q, N = sum of the negative coefficients.
+    The PACKED tables the kernel runs re-sort these terms (emit.plan_lin_round: negative
+    terms first as plain sums, one sign flip, positive terms; the K1 entries are dropped);
+    vmgen/tablesim.py executes that form."""
     uops = []
     mag = nmag = 0
     for c, v in terms:

@@ -1,4 +1,5 @@
-"""Bit-exact Python interpreter for the VM tables (CPU check of the schedules).
+"""Python interpreter for the SCHEDULED programs (CPU check of formulas, scheduling and
+slot allocation; the packed encoding the kernel decodes is checked by tablesim.py).
 
 Works in the GPU's own value domain: every slot holds the Montgomery content
 x*R mod q (R = 2^384), MUL is a*b*R^-1 mod q, a LIN op is an exact sum of
