@@ -166,7 +166,7 @@ DIRECT_SEGS = ["mul_0_1", "from_mont_1_0", "to_mont_0_1", "copy_1_0",     # call
                "h1_a", "h1w_a", "h1_b", "h1_c", "d1_a", "d1_c", "d2_a", "d2_b", "d2_c"]
 POW_SEG = re.compile(r"^(h1_(sqr|mul)[23]|d1_(sqr|mul)|d2[pq]_(sqr|mul))$")
 MSM_NP = {1: 6, 2: 2}                                         # points per team in the MSM kernels
-H1_NE, H2_NM = 12, 2                                          # encodings / messages per team (hash to G2)
+H1_NE, H2_NM = 12, 3                                          # encodings / messages per team (hash to G2)
 D1_NE, D2_NE = 32, 16                                         # points per team (decompression)
 
 

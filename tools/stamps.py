@@ -9,7 +9,7 @@ e.lib.blsgpu_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_u
 g1 = open(os.path.join(ROOT, "tests/golden/pairs_seed1_g1.bin"), "rb").read()
 g2 = open(os.path.join(ROOT, "tests/golden/pairs_seed1_g2.bin"), "rb").read()
 buf = (ctypes.c_ulonglong * 9)()
-for n in (1025, 1025, 4, 8200):
+for n in (1025, 1025, 4, 8200, 32800):
     reps = (n + 1024) // 1025
     e.pairing_multi((g1 * reps)[:96 * n], (g2 * reps)[:192 * n], n)
     e.lib.blsgpu_debug_stamps(e.h, ctypes.byref(buf))
