@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) k_h2c_hash(const uint32_t* __restrict__ m
 // ---------------------------------------------------------------------------
 // Fixed-exponent powers x^((q-3)/4) -- the square-root / Legendre-symbol exponent of
 // vmgen/h2c_programs.py and decomp_programs.py -- in registers, one value per lane: 379
-// squarings + 190 products with no table, no LDS.  The VM programs around it are cut into
+// squarings + ~110 products (sliding window, odd powers in registers), no LDS.  The VM programs around it are cut into
 // stages that hand their scratchpad state over through an image in HBM:
 //   stage kernel (few rounds) -> k_pow on the image's BASE slots -> next stage kernel ...
 // image: per team the slots [STATE0, STATE1) of its scratchpad, 12 u32 each.
@@ -91,17 +91,36 @@ __global__ void __launch_bounds__(256) k_pow(uint32_t* __restrict__ img, uint32_
     const uint32_t team = v / cnt, k = v % cnt;
     const uint32_t* src = img + ((size_t)team * img_slots + base_off + k) * 12;
     uint32_t* dst = img + ((size_t)team * img_slots + acc_off + k) * 12;
-    uint32_t b[12], a[12];
+    // sliding window over the fixed exponent (vmgen/emit.pow_windows): odd powers b, b^3, ... in registers
+    constexpr int NT = 1 << (BLSVM_POW_WINDOW - 1);
+    uint32_t tbl[NT][12], a[12], t[12];
 #pragma unroll
-    for (int j = 0; j < 12; j++) { b[j] = src[j]; a[j] = b[j]; }
-    const uint32_t e[12] = {BLSVM_POW_E[0], BLSVM_POW_E[1], BLSVM_POW_E[2],  BLSVM_POW_E[3],  BLSVM_POW_E[4], BLSVM_POW_E[5],
-                            BLSVM_POW_E[6], BLSVM_POW_E[7], BLSVM_POW_E[8],  BLSVM_POW_E[9],  BLSVM_POW_E[10], BLSVM_POW_E[11]};
+    for (int j = 0; j < 12; j++) tbl[0][j] = src[j];
+    bls::fq_mul_relaxed(t, tbl[0], tbl[0]);
+#pragma unroll
+    for (int i = 1; i < NT; i++) bls::fq_mul_relaxed(tbl[i], tbl[i - 1], t);
+    auto pick = [&](uint32_t* m, uint32_t k) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            m[j] = tbl[0][j];
+#pragma unroll
+            for (int i = 1; i < NT; i++) m[j] = (k == (uint32_t)i) ? tbl[i][j] : m[j];
+        }
+    };
+    pick(a, BLSVM_POW_WIN[0][1]);
 #pragma unroll 1
-    for (int bit = BLSVM_POW_E_BITS - 2; bit >= 0; bit--) {
-        uint32_t t[12];
-        bls::fq_mul_relaxed(t, a, a);
-        if ((e[bit >> 5] >> (bit & 31)) & 1u) bls::fq_mul_relaxed(a, t, b);
-        else {
+    for (int s = 1; s < BLSVM_POW_STEPS; s++) {
+        const uint32_t nsq = BLSVM_POW_WIN[s][0], k = BLSVM_POW_WIN[s][1];
+#pragma unroll 1
+        for (uint32_t i = 0; i < nsq; i++) {
+            bls::fq_mul_relaxed(t, a, a);
+#pragma unroll
+            for (int j = 0; j < 12; j++) a[j] = t[j];
+        }
+        if (k != 255u) {
+            uint32_t m[12];
+            pick(m, k);
+            bls::fq_mul_relaxed(t, a, m);
 #pragma unroll
             for (int j = 0; j < 12; j++) a[j] = t[j];
         }

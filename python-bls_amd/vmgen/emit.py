@@ -158,6 +158,38 @@ def pack(segs, order):
     return seg_rounds, data
 
 
+POW_WINDOW = 3
+
+
+def pow_windows(e, w=POW_WINDOW):
+    """Left-to-right sliding-window schedule of b^e: [(squarings, k)] -- do `squarings`
+    squarings, then multiply by the odd power b^(2k+1) (k = 255: no product).  The first
+    entry has no squarings: it loads b^(2k+1)."""
+    bits = bin(e)[2:]
+    out, i, pend = [], 0, 0
+    while i < len(bits):
+        if bits[i] == "0":
+            pend += 1
+            i += 1
+            continue
+        L = min(w, len(bits) - i)
+        while bits[i + L - 1] == "0":
+            L -= 1
+        v = int(bits[i:i + L], 2)
+        out.append((pend + L if out else 0, (v - 1) // 2))
+        assert out[-1][0] < 255
+        pend = 0
+        i += L
+    if pend:
+        out.append((pend, 255))
+    # replay with integers
+    acc = None
+    for nsq, k in out:
+        acc = 2 * k + 1 if acc is None else (acc << nsq) + (0 if k == 255 else 2 * k + 1)
+    assert acc == e
+    return out
+
+
 def limbs32(v):
     return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(12)]
 
@@ -244,6 +276,10 @@ def generate(path=None, verbose=False):
         w("#define BLSVM_%s_ACC %d\n#define BLSVM_%s_BASE %d\n#define BLSVM_%s_STATE0 %d\n#define BLSVM_%s_STATE1 %d\n" % (tag, dlay.ACC, tag, dlay.BASE, tag, dlay.X, tag, dlay.TEMP0))
     w("static const uint32_t BLSVM_POW_E[12] = {%s};   /* (q - 3) / 4 */\n#define BLSVM_POW_E_BITS %d\n" % (
         ", ".join("0x%08xu" % ((HP.EXP_E >> (32 * i)) & 0xFFFFFFFF) for i in range(12)), HP.EXP_E.bit_length()))
+    pw = pow_windows(HP.EXP_E)
+    w("/* sliding-window schedule of the same power: {squarings, k}: a <- a^(2^squarings) * b^(2k+1); k = 255: no product */\n")
+    w("#define BLSVM_POW_WINDOW %d\n#define BLSVM_POW_STEPS %d\n" % (POW_WINDOW, len(pw)))
+    w("static const uint8_t BLSVM_POW_WIN[%d][2] = {%s};\n" % (len(pw), ", ".join("{%d, %d}" % x for x in pw)))
     flat("BLSVM_H2_FLAT", [r for n in h2script for r in seg_rounds[n]])
     flat("BLSVM_MILLER_FLAT", mflat)
     flat("BLSVM_FEXP_FLAT", fflat)
