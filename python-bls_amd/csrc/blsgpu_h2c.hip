@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) k_pow(uint32_t* __restrict__ img, uint32_
     uint32_t tbl[NT][12], a[12], t[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) tbl[0][j] = src[j];
-    bls::fq_mul_relaxed(t, tbl[0], tbl[0]);
+    bls::fq_sqr_relaxed(t, tbl[0]);
 #pragma unroll
     for (int i = 1; i < NT; i++) bls::fq_mul_relaxed(tbl[i], tbl[i - 1], t);
     auto pick = [&](uint32_t* m, uint32_t k) {
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) k_pow(uint32_t* __restrict__ img, uint32_
         const uint32_t nsq = BLSVM_POW_WIN[s][0], k = BLSVM_POW_WIN[s][1];
 #pragma unroll 1
         for (uint32_t i = 0; i < nsq; i++) {
-            bls::fq_mul_relaxed(t, a, a);
+            bls::fq_sqr_relaxed(t, a);
 #pragma unroll
             for (int j = 0; j < 12; j++) a[j] = t[j];
         }

@@ -156,6 +156,17 @@ BLS_HD void fq_mul_relaxed(uint32_t* __restrict__ r, const uint32_t* __restrict_
     for (int j = 0; j < 12; j++) r[j] = t[j];   // t[12] == 0 whenever the result is below 2^384
 #endif
 }
+// r = a^2 * R^-1 mod q with r < 2q for a < 3q: the dedicated squaring columns on the GPU
+// (fq_mul_gfx950.h: 78 + 144 multiply-accumulates instead of 288), the product on the host
+BLS_HD void fq_sqr_relaxed(uint32_t* __restrict__ r, const uint32_t* __restrict__ a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    fq_sqr_dev(r, a);
+#else
+    uint32_t b[12];
+    for (int j = 0; j < 12; j++) b[j] = a[j];
+    fq_mul_relaxed(r, a, b);
+#endif
+}
 // x (< 2q) -> canonical
 BLS_HD void fq_canon(uint32_t* __restrict__ x) {
     const uint32_t q[12] = BLS_Q_LIMBS;
