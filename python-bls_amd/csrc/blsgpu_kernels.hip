@@ -108,14 +108,26 @@ struct RecReader {
     }
 };
 
-// 64-bit value of another lane of the same quad (quad_perm control CTRL)
-// of the READING lane's `mask` (0 or ~0): the value if the lane absorbs it, else 0
 template <int CTRL>
-__device__ __forceinline__ uint64_t dpp_quad64(uint64_t v, uint32_t mask) {
-    uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, CTRL, 0xF, 0xF, true) & mask;
-    uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true) & mask;
-    return ((uint64_t)hi << 32) | lo;
-}
+__device__ __forceinline__ void dpp_quad_absorb(uint64_t& acc, uint32_t mask);
+#define BLSGPU_DPP_ABSORB(CTRL, PERM)                                                                            \
+    template <>                                                                                                  \
+    __device__ __forceinline__ void dpp_quad_absorb<CTRL>(uint64_t& acc, uint32_t mask) {                        \
+        uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32), t0, t1;                                        \
+        asm volatile("v_and_b32_dpp %2, %0, %4 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  \
+                     "v_and_b32_dpp %3, %1, %4 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  \
+                     "v_add_co_u32 %0, vcc, %0, %2\n\t"                                                          \
+                     "v_addc_co_u32 %1, vcc, %1, %3, vcc"                                                        \
+                     : "+v"(lo), "+v"(hi), "=&v"(t0), "=&v"(t1)                                                  \
+                     : "v"(mask)                                                                                 \
+                     : "vcc");                                                                                   \
+        acc = ((uint64_t)hi << 32) | lo;                                                                         \
+    }
+// acc += (the accumulator of another lane of the same quad) & mask, mask = 0 or ~0 of the
+// READING lane (the value if the lane absorbs it, else 0): four instructions per limb
+BLSGPU_DPP_ABSORB(0xF5, "[1,1,3,3]")       // lanes 0,2 of a quad += lanes 1,3
+BLSGPU_DPP_ABSORB(0xAA, "[2,2,2,2]")       // lane 0 += lane 2
+#undef BLSGPU_DPP_ABSORB
 
 // Walk `n` rounds of a flat sequence on the team whose scratchpad starts at
 // base16 (16-byte units).  Round headers are read three rounds ahead and every
@@ -238,13 +250,15 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
             const uint32_t levels = (meta >> 16) & 3u;
             if (levels >= 1u) {
                 const uint32_t m1 = (uint32_t)((int32_t)(w1 << 17) >> 31);
+                asm volatile("s_nop 4");      // the hazard recogniser does not see the DPP reads inside the asm blocks
 #pragma unroll
-                for (int j = 0; j < 12; j++) acc[j] += dpp_quad64<0xF5>(acc[j], m1);   // lanes 0,2 of a quad += lanes 1,3
+                for (int j = 0; j < 12; j++) dpp_quad_absorb<0xF5>(acc[j], m1);
             }
             if (levels >= 2u) {
                 const uint32_t m2 = (uint32_t)((int32_t)(w1 << 16) >> 31);
+                asm volatile("s_nop 4");
 #pragma unroll
-                for (int j = 0; j < 12; j++) acc[j] += dpp_quad64<0xAA>(acc[j], m2);   // lane 0 += lane 2
+                for (int j = 0; j < 12; j++) dpp_quad_absorb<0xAA>(acc[j], m2);
             }
 #ifdef BLSGPU_STAMPS
             asm volatile("" :: "v"(acc[0]), "v"(acc[11]));
