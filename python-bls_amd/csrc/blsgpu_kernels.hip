@@ -178,12 +178,18 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
         h0 = h1;
         h1.x = __builtin_amdgcn_readfirstlane(hraw.x); h1.y = __builtin_amdgcn_readfirstlane(hraw.y);
         if (i + 3 < n) hraw = ld2(seq, i + 3);
-        if (i + 1 < n) {
+        {
+            // (after the last round h0 still holds a valid, older header: the fetch is harmless)
             gptr_u2 rec = (gptr_u2)(gdata + BLSGPU_DOFF(h0) + lane * rec_len(h0.y));
             const uint32_t nchn = rec_len(h0.y) >> 2;
 #pragma unroll
-            for (int c = 0; c < LIN_CHUNKS; c++)
-                if (c < (int)nchn) nx[c] = ld2(rec, c);
+            for (int c = 0; c < LIN_CHUNKS; c++) {
+                // chunks past the record are never read: leave their registers as they are
+                // instead of carrying a value around the loop (a register copy per chunk and round)
+                uint2 any;
+                asm volatile("" : "=v"(any.x), "=v"(any.y));
+                nx[c] = (c < (int)nchn) ? ld2(rec, c) : any;
+            }
         }
         const uint32_t kind = meta & 3u;
         if (kind == 0u) {                                    // MUL
