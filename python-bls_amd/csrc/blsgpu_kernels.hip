@@ -165,19 +165,20 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
 #ifdef BLSGPU_STAMPS
     unsigned long long st_acc[4] = {0, 0, 0, 0}, st_cnt[4] = {0, 0, 0, 0}, st_lin[3] = {0, 0, 0};
 #endif
-    for (uint32_t i = 0; i < n; ++i) {
+    uint32_t i = 0;                                          // rounds started (advanced inside `round`)
+    // one round: `ch` = this round's lane record (fetched during the previous round),
+    // `nxt` receives the next round's
+    auto round = [&](const uint2 (&ch)[LIN_CHUNKS], uint2 (&nxt)[LIN_CHUNKS]) __attribute__((always_inline)) {
 #ifdef BLSGPU_STAMPS
         unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #endif
         const uint32_t meta = h0.y;
-        uint2 ch[LIN_CHUNKS];
-#pragma unroll
-        for (int c = 0; c < LIN_CHUNKS; c++) ch[c] = nx[c];
         const uint2 e_cur = ch[0];
         // ---- prefetch for the following rounds
         h0 = h1;
         h1.x = __builtin_amdgcn_readfirstlane(hraw.x); h1.y = __builtin_amdgcn_readfirstlane(hraw.y);
         if (i + 3 < n) hraw = ld2(seq, i + 3);
+        ++i;
         {
             // (after the last round h0 still holds a valid, older header: the fetch is harmless)
             gptr_u2 rec = (gptr_u2)(gdata + BLSGPU_DOFF(h0) + lane * rec_len(h0.y));
@@ -188,7 +189,7 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
                 // instead of carrying a value around the loop (a register copy per chunk and round)
                 uint2 any;
                 asm volatile("" : "=v"(any.x), "=v"(any.y));
-                nx[c] = (c < (int)nchn) ? ld2(rec, c) : any;
+                nxt[c] = (c < (int)nchn) ? ld2(rec, c) : any;
             }
         }
         const uint32_t kind = meta & 3u;
@@ -307,6 +308,24 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
         st_acc[kind] += __builtin_amdgcn_s_memtime() - st_t0;
         st_cnt[kind] += 1;
 #endif
+    };
+    if (LIGHT) {
+        // two copies of the round with the record buffers swapped: no register copies
+        // from the prefetch buffer to the current one (8 x 64 bit per round)
+        uint2 nb[LIN_CHUNKS];
+        while (true) {
+            round(nx, nb);
+            if (i >= n) break;
+            round(nb, nx);
+            if (i >= n) break;
+        }
+    } else {
+        while (i < n) {
+            uint2 ch[LIN_CHUNKS];
+#pragma unroll
+            for (int c = 0; c < LIN_CHUNKS; c++) ch[c] = nx[c];
+            round(ch, nx);
+        }
     }
 #ifdef BLSGPU_STAMPS
     if (T.stamps && blockIdx.x == 0 && threadIdx.x == 0)
