@@ -201,7 +201,9 @@ __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t*
         team[BLSVM_H2_S * 12 + d] = enc[((size_t)(e / BLSVM_H1_NE) * H1_IMG + (BLSVM_H1_S - BLSVM_H1_STATE0) + 5 * (e % BLSVM_H1_NE)) * 12 + d % 60];
     }
     wave_fence();
-    run_rounds(T, T.h2flat, BLSVM_H2_FLAT_LEN, 0, lane);
+    // the two double-and-add chains hold products and sums only: the light interpreter
+    run_rounds<true>(T, T.h2flat, BLSVM_H2_FLAT_LEN - BLSVM_H2_FINAL_LEN, 0, lane);
+    run_rounds(T, T.h2flat + (BLSVM_H2_FLAT_LEN - BLSVM_H2_FINAL_LEN), BLSVM_H2_FINAL_LEN, 0, lane);
     if (lane < 4u * BLSVM_H2_NM) {
         uint32_t X[12];
         lds_load12(X, (BLSVM_H2_OUT + lane) * 3);

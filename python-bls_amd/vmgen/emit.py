@@ -281,6 +281,8 @@ def generate(path=None, verbose=False):
     w("#define BLSVM_POW_WINDOW %d\n#define BLSVM_POW_STEPS %d\n" % (POW_WINDOW, len(pw)))
     w("static const uint8_t BLSVM_POW_WIN[%d][2] = {%s};\n" % (len(pw), ", ".join("{%d, %d}" % x for x in pw)))
     flat("BLSVM_H2_FLAT", [r for n in h2script for r in seg_rounds[n]])
+    assert h2script[-1] == "h2_final" and all(r["kind"] in ("mul", "lin") for n in h2script[:-1] for r in segs[n].rounds)
+    w("#define BLSVM_H2_FINAL_LEN %d   /* rounds of the last segment (the only one with an inversion) */\n" % len(seg_rounds["h2_final"]))
     flat("BLSVM_MILLER_FLAT", mflat)
     flat("BLSVM_FEXP_FLAT", fflat)
     for deg, (msegs, lay) in msm.items():
