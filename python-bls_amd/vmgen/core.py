@@ -149,6 +149,7 @@ class Builder:
 # ---------------------------------------------------------------------------
 MAX_COEF = 31          # a micro-op adds coef * x, x = slot or its 384-bit complement
 MAX_LIN_MAG = 160      # sum of |coefficients| per linear combination
+FOLD_COPY_MAX_OPS = 48  # a linear round takes folded output copies up to this many combinations
 K1_SLOT = None         # set by programs.py: slot holding -(2^384 - 1) mod q
 
 
@@ -196,7 +197,7 @@ class Segment:
         self.stats = {}
 
 
-def schedule(b, temp_base=0, lanes=LANES, verbose=False):
+def schedule(b, temp_base=0, lanes=LANES, verbose=False, fold_copies=True):
     """List-schedule builder b into rounds and allocate slots.
 
     Returns a Segment.  Temporaries are allocated upwards from slot temp_base.
@@ -378,6 +379,26 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False):
                 K = max(K, len(u))
                 lanes_out.append((u, slot[v.id]))
             seg.rounds.append({"kind": "lin", "K": K, "lanes": lanes_out})
+    # A copy temp -> output slot fits into an EXISTING linear round r when the value is
+    # there (its producer ran before r) and the slot's old content has no reader after r
+    # (inside a round every lane reads before any lane writes): no round of its own.
+    # Pass-through copies (source = an input slot) keep their final round.
+    if copies and fold_copies:
+        passthrough_src = {v.fixed for v, _ in copies if v.kind == "in"}
+        rest = []
+        for v, fx in copies:
+            best = None
+            if v.kind != "in" and fx not in passthrough_src:
+                r0 = max(round_of[v.id] + 1, fixed_busy_until.get(fx, -1))
+                for ri in range(r0, nrounds):
+                    r = seg.rounds[ri]
+                    if r["kind"] == "lin" and len(r["lanes"]) < FOLD_COPY_MAX_OPS and (best is None or len(r["lanes"]) <= len(seg.rounds[best]["lanes"])):
+                        best = ri
+            if best is None:
+                rest.append((v, fx))
+            else:
+                seg.rounds[best]["lanes"].append(([(0, 1, slot[v.id])], fx))
+        copies = rest
     # final copy rounds (dst <- src as a 1-uop LIN); a chain of copies whose
     # destination is another copy's source must be ordered: do them in one
     # round, which is safe because every lane reads before any lane writes.
