@@ -164,3 +164,47 @@ def test_packed_tables_decode_like_the_kernel(golden):
         t.run(sr["mul_0_1"])
         acc = [t.team[P.reg(0) + i] for i in range(12)]
     assert got == finish(acc)
+
+
+def test_fixed_power_window_schedule():
+    """The sliding-window schedule k_pow walks (emit.pow_windows) spells the exponent (q - 3) / 4 and,
+    replayed on integers, gives the same power as pow()."""
+    from vmgen import h2c_programs as HP
+    q = sim.Q
+    assert HP.EXP_E == (q - 3) // 4
+    for w in (1, 2, 3, 4, 5):
+        sched = emit.pow_windows(HP.EXP_E, w)            # asserts the exponent identity itself
+        assert sched[0][0] == 0 and all(k == 255 or k < (1 << (w - 1)) for _, k in sched)
+    sched = emit.pow_windows(HP.EXP_E)
+    b = 0x1234567890abcdef1234567890abcdef % q
+    odd = [pow(b, 2 * k + 1, q) for k in range(1 << (emit.POW_WINDOW - 1))]
+    acc = odd[sched[0][1]]
+    for nsq, k in sched[1:]:
+        for _ in range(nsq):
+            acc = acc * acc % q
+        if k != 255:
+            acc = acc * odd[k] % q
+    assert acc == pow(b, HP.EXP_E, q)
+
+
+def test_squaring_columns_of_the_generated_kernel():
+    """gen_fqmul.generate_sqr takes each cross product once against the doubled operand
+    (d'[k] = a[k] << 1 next to the diagonal, d[k] = (a[k] << 1) | (a[k-1] >> 31) above): the
+    column sums must add up to a^2 for every a < 2^383 (2a fits twelve limbs)."""
+    import random
+    rng = random.Random(5)
+    cases = [0, 1, (1 << 383) - 1, 4 * sim.Q - 1 if 4 * sim.Q < (1 << 383) else (1 << 383) - 1, 0x80000000 << 64]
+    cases += [rng.randrange(1 << 383) for _ in range(300)]
+    M = 0xFFFFFFFF
+    for a in cases:
+        A = [(a >> (32 * i)) & M for i in range(12)]
+        e = [0] + [(A[k] << 1) & M for k in range(1, 12)]
+        d = [0] + [e[k] | (A[k - 1] >> 31) for k in range(1, 12)]
+        tot = 0
+        for i in range(23):
+            for j in range(max(0, i - 11), (i + 1) // 2):
+                k = i - j
+                tot += A[j] * (e[k] if k == j + 1 else d[k]) << (32 * i)
+            if i % 2 == 0:
+                tot += A[i // 2] ** 2 << (32 * i)
+        assert tot == a * a
