@@ -36,6 +36,26 @@ PEAK_TMACS = 34.65        # measured v_mad_u64_u32 rate, profiles/r01_intrate_mi
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(kernel, pairings_per_launch):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc passes
+    (FETCH_SIZE + WRITE_SIZE, KB per dispatch; profiles/r01_bench_pmc_summary.csv, collected by
+    tools/profile_round.sh on this same workload).  Counters cannot be read inside this process,
+    so the figure is only reported for the profiled shape (32 800 pairings per k_miller_mp launch);
+    FETCH_SIZE is left uncorrected (dword table loads are outside the guide's x2 calibration)."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.csv")
+    if kernel != "k_miller_mp" or pairings_per_launch != 32800 or not os.path.exists(path):
+        return None
+    kb = {}
+    with open(path) as f:
+        for row in f:
+            c = row.strip().split(",")
+            if len(c) == 4 and c[0].endswith(kernel) and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                kb[c[1]] = float(c[3])
+    if len(kb) != 2:
+        return None
+    return int((kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024)
+
+
 def cpu_baseline(g1, g2, n):
     """The oracle (CPU restatement of the reference's algorithm) on the host
     cores of this box; bounded sample = the same 1025-pair batch, once."""
@@ -216,6 +236,7 @@ def main():
         # region (launches do not overlap each other, see step())
         miller_avg = sum(miller_ms) / len(miller_ms)
         ach = MAC_PER_PAIRING * n * B / (miller_avg * 1e-3) / 1e12
+        kname = "k_miller_mp" if n * B >= 2048 else "k_miller"
         line = {
             "metric": "BLS12-381 pairings/sec (aggregate_verify multi-pairing)",
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps,
@@ -226,8 +247,10 @@ def main():
                        "pairs_per_verification_per_gpu": n, "verifications_per_step": B, "pairs_per_step_per_gpu": n * B,
                        "parallelism": "shard%d+allgather%dB" % (world, 576 * B), "steps_in_flight": S, "check": check},
             "roofline": {"bound": "valu-int32-mac", "achieved": ach, "peak": PEAK_TMACS, "unit": "TMAC/s",
-                         "frac": ach / PEAK_TMACS, "traffic": None,
-                         "kernel": "k_miller_mp" if n * B >= 2048 else "k_miller",
+                         "frac": ach / PEAK_TMACS, "traffic": pmc_traffic(kname, n * B),
+                         "traffic_unit": "bytes per launch, offline rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (profiles/r01_bench_pmc_summary.csv)",
+                         "algorithmic_bytes_per_launch": (HBM_BYTES_PER_PAIRING * n * B + 576 * ((n + 2) // 3) * B),
+                         "kernel": kname,
                          "kernel_launches_timed": len(miller_ms), "kernel_ms_avg": miller_avg,
                          "pairings_per_launch": n * B, "mac_per_pairing": MAC_PER_PAIRING,
                          "reduce_kernels_ms_per_step": sum(reduce_ms) / max(1, len(miller_ms)),
