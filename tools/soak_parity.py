@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (GPU box): random subsets of the seeded pairs, random sizes and
+group shapes, degenerate coordinates sprinkled in, through both Miller kernels and the batch
+entry point, every result against the CPU oracle.  Not part of the test-suite (minutes of
+oracle time); prints one line per trial and a summary."""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "python-bls_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+
+
+def main():
+    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    import oracle as O
+    from bls_py import _native
+    O.build()
+    eng = _native.Engine(0)
+    gold = os.path.join(ROOT, "tests", "golden")
+    g1 = open(os.path.join(gold, "pairs_seed1_g1.bin"), "rb").read()
+    g2 = open(os.path.join(gold, "pairs_seed1_g2.bin"), "rb").read()
+    rng = random.Random(20261003)
+    bad = 0
+    t0 = time.time()
+
+    def pick(n, degenerate):
+        a, b = [], []
+        for _ in range(n):
+            i = rng.randrange(1025)
+            p, q = g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)]
+            if degenerate and rng.random() < 0.05:
+                kind = rng.randrange(3)
+                if kind == 0:
+                    p = bytes(96)                       # P = (0, 0): factor 1
+                elif kind == 1:
+                    q = bytes(192)                      # Q = (0, 0)
+                else:
+                    p, q = bytes(96), bytes(192)
+            a.append(p)
+            b.append(q)
+        return b"".join(a), b"".join(b)
+
+    for t in range(trials):
+        mode = t % 3
+        if mode == 0:                                   # one multi-pairing, one-pair kernel
+            n = rng.choice([1, 2, 3, 5, 63, 64, 65, 127, 200, 257])
+            a, b = pick(n, t % 2 == 1)
+            eng.set_mp_threshold(1 << 40)
+            got = eng.pairing_multi(a, b, n)
+            want = O.pairing_multi(a, b, n, threads=16)
+            ok = got == want
+        elif mode == 1:                                 # one multi-pairing, three-pair kernel
+            n = rng.choice([3, 4, 7, 100, 191, 192, 193, 500, 1025])
+            a, b = pick(n, t % 2 == 0)
+            eng.set_mp_threshold(0)
+            got = eng.pairing_multi(a, b, n)
+            want = O.pairing_multi(a, b, n, threads=16)
+            ok = got == want
+        else:                                           # batch of equal-sized groups
+            gsz, groups = rng.choice([(1, 40), (2, 33), (5, 17), (23, 9), (24, 9), (25, 8), (67, 5), (130, 3)])
+            a, b = pick(gsz * groups, t % 2 == 0)
+            eng.set_mp_threshold(rng.choice([0, 4096, 1 << 40]))
+            got = eng.pairing_multi_batch(a, b, gsz, groups)
+            want = b"".join(O.pairing_multi(a[96 * gsz * g:96 * gsz * (g + 1)], b[192 * gsz * g:192 * gsz * (g + 1)], gsz, threads=16)
+                            for g in range(groups))
+            ok = got == want
+            n = gsz * groups
+        bad += 0 if ok else 1
+        print("trial %d mode %d pairs %d %s  (%.0f s)" % (t, mode, n, "ok" if ok else "MISMATCH", time.time() - t0), flush=True)
+    print("soak: %d trials, %d mismatches" % (trials, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
