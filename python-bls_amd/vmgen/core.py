@@ -197,7 +197,7 @@ class Segment:
         self.stats = {}
 
 
-def schedule(b, temp_base=0, lanes=LANES, verbose=False, fold_copies=True):
+def schedule(b, temp_base=0, lanes=LANES, verbose=False, fold_copies=True, lazy_lin=False):
     """List-schedule builder b into rounds and allocate slots.
 
     Returns a Segment.  Temporaries are allocated upwards from slot temp_base.
@@ -269,28 +269,23 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False, fold_copies=True):
             pending.remove(v)
         rounds.append(r)
 
-    level = 0
-    while pending:
-        # LIN phase: all ready linear ops, sub-level by sub-level
-        while True:
-            rl = [v for v in pending if v.kind == "lin" and all(s.id in done for s in srcs(v))]
-            if not rl:
-                break
-            rl.sort(key=lambda v: -prio[v.id])
-            if len(rl) <= lanes:
-                emit("lin", rl)
-            else:
-                # more ops than lanes: deal them out by length so that every round of the
-                # level keeps free lanes for splitting its long combinations (emit.py)
-                nr = (len(rl) + lanes - 1) // lanes
-                by_len = sorted(rl, key=lambda v: -len(v.terms))
-                for r in range(nr):
-                    emit("lin", by_len[r::nr])
-        if not pending:
-            break
-        level += 1
-        for kind in ("inv", "sgn", "mul"):
-            rh = [v for v in pending if v.kind == kind and all(s.id in done for s in srcs(v))]
+    def emit_lins(rl):
+        rl.sort(key=lambda v: -prio[v.id])
+        if len(rl) <= lanes:
+            emit("lin", rl)
+        else:
+            # more ops than lanes: deal them out by length so that every round of the
+            # level keeps free lanes for splitting its long combinations (emit.py)
+            nr = (len(rl) + lanes - 1) // lanes
+            by_len = sorted(rl, key=lambda v: -len(v.terms))
+            for r in range(nr):
+                emit("lin", by_len[r::nr])
+
+    def choose_heavy(ready_ids, level, kinds=("inv", "sgn", "mul")):
+        """the heavy ops of the next level among those whose sources are in ready_ids"""
+        out = []
+        for kind in kinds:
+            rh = [v for v in pending if v.kind == kind and all(s.id in ready_ids for s in srcs(v))]
             must = [v for v in rh if alap[v.id] <= level]
             if not must:
                 continue
@@ -298,8 +293,82 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False, fold_copies=True):
             opt = sorted([v for v in rh if alap[v.id] > level], key=lambda v: (alap[v.id], -prio[v.id]))
             chosen = must + opt[:cap - len(must)]
             chosen.sort(key=lambda v: -prio[v.id])
-            for i in range(0, len(chosen), lanes):
-                emit(kind, chosen[i:i + lanes])
+            out.append((kind, chosen))
+        return out
+
+    level = 0
+    while pending:
+        if lazy_lin is True and any(heavy(v) for v in pending):
+            # LIN phase, on demand: decide the next level's heavy ops first (looking through
+            # the linear ops that COULD run now), then run only the linear ops they read;
+            # the others wait for their own consumers, which spreads the linear work over
+            # the levels instead of piling it up in front of the first one
+            reach = set(done)
+            grew = True
+            lin_pending = [v for v in pending if v.kind == "lin"]
+            while grew:
+                grew = False
+                for v in lin_pending:
+                    if v.id not in reach and all(s.id in reach for s in srcs(v)):
+                        reach.add(v.id)
+                        grew = True
+            level += 1
+            plan = choose_heavy(reach, level)
+            need, stack = set(), [s for _, ch in plan for v in ch for s in srcs(v)]
+            while stack:
+                x = stack.pop()
+                if x.id in done or x.id in need or x.kind != "lin":
+                    continue
+                need.add(x.id)
+                stack += srcs(x)
+            while True:
+                rl = [v for v in pending if v.id in need and all(s.id in done for s in srcs(v))]
+                if not rl:
+                    break
+                emit_lins(rl)
+            for kind, chosen in plan:
+                for i in range(0, len(chosen), lanes):
+                    emit(kind, chosen[i:i + lanes])
+            assert level <= depth + 2 * len(ops), "scheduler failed to progress"
+            continue
+        # LIN phase: all ready linear ops, sub-level by sub-level
+        while True:
+            rl = [v for v in pending if v.kind == "lin" and all(s.id in done for s in srcs(v))]
+            if not rl:
+                break
+            if lazy_lin == "overflow" and len(rl) > lanes and any(heavy(v) for v in pending):
+                # more ready combinations than lanes: run what the next level's heavy ops read
+                # (looking through the linear ops that could run now) and as many of the others
+                # as fit the same number of rounds; the rest waits for a later linear phase
+                reach = set(done)
+                grew = True
+                lin_pending = [v for v in pending if v.kind == "lin"]
+                while grew:
+                    grew = False
+                    for v in lin_pending:
+                        if v.id not in reach and all(s.id in reach for s in srcs(v)):
+                            reach.add(v.id)
+                            grew = True
+                need, stack = set(), [s for _, ch in choose_heavy(reach, level + 1) for v in ch for s in srcs(v)]
+                while stack:
+                    x = stack.pop()
+                    if x.id in done or x.id in need or x.kind != "lin":
+                        continue
+                    need.add(x.id)
+                    stack += srcs(x)
+                now = [v for v in rl if v.id in need]
+                if now:
+                    cap = lanes * ((len(now) + lanes - 1) // lanes)
+                    rest = sorted([v for v in rl if v.id not in need], key=lambda v: -prio[v.id])
+                    rl = now + rest[:cap - len(now)]
+            emit_lins(rl)
+        if not pending:
+            break
+        level += 1
+        for only in ("inv", "sgn", "mul"):               # a kind sees the results of the kinds before it
+            for kind, chosen in choose_heavy(done, level, (only,)):
+                for i in range(0, len(chosen), lanes):
+                    emit(kind, chosen[i:i + lanes])
         assert level <= depth + 2 * len(ops), "scheduler failed to progress"
     # ---- live ranges -----------------------------------------------------
     last_use = {}

@@ -476,11 +476,16 @@ def build_multi(cfg=None, G=MP_G, verbose=False):
     cfg = cfg or tw.Cfg()
     lazy = lazy_cfg(cfg)
     script, first_add = miller_script("mp_init", "mp_body")
-    builders = [seg_init(lazy, first_add, G, "mp_init")]
+    builders = [(seg_init(lazy, first_add, G, "mp_init"), False)]
     for name in sorted(set(script[1:])):
         cur_add, nxt = int(name[-2]), int(name[-1])
-        builders.append(seg_body(lazy if (cur_add, nxt) in ((0, 0), (0, 2)) else cfg, cur_add, nxt, G, "mp_body"))
+        # Every body takes unmaterialised Fq2 products.  The bodies with a chord step would
+        # not fit the scratchpad that way (179 / 189 temporaries with 178 to spare) unless
+        # their linear combinations are scheduled on demand (core.schedule lazy_lin), which
+        # costs a few more rounds there but frees ~60 slots; the plain doubling body keeps
+        # the as-soon-as-possible order (fewest rounds).
+        builders.append((seg_body(lazy, cur_add, nxt, G, "mp_body"), (cur_add, nxt) != (0, 0)))
     segs = {}
-    for b in builders:
-        segs[b.name] = schedule(b, temp_base=mp_temp0(G), verbose=verbose)
+    for b, on_demand in builders:
+        segs[b.name] = schedule(b, temp_base=mp_temp0(G), verbose=verbose, lazy_lin=on_demand)
     return segs, script
