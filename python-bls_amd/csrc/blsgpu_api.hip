@@ -50,7 +50,7 @@ struct blsgpu_ctx {
     size_t mp_threshold = 4096;        // pairs from which k_miller_mp is used
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
-    size_t h2c_reg_threshold = 40960;  // messages from which cofactor clearing runs one message per lane
+    size_t h2c_reg_threshold = 57344;  // messages from which cofactor clearing runs one message per lane
     size_t msm_lane_threshold = 65536; // points from which the bucket sums run one (group, chunk, window) per lane
     uint32_t* d_buckets = nullptr;     // their buckets (HBM)
     size_t bucket_cap = 0;

@@ -222,8 +222,8 @@ __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t*
 // formulas as vmgen/h2c_programs.build_h2: complete projective addition / doubling
 // of Renes-Costello-Batina for a = 0, the endomorphism psi, ec.py:536-550).  The
 // point arithmetic of one message is strictly sequential (two double-and-add chains
-// by |x|), so the 64-lane VM keeps three messages per wavefront busy at ~55 % of its
-// lanes; here every lane carries a message and nothing but products and modular
+// by |x|), so the 64-lane VM needs five messages per wavefront to keep its
+// lanes busy; here every lane carries a message and nothing but products and modular
 // additions is executed.  The field product is a real function call (s_swappc, operands
 // by value in VGPRs): inlining 36 products per point addition would not fit the
 // instruction cache.

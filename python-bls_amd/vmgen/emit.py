@@ -198,7 +198,7 @@ DIRECT_SEGS = ["mul_0_1", "from_mont_1_0", "to_mont_0_1", "copy_1_0",     # call
                "h1_a", "h1w_a", "h1_b", "h1_c", "d1_a", "d1_c", "d2_a", "d2_b", "d2_c"]
 POW_SEG = re.compile(r"^(h1_(sqr|mul)[23]|d1_(sqr|mul)|d2[pq]_(sqr|mul))$")
 MSM_NP = {1: 6, 2: 2}                                         # points per team in the MSM kernels
-H1_NE, H2_NM = 12, 3                                          # encodings / messages per team (hash to G2)
+H1_NE, H2_NM = 12, 5                                          # encodings / messages per team (hash to G2)
 D1_NE, D2_NE = 32, 16                                         # points per team (decompression)
 
 
@@ -281,8 +281,8 @@ def generate(path=None, verbose=False):
     w("#define BLSVM_POW_WINDOW %d\n#define BLSVM_POW_STEPS %d\n" % (POW_WINDOW, len(pw)))
     w("static const uint8_t BLSVM_POW_WIN[%d][2] = {%s};\n" % (len(pw), ", ".join("{%d, %d}" % x for x in pw)))
     flat("BLSVM_H2_FLAT", [r for n in h2script for r in seg_rounds[n]])
-    assert h2script[-1] == "h2_final" and all(r["kind"] in ("mul", "lin") for n in h2script[:-1] for r in segs[n].rounds)
-    w("#define BLSVM_H2_FINAL_LEN %d   /* rounds of the last segment (the only one with an inversion) */\n" % len(seg_rounds["h2_final"]))
+    assert h2script[-1] == "h2_affine" and all(r["kind"] in ("mul", "lin") for n in h2script[:-1] for r in segs[n].rounds)
+    w("#define BLSVM_H2_FINAL_LEN %d   /* rounds of the last segment (the only one with an inversion) */\n" % len(seg_rounds["h2_affine"]))
     flat("BLSVM_MILLER_FLAT", mflat)
     flat("BLSVM_FEXP_FLAT", fflat)
     for deg, (msegs, lay) in msm.items():

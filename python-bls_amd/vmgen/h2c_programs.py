@@ -274,14 +274,29 @@ def build_h2(NM, cfg=None, verbose=False):
     for m in range(NM):
         _out_pt(b, _pt(b, L.A, m), L.T0, m, zero)
     done(b)
-    b = Builder("h2_final")                            # A = [x^2]P, T0 = [x]P  (ec.py:540-550)
+    # The closing combination  R = ([x^2]P + [x]P - P) - psi([x]P + P) + psi^2(2P)  (ec.py:540-550)
+    # runs as a chain of ONE point operation per message and segment, reusing the loop's
+    # segments where it can: as one wide segment it needed three times the temporaries of the
+    # double-and-add loop and so dictated the scratchpad size (and with it how many messages a
+    # team and how many teams a compute unit hold) for 6 % of the rounds.
+    # here A = [x^2]P, T0 = [x]P:   A += T0;  A -= P;  T0 += P;  T0 = psi(T0);  A -= T0;
+    #                                T0 = 2P;  T0 = psi(psi(T0));  A += T0;  affine(A)
+    for name, dst, fn in (
+            ("h2_sub_p", "A", lambda b, m: padd(F, _pt(b, L.A, m), neg(_pt(b, L.P, m)))),
+            ("h2_t0_add_p", "T0", lambda b, m: padd(F, _pt(b, L.T0, m), _pt(b, L.P, m))),
+            ("h2_psi_t0", "T0", lambda b, m: psi(b, _pt(b, L.T0, m))),
+            ("h2_sub_t0", "A", lambda b, m: padd(F, _pt(b, L.A, m), neg(_pt(b, L.T0, m)))),
+            ("h2_dbl_p", "T0", lambda b, m: pdbl(F, _pt(b, L.P, m))),
+            ("h2_psi2_t0", "T0", lambda b, m: psi(b, matp(psi(b, _pt(b, L.T0, m)))))):
+        b = Builder(name)
+        zero = b.inp(C_ZERO)
+        for m in range(NM):
+            _out_pt(b, fn(b, m), getattr(L, dst), m, zero)
+        done(b)
+    b = Builder("h2_affine")
     zero, raw1 = b.inp(C_ZERO), b.inp(C_RAW1)
     for m in range(NM):
-        P, T0, T1 = _pt(b, L.P, m), _pt(b, L.T0, m), _pt(b, L.A, m)
-        t2 = matp(padd(F, matp(padd(F, T1, T0)), neg(P)))
-        t3 = matp(psi(b, matp(padd(F, T0, P))))
-        p2 = matp(psi(b, matp(psi(b, matp(pdbl(F, P))))))
-        R = matp(padd(F, matp(padd(F, t2, neg(t3))), p2))
+        R = _pt(b, L.A, m)
         zi = tw.f2_inv(cfg, R[2])
         xa, ya = cfg.mul2(R[0], zi), cfg.mul2(R[1], zi)
         for k, v in enumerate((xa, ya)):
@@ -297,5 +312,6 @@ def build_h2(NM, cfg=None, verbose=False):
             if ch == "1":
                 sc.append(add_seg)
         return sc
-    script = ["h2_start"] + mul_x("h2_add_p") + ["h2_save_t0"] + mul_x("h2_add_t0") + ["h2_final"]
+    script = ["h2_start"] + mul_x("h2_add_p") + ["h2_save_t0"] + mul_x("h2_add_t0") + \
+             ["h2_add_t0", "h2_sub_p", "h2_t0_add_p", "h2_psi_t0", "h2_sub_t0", "h2_dbl_p", "h2_psi2_t0", "h2_add_t0", "h2_affine"]
     return segs, L, script
