@@ -443,27 +443,25 @@ __global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, c
 constexpr int MP_TEAM_DW = BLSVM_MP_TEAM_SLOTS * 12;
 constexpr int MP_TEAM_BYTES = MP_TEAM_DW * 4;
 
-__device__ __forceinline__ uint32_t mp_pair_base(uint32_t g) {
-    return g == 0 ? (uint32_t)BLSVM_SLOT_PX : (uint32_t)(BLSVM_MP_BLOCK0 + BLSVM_PAIR_BLOCK * (g - 1));
-}
-// raw big-endian pair -> 6 limb slots starting at slot `dst`
-__device__ __forceinline__ void load_pair_raw(uint32_t* team, uint32_t dst, const uint32_t* __restrict__ g1,
+// raw big-endian pair -> limb slots: P (2 values) from slot `p_slot`, Q (4 values) from `q_slot`
+__device__ __forceinline__ void load_pair_raw(uint32_t* team, uint32_t p_slot, uint32_t q_slot, const uint32_t* __restrict__ g1,
                                               const uint32_t* __restrict__ g2, size_t pair, uint32_t lane) {
     for (uint32_t d = lane; d < 72; d += 64) {
         uint32_t w = (d < 24) ? g1[pair * 24 + d] : g2[pair * 48 + (d - 24)];
         uint32_t e = d / 12, k = d % 12;
-        team[(dst + e) * 12 + (11 - k)] = bswap32(w);
+        uint32_t slot = (e < 2) ? p_slot + e : q_slot + (e - 2);
+        team[slot * 12 + (11 - k)] = bswap32(w);
     }
 }
 // bit0: P == (0,0); bit1: P.y == 0; bit2: Q == (0,0)   (wave-uniform result)
-__device__ __forceinline__ uint32_t pair_flags(const uint32_t* team, uint32_t slot, uint32_t lane) {
-    uint32_t v0 = team[slot * 12 + lane];                          // dwords 0..63 of the 72
-    uint32_t v1 = (lane < 8) ? team[slot * 12 + 64 + lane] : 0u;   // dwords 64..71
-    uint64_t nz0 = __ballot(v0 != 0), nz1 = __ballot(v1 != 0);
+__device__ __forceinline__ uint32_t pair_flags(const uint32_t* team, uint32_t p_slot, uint32_t q_slot, uint32_t lane) {
+    uint32_t vp = (lane < 24) ? team[p_slot * 12 + lane] : 0u;     // 24 dwords of P
+    uint32_t vq = (lane < 48) ? team[q_slot * 12 + lane] : 0u;     // 48 dwords of Q
+    uint64_t nzp = __ballot(vp != 0), nzq = __ballot(vq != 0);
     uint32_t f = 0;
-    if ((nz0 & 0xFFFFFFull) == 0) f |= 1u;
-    if ((nz0 & 0xFFF000ull) == 0) f |= 2u;
-    if ((nz0 >> 24) == 0 && nz1 == 0) f |= 4u;
+    if (nzp == 0) f |= 1u;
+    if ((nzp & 0xFFF000ull) == 0) f |= 2u;
+    if (nzq == 0) f |= 4u;
     return f;
 }
 
@@ -477,22 +475,21 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
     const uint32_t cnt = min((uint32_t)BLSVM_MP_G, gsz - in_grp);
     team_init_consts(T, team, lane);
     wave_fence();
-    // the multi-pair tables address the scratchpad with the gamma constants
-    // squeezed out: every slot >= BLSVM_NCONST sits BLSVM_MP_SHIFT lower
+    // the multi-pair programs have their own scratchpad layout (vmgen/programs.MPLayout)
     uint32_t special = (cnt < (uint32_t)BLSVM_MP_G) ? 1u : 0u;
     for (uint32_t g = 0; g < cnt; ++g) {
-        load_pair_raw(team, mp_pair_base(g) - BLSVM_MP_SHIFT, g1, g2, first + g, lane);
+        load_pair_raw(team, BLSVM_MP_CORE + 14u * g, BLSVM_MP_Q + 4u * g, g1, g2, first + g, lane);
         wave_fence();
-        special |= pair_flags(team, mp_pair_base(g) - BLSVM_MP_SHIFT, lane);
+        special |= pair_flags(team, BLSVM_MP_CORE + 14u * g, BLSVM_MP_Q + 4u * g, lane);
     }
     if (!special) {
         run_rounds<true>(T, T.mpflat, BLSVM_MP_FLAT_LEN, 0, lane);
     } else {
         bool have = false;
         for (uint32_t g = 0; g < cnt; ++g) {
-            load_pair_raw(team, BLSVM_SLOT_PX, g1, g2, first + g, lane);
+            load_pair_raw(team, BLSVM_SLOT_PX, BLSVM_SLOT_QX0, g1, g2, first + g, lane);
             wave_fence();
-            const uint32_t fl = pair_flags(team, BLSVM_SLOT_PX, lane);
+            const uint32_t fl = pair_flags(team, BLSVM_SLOT_PX, BLSVM_SLOT_QX0, lane);
             if (fl & 4u) team_set_acc(team, lane, !(fl & 2u));
             else if (fl & 1u) team_set_acc(team, lane, true);
             else run_rounds<true>(T, T.mflat, BLSVM_MILLER_FLAT_LEN, 0, lane);
@@ -504,7 +501,7 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
         if (!have) team_set_acc(team, lane, true);
     }
     wave_fence();
-    const uint32_t f_dw = special ? (uint32_t)F_DW : (uint32_t)(F_DW - BLSVM_MP_SHIFT * 12);
+    const uint32_t f_dw = special ? (uint32_t)F_DW : (uint32_t)(BLSVM_MP_F * 12);
     for (uint32_t i = lane; i < 144; i += 64) partials[(size_t)blockIdx.x * 144 + i] = team[f_dw + i];
 }
 

@@ -110,13 +110,8 @@ def pack(segs, order):
     for name in order:
         seg = segs[name]
         lst = []
-        if name.startswith("mp_"):
-            def mv(s):
-                assert s < P.C_GAM or s >= P.NCONST, "multi-pair program touches a gamma constant"
-                return s if s < P.C_GAM else s - P.MP_SHIFT
-        else:
-            def mv(s):
-                return s
+        def mv(s):                                    # (every program is built in the kernel's own slot numbers)
+            return s
         for rnd in seg.rounds:
             off = len(data)
             assert off % 4 == 0
@@ -205,7 +200,7 @@ D1_NE, D2_NE = 32, 16                                         # points per team 
 def build_tables(verbose=False):
     """Everything the header is made of, as Python objects (also what tablesim runs)."""
     segs, mscript, fscript = P.build_all(verbose=verbose)
-    mpsegs, mpscript = P.build_multi(verbose=verbose)
+    mpsegs, mpscript, mplay = P.build_multi(verbose=verbose)
     segs.update(mpsegs)
     msm = {}
     for deg, NP in MSM_NP.items():
@@ -227,7 +222,7 @@ def build_tables(verbose=False):
     # squaring / multiplication segments stay out of the packed tables
     order = sorted(n for n in segs if not POW_SEG.match(n))
     seg_rounds, data = pack(segs, order)
-    return dict(segs=segs, mscript=mscript, fscript=fscript, mpsegs=mpsegs, mpscript=mpscript, msm=msm,
+    return dict(segs=segs, mscript=mscript, fscript=fscript, mpsegs=mpsegs, mpscript=mpscript, mplay=mplay, msm=msm,
                 h1=(h1segs, h1lay, h1script), h1w=(h1segs, h1lay, h1wscript), h2=(h2segs, h2lay, h2script),
                 d1=(d1segs, d1lay, d1script), d2=(d2segs, d2lay, d2script), order=order,
                 seg_rounds=seg_rounds, data=data)
@@ -241,7 +236,9 @@ def generate(path=None, verbose=False):
     team_slots = P.TEMP0 + max(s.ntemp for n, s in segs.items()
                                if not n.startswith("g") and not n.startswith("mp_") and not n.startswith("h")
                                and not n.startswith("d1") and not n.startswith("d2"))
-    mp_team_slots = max(team_slots, P.mp_temp0(P.MP_G) + max(s.ntemp for s in mpsegs.values()) - P.MP_SHIFT)
+    mplay = tb["mplay"]
+    # (the kernel's fallback for special pairs runs the single-pair program in the same scratchpad)
+    mp_team_slots = max(team_slots, P.mp_team_slots(mpsegs))
     for deg, (msegs, lay) in msm.items():
         team_slots = max(team_slots, lay.TEMP0 + max(s.ntemp for s in msegs.values()))
     consts = P.const_table()
@@ -262,8 +259,9 @@ def generate(path=None, verbose=False):
         for i in range(0, len(lst), 4):
             w("  " + " ".join("{%d,0x%x}," % x for x in lst[i:i + 4]) + "\n")
         w("};\n")
-    w("#define BLSVM_MP_TEAM_SLOTS %d\n#define BLSVM_MP_SHIFT %d\n#define BLSVM_MP_NCONST %d\n" % (mp_team_slots, P.MP_SHIFT, P.C_GAM))
-    w("#define BLSVM_MP_G %d\n#define BLSVM_MP_BLOCK0 %d\n#define BLSVM_PAIR_BLOCK %d\n" % (P.MP_G, P.MP_BLOCK0, P.PAIR_BLOCK))
+    w("#define BLSVM_MP_TEAM_SLOTS %d\n#define BLSVM_MP_NCONST %d\n#define BLSVM_MP_G %d\n" % (mp_team_slots, P.C_GAM, P.MP_G))
+    w("/* multi-pair scratchpad (programs.MPLayout): accumulator, pair g's PX PY at CORE + 14 g, its Q at Q + 4 g */\n")
+    w("#define BLSVM_MP_F %d\n#define BLSVM_MP_CORE %d\n#define BLSVM_MP_Q %d\n" % (mplay.F, mplay.CORE, mplay.Q))
     flat("BLSVM_MP_FLAT", [r for n in mpscript for r in seg_rounds[n]])
     w("#define BLSVM_H1_NE %d\n#define BLSVM_H1_SLOTS %d\n" % (H1_NE, h1lay.TEMP0 + max(s.ntemp for s in h1segs.values())))
     w("#define BLSVM_H2_NM %d\n#define BLSVM_H2_SLOTS %d\n" % (H2_NM, h2lay.TEMP0 + max(s.ntemp for s in h2segs.values())))

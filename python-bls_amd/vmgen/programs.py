@@ -29,10 +29,8 @@ C_ZERO, C_ONE, C_R2, C_RAW1 = 0, 1, 2, 3
 C_K1 = 4                                  # -(2^384 - 1) mod q  (LIN complement surplus)
 C_GAM = 5                                 # gamma_i^j, i=1..3, j=1..5: Fq2 each (final exponentiation only)
 NCONST = C_GAM + 3 * 5 * 2                # 35
-# The multi-pair Miller programs never touch the gamma constants: their tables are
-# emitted with every slot >= NCONST moved down by MP_SHIFT, which is what lets 12
-# teams share a CU's LDS (emit.py).
-MP_SHIFT = NCONST - C_GAM
+# The multi-pair Miller programs never touch the gamma constants: their scratchpad
+# (MPLayout) starts right after C_K1.
 # named values
 PX, PY = 36, 37
 QX0, QX1, QY0, QY1 = 38, 39, 40, 41
@@ -142,8 +140,10 @@ def t_double(cfg, Tp, px3n, py):
     return (X3, Y3, Z3), (l0, l1, l4)
 
 
-def t_add(cfg, Tp, Qa, px, py):
-    """Chord step T + Q (Q affine).  Mixed addition:
+def t_add(cfg, Tp, Qa, px, py, px_is_m3=False):
+    """Chord step T + Q (Q affine).  px_is_m3: `px` holds -3 px (the multi-pair layout keeps
+    only that multiple); the line is then returned times 3, a factor in Fq that the final
+    exponentiation removes like the other line scalings.  Mixed addition:
       th = Y - yq Z, la = X - xq Z, C = th^2, D = la^2, E = la D, Fz = Z C,
       G = X D, H = E + Fz - 2G, X3 = la H, Y3 = th (G - H) - E Y, Z3 = Z E
     line: l0 = th xq - la yq, l1 = -th px, l4 = la py"""
@@ -161,36 +161,63 @@ def t_add(cfg, Tp, Qa, px, py):
     Y3 = tw.f2_sub(cfg.mul2(th, tw.f2_sub(G, H)), cfg.mul2(E, Y))
     Z3 = cfg.mul2(Z, E)
     l0 = tw.f2_sub(cfg.mul2(th, xq), cfg.mul2(la, yq))
+    if px_is_m3:
+        return (X3, Y3, Z3), (tw.f2_scale(l0, 3), tw.f2_mul_fq(th, px), tw.f2_scale(tw.f2_mul_fq(la, py), 3))
     l1 = tw.f2_neg(tw.f2_mul_fq(th, px))
     l4 = tw.f2_mul_fq(la, py)
     return (X3, Y3, Z3), (l0, l1, l4)
 
 
-# Per-pair block: PX, PY, QX0, QX1, QY0, QY1, T(6), LD(6), LA(6), NPX3 = 25 slots.
-# Pair 0 uses the named slots above (PX .. NPX3 are contiguous); in the multi-pair
-# programs pairs 1.. live in further blocks at MP_BLOCK0 + 25 (g - 1).
-PAIR_BLOCK = 25
-MP_BLOCK0 = REG0 + 24                      # overlays registers R2.. (unused by the Miller kernel)
 MP_G = 3                                   # pairs per team in the multi-pair programs
 
 
-def pair_base(g):
-    return PX if g == 0 else MP_BLOCK0 + PAIR_BLOCK * (g - 1)
-
-
-def mp_temp0(G):
-    return max(TEMP0, MP_BLOCK0 + PAIR_BLOCK * (G - 1))
-
-
 class PairSlots:
-    def __init__(self, g):
-        o = pair_base(g)
+    """slots of the one pair of the single-pair programs (the named values above)"""
+    F = F
+
+    def __init__(self, g=0):
+        assert g == 0
+        o = PX
         self.PX, self.PY, self.QX0, self.QY0 = o, o + 1, o + 2, o + 4
         self.TX, self.TY, self.TZ = o + 6, o + 8, o + 10
         self.LD, self.LA, self.NPX3 = o + 12, o + 18, o + 24
 
 
 assert PairSlots(0).TX == TX and PairSlots(0).LD == LD and PairSlots(0).LA == LA and PairSlots(0).NPX3 == NPX3
+
+
+class MPLayout:
+    """Scratchpad of the multi-pair Miller programs (G pairs per team, one accumulator), in
+    the slot numbers the kernel uses.  Ordered by lifetime so that the scheduler's
+    temporaries can start as low as possible -- the scratchpad size decides how many teams a
+    compute unit holds, and every further team per CU is worth ~5 %:
+      constants the Miller loop reads (C_ZERO .. C_K1) | F (12) | per pair PX PY T(6) LD(6) |
+      Q of every pair (4 each: read by the chord steps only, but inputs, so always live) |
+      LA of every pair (6 each: live only from a chord step to the body that multiplies the
+      chord lines in) | temporaries.
+    Bodies that neither read nor write LA put their temporaries over it (TEMP_LO)."""
+
+    def __init__(self, G):
+        self.G = G
+        o = C_GAM
+        self.F = o; o += 12
+        self.CORE = o; o += 14 * G
+        self.Q = o; o += 4 * G
+        self.LA = o; o += 6 * G
+        self.TEMP_LO, self.TEMP_HI = self.LA, o
+
+    def pair(self, g):
+        lay = self
+
+        class S:
+            F = lay.F
+            PX, PY = lay.CORE + 14 * g, lay.CORE + 14 * g + 1
+            TX, TY, TZ = PX + 2, PX + 4, PX + 6
+            LD = PX + 8
+            QX0, QY0 = lay.Q + 4 * g, lay.Q + 4 * g + 2
+            LA = lay.LA + 6 * g
+            NPX3 = None                    # -3 px is a linear expression here, not a stored value
+        return S
 
 
 def _out_t(b, ps, T2, ld, la, zero):
@@ -207,17 +234,19 @@ def _out2z(b, e, off, zero):
     b.out(e[1] if not e[1].is_zero() else zero, T(off + 1))
 
 
-def seg_init(cfg, first_add, G=1, name="init"):
+def seg_init(cfg, first_add, G=1, name="init", lay=None):
     """Raw inputs -> Montgomery; T = Q, F = 1; first tangent(+chord) step, for G pairs."""
     b = Builder(name)
     r2 = b.inp(C(C_R2))
     one = b.inp(C(C_ONE))
     zero = b.inp(C(C_ZERO))
-    b.out(one, T(F))
+    slots = lay.pair if lay else PairSlots
+    Fb = slots(0).F
+    b.out(one, T(Fb))
     for i in range(1, 12):
-        b.out(zero, T(F + i))
+        b.out(zero, T(Fb + i))
     for g in range(G):
-        ps = PairSlots(g)
+        ps = slots(g)
         px = (b.inp(T(ps.PX)) * r2).mat()
         py = (b.inp(T(ps.PY)) * r2).mat()
         q = [(b.inp(T(ps.QX0 + i)) * r2).mat() for i in range(4)]
@@ -225,7 +254,13 @@ def seg_init(cfg, first_add, G=1, name="init"):
         for i in range(4):
             b.out(q[i], T(ps.QX0 + i))
         px3n = (px * -3).mat()
-        b.out(px3n, T(ps.NPX3))
+        m3 = ps.NPX3 is None                 # multi-pair layout: the PX slot itself holds -3 px
+        if m3:
+            b.outputs = [(v, fx) for v, fx in b.outputs if fx != T(ps.PX)]
+            b.out(px3n, T(ps.PX))
+            px = px3n
+        else:
+            b.out(px3n, T(ps.NPX3))
         Tp = ((q[0], q[1]), (q[2], q[3]), (one, b.zero()))
         Qa = ((q[0], q[1]), (q[2], q[3]))
         # Z = (1, 0): products with the zero imaginary part vanish at trace time
@@ -233,40 +268,62 @@ def seg_init(cfg, first_add, G=1, name="init"):
         la = None
         if first_add:
             T2 = tuple(tw.f2_mat(c) for c in T2)
-            T2, la = t_add(cfg, T2, Qa, px, py)
+            T2, la = t_add(cfg, T2, Qa, px, py, m3)
         _out_t(b, ps, T2, ld, la, zero)
     return b
 
 
-def seg_body(cfg, cur_add, nxt, G=1, prefix="body"):
+def seg_body(cfg, cur_add, nxt, G=1, prefix="body", lay=None):
     """One pipelined Miller iteration for G pairs sharing the accumulator:
          f <- f^2 * prod_g LD_g (* LA_g if cur_add)    [lines of the current step]
          (T_g, LD_g, LA_g) <- next step of each T chain [nxt: 0 tangent, 1 tangent+chord,
                                                          2 nothing (last iteration)]"""
     b = Builder("%s_%d%d" % (prefix, cur_add, nxt))
-    f = in12(b, F)
+    slots = lay.pair if lay else PairSlots
+    Fb = slots(0).F
+    f = in12(b, Fb)
     f = tw.f12_sqr(cfg, f)
     for g in range(G):
-        ps = PairSlots(g)
+        ps = slots(g)
         ld = [in2(b, ps.LD + 2 * i) for i in range(3)]
         f = tw.f12_mul_by_014(cfg, f, *ld)
         if cur_add:
             la = [in2(b, ps.LA + 2 * i) for i in range(3)]
             f = tw.f12_mul_by_014(cfg, f, *la)
-    out12(b, f, F)
+    out12(b, f, Fb)
     if nxt != 2:
         zero = b.inp(C(C_ZERO))
         for g in range(G):
-            ps = PairSlots(g)
+            ps = slots(g)
             Tp = (in2(b, ps.TX), in2(b, ps.TY), in2(b, ps.TZ))
             Qa = (in2(b, ps.QX0), in2(b, ps.QY0))
-            px, py, px3n = b.inp(T(ps.PX)), b.inp(T(ps.PY)), b.inp(T(ps.NPX3))
+            px, py = b.inp(T(ps.PX)), b.inp(T(ps.PY))
+            m3 = ps.NPX3 is None             # multi-pair layout: the PX slot holds -3 px
+            px3n = px if m3 else b.inp(T(ps.NPX3))
             T2, ldn = t_double(cfg, Tp, px3n, py)
             lan = None
             if nxt == 1:
                 T2 = tuple(tw.f2_mat(c) for c in T2)
-                T2, lan = t_add(cfg, T2, Qa, px, py)
+                T2, lan = t_add(cfg, T2, Qa, px, py, m3)
             _out_t(b, ps, T2, ldn, lan, zero)
+    return b
+
+
+def seg_chord(cfg, G, lay, name="mp_chord"):
+    """The chord step of every T chain on its own:  (T_g, LA_g) <- T_g + Q_g  -- what a
+    body with nxt = 1 does after its tangent step, as a separate segment so that no body has
+    to hold a tangent AND a chord step's temporaries."""
+    b = Builder(name)
+    zero = b.inp(C(C_ZERO))
+    for g in range(G):
+        ps = lay.pair(g)
+        Tp = (in2(b, ps.TX), in2(b, ps.TY), in2(b, ps.TZ))
+        Qa = (in2(b, ps.QX0), in2(b, ps.QY0))
+        px, py = b.inp(T(ps.PX)), b.inp(T(ps.PY))
+        T2, lan = t_add(cfg, Tp, Qa, px, py, True)
+        _out2z(b, T2[0], ps.TX, zero), _out2z(b, T2[1], ps.TY, zero), _out2z(b, T2[2], ps.TZ, zero)
+        for i, c in enumerate(lan):
+            _out2z(b, c, ps.LA + 2 * i, zero)
     return b
 
 
@@ -472,20 +529,30 @@ def build_all(cfg=None, verbose=False):
 
 def build_multi(cfg=None, G=MP_G, verbose=False):
     """Miller-loop programs for G pairs per team sharing one accumulator:
-    returns (segments by name, script)."""
+    returns (segments by name, script, layout)."""
     cfg = cfg or tw.Cfg()
     lazy = lazy_cfg(cfg)
-    script, first_add = miller_script("mp_init", "mp_body")
-    builders = [(seg_init(lazy, first_add, G, "mp_init"), False)]
-    for name in sorted(set(script[1:])):
+    lay = MPLayout(G)
+    script0, first_add = miller_script("mp_init", "mp_body")
+    # a body whose T chains take a tangent AND a chord step is the plain body followed by the
+    # chord segment: every segment then fits the scratchpad the plain doubling body needs
+    script = []
+    for name in script0:
+        script += ["mp_body_%s0" % name[-2], "mp_chord"] if name.endswith("1") else [name]
+    # (segment, first temporary, linear combinations on demand).  The body that multiplies
+    # the chord lines in reads LA, so its temporaries start above it; scheduling its linear
+    # combinations on demand (core.schedule lazy_lin) costs it a few rounds and saves ~50 slots.
+    plan = [(seg_init(lazy, first_add, G, "mp_init", lay), lay.TEMP_HI, False),
+            (seg_chord(lazy, G, lay), lay.TEMP_HI, False)]
+    for name in sorted(set(n for n in script if n.startswith("mp_body"))):
         cur_add, nxt = int(name[-2]), int(name[-1])
-        # Every body takes unmaterialised Fq2 products.  The bodies with a chord step would
-        # not fit the scratchpad that way (179 / 189 temporaries with 178 to spare) unless
-        # their linear combinations are scheduled on demand (core.schedule lazy_lin), which
-        # costs a few more rounds there but frees ~60 slots; the plain doubling body keeps
-        # the as-soon-as-possible order (fewest rounds).
-        builders.append((seg_body(lazy, cur_add, nxt, G, "mp_body"), (cur_add, nxt) != (0, 0)))
+        plan.append((seg_body(lazy, cur_add, nxt, G, "mp_body", lay), lay.TEMP_HI if cur_add else lay.TEMP_LO, bool(cur_add)))
     segs = {}
-    for b, on_demand in builders:
-        segs[b.name] = schedule(b, temp_base=mp_temp0(G), verbose=verbose, lazy_lin=on_demand)
-    return segs, script
+    for b, tb, on_demand in plan:
+        segs[b.name] = schedule(b, temp_base=tb, verbose=verbose, lazy_lin=on_demand)
+        segs[b.name].temp_base = tb
+    return segs, script, lay
+
+
+def mp_team_slots(segs):
+    return max(s.temp_base + s.ntemp for s in segs.values())

@@ -140,22 +140,23 @@ def test_packed_tables_decode_like_the_kernel(golden):
     assert finish([m.team[P.F + i] for i in range(12)]).hex() == g["final_exp"]
     # three pairs per team: small4[0..2]; expected = product of the three single pairings
     v = golden("pairing.json")["small4"]
-    m = tablesim.TableMachine(consts[:P.C_GAM], 400, data, P.C_K1)
+    m = tablesim.TableMachine(consts[:P.C_GAM], P.mp_team_slots(tb["mpsegs"]), data, P.C_K1)
     singles = []
     for k in range(3):
         a, b = bytes.fromhex(v["g1"][k]), bytes.fromhex(v["g2"][k])
         pv = [int.from_bytes(a[i * 48:(i + 1) * 48], "big") for i in range(2)] + \
              [int.from_bytes(b[i * 48:(i + 1) * 48], "big") for i in range(4)]
-        base = (P.PX if k == 0 else P.MP_BLOCK0 + P.PAIR_BLOCK * (k - 1)) - P.MP_SHIFT
-        for i, x in enumerate(pv):
-            m.team[base + i] = x
+        ps = tb["mplay"].pair(k)                     # the kernel puts P and Q of pair k here
+        m.team[ps.PX], m.team[ps.PY] = pv[0], pv[1]
+        for i in range(4):
+            m.team[ps.QX0 + i] = pv[2 + i]
         s = tablesim.TableMachine(consts, 400, data, P.C_K1)
         for i, x in enumerate(pv):
             s.team[P.PX + i] = x
         s.run([r for n in tb["mscript"] for r in sr[n]])
         singles.append([s.team[P.F + i] for i in range(12)])
     m.run([r for n in tb["mpscript"] for r in sr[n]])
-    got = finish([m.team[P.F - P.MP_SHIFT + i] for i in range(12)])
+    got = finish([m.team[tb["mplay"].F + i] for i in range(12)])
     acc = singles[0]
     for nxt in singles[1:]:
         t = tablesim.TableMachine(consts, 400, data, P.C_K1)
