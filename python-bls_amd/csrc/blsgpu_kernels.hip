@@ -135,8 +135,11 @@ BLSGPU_DPP_ABSORB(0xAA, "[2,2,2,2]")       // lane 0 += lane 2
 // the previous round.
 // LIGHT = the program holds MUL and LIN rounds only (Miller loops, group sums):
 // the inversion and sign code is left out of the kernel.
+// (in the multi-pair Miller programs kinds 2 / 3 are SAVE / RESTORE: the 12-slot window at
+// slot K of the round header <-> `stash`, three registers per lane -- programs.MPLayout.)
 template <bool LIGHT = false>
-__device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __restrict__ seq_, uint32_t n, uint32_t base16, uint32_t lane) {
+__device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __restrict__ seq_, uint32_t n, uint32_t base16, uint32_t lane,
+                                           uint32_t* stash = nullptr) {
     if (n == 0) return;
     gptr_u2 seq = (gptr_u2)seq_;
     gptr_u16 gdata = (gptr_u16)T.data;
@@ -284,7 +287,17 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
 #endif
             if (rd != 0xFFFFu) lds_store12(D, base16 + rd);
         } else if (LIGHT) {
-            // no other kind in a light program
+            if (stash) {                                     // SAVE / RESTORE of the window at slot K
+                uint32_t* win = reinterpret_cast<uint32_t*>(smem4) + base16 * 4u + ((meta >> 8) & 0xFFu) * 12u;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const uint32_t idx = lane + 64u * j;
+                    if (idx < 144u) {
+                        if (kind == 2u) stash[j] = win[idx];
+                        else win[idx] = stash[j];
+                    }
+                }
+            }
         } else if (kind == 2u) {                             // INV
             uint32_t ra = e_cur.x & 0xFFFFu, rd = e_cur.y & 0xFFFFu;
             if (rd != 0xFFFFu) {
@@ -483,7 +496,8 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
         special |= pair_flags(team, BLSVM_MP_CORE + 14u * g, BLSVM_MP_Q + 4u * g, lane);
     }
     if (!special) {
-        run_rounds<true>(T, T.mpflat, BLSVM_MP_FLAT_LEN, 0, lane);
+        uint32_t stash[3] = {0u, 0u, 0u};                        // Q of the team's pairs between the chord steps
+        run_rounds<true>(T, T.mpflat, BLSVM_MP_FLAT_LEN, 0, lane, stash);
     } else {
         bool have = false;
         for (uint32_t g = 0; g < cnt; ++g) {

@@ -3,7 +3,8 @@
 Layout consumed by csrc/blsgpu_kernels.hip:
   BLSVM_MILLER_FLAT / BLSVM_FEXP_FLAT: the scripts expanded into the flat
       sequence of rounds the kernel walks: {data_off (u16 units), meta},
-      meta = kind (0 MUL, 1 LIN, 2 INV, 3 SGN) | K << 8   (K = micro-ops per lane, LIN)
+      meta = kind (0 MUL, 1 LIN, 2 INV, 3 SGN; in the light multi-pair programs 2 SAVE, 3 RESTORE of
+             the 12-slot window at slot K) | K << 8   (K = micro-ops per lane, LIN)
   BLSVM_SEG_FLAT: the same for single segments the kernels call directly
       (BLSVM_SEGF_<NAME>_OFF / _LEN index it)
   BLSVM_DATA[] u16, per round a record per lane:
@@ -118,6 +119,12 @@ def pack(segs, order):
             kind = rnd["kind"]
             lanes = rnd["lanes"]
             assert len(lanes) <= LANES
+            if kind in ("save", "restore"):
+                # light programs only: the 12-slot window at slot K <-> the stash registers; no
+                # lane records (the look-ahead fetch reads the start of the data, harmlessly)
+                assert name.startswith("mp_") and rnd["K"] < 256
+                lst.append((0, (2 if kind == "save" else 3) | (rnd["K"] << 8)))
+                continue
             if kind in ("mul", "inv", "sgn"):
                 for ln in range(LANES):
                     if ln < len(lanes):

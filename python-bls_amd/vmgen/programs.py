@@ -192,19 +192,23 @@ class MPLayout:
     temporaries can start as low as possible -- the scratchpad size decides how many teams a
     compute unit holds, and every further team per CU is worth ~5 %:
       constants the Miller loop reads (C_ZERO .. C_K1) | F (12) | per pair PX PY T(6) LD(6) |
-      Q of every pair (4 each: read by the chord steps only, but inputs, so always live) |
       LA of every pair (6 each: live only from a chord step to the body that multiplies the
-      chord lines in) | temporaries.
-    Bodies that neither read nor write LA put their temporaries over it (TEMP_LO)."""
+      chord lines in) | the Q window (4 per pair) | temporaries.
+    Q is an input that only the five chord steps read: after the first segment has brought it
+    into Montgomery form the kernel keeps it in three registers per lane (a SAVE round) and
+    writes it back into the window in front of a chord segment (RESTORE round); everywhere
+    else the window is temporaries.  Bodies that neither read nor write LA put their
+    temporaries over it as well (TEMP_LO); the body that reads LA starts at TEMP_MID."""
 
     def __init__(self, G):
         self.G = G
         o = C_GAM
         self.F = o; o += 12
         self.CORE = o; o += 14 * G
-        self.Q = o; o += 4 * G
         self.LA = o; o += 6 * G
-        self.TEMP_LO, self.TEMP_HI = self.LA, o
+        self.Q = o; o += 4 * G
+        self.TEMP_LO, self.TEMP_MID, self.TEMP_HI = self.LA, self.Q, o
+        assert 4 * G * 12 <= 3 * 64, "the Q window must fit three registers per lane"
 
     def pair(self, g):
         lay = self
@@ -546,11 +550,14 @@ def build_multi(cfg=None, G=MP_G, verbose=False):
             (seg_chord(lazy, G, lay), lay.TEMP_HI, False)]
     for name in sorted(set(n for n in script if n.startswith("mp_body"))):
         cur_add, nxt = int(name[-2]), int(name[-1])
-        plan.append((seg_body(lazy, cur_add, nxt, G, "mp_body", lay), lay.TEMP_HI if cur_add else lay.TEMP_LO, bool(cur_add)))
+        plan.append((seg_body(lazy, cur_add, nxt, G, "mp_body", lay), lay.TEMP_MID if cur_add else lay.TEMP_LO, bool(cur_add)))
     segs = {}
     for b, tb, on_demand in plan:
         segs[b.name] = schedule(b, temp_base=tb, verbose=verbose, lazy_lin=on_demand)
         segs[b.name].temp_base = tb
+    # the Q window travels in registers between the segments that use it (MPLayout)
+    segs["mp_init"].rounds.append({"kind": "save", "K": lay.Q, "lanes": []})
+    segs["mp_chord"].rounds.insert(0, {"kind": "restore", "K": lay.Q, "lanes": []})
     return segs, script, lay
 
 

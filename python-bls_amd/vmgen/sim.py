@@ -42,9 +42,17 @@ class Machine:
     def run(self, seg):
         for rnd in seg.rounds:
             kind = rnd["kind"]
-            self.rounds_run[kind] += 1
-            self.lane_ops[kind] += len(rnd["lanes"])
+            self.rounds_run[kind] = self.rounds_run.get(kind, 0) + 1
+            self.lane_ops[kind] = self.lane_ops.get(kind, 0) + len(rnd["lanes"])
             writes = []
+            if kind in ("save", "restore"):
+                # the 12-slot window at slot rnd["K"] <-> the team's stash registers (programs.MPLayout)
+                self.rounds_run[kind] = self.rounds_run.get(kind, 0)
+                if kind == "save":
+                    self.stash = self.team[rnd["K"]:rnd["K"] + 12]
+                else:
+                    self.team[rnd["K"]:rnd["K"] + 12] = self.stash
+                continue
             if kind == "mul":
                 for a, b, d in rnd["lanes"]:
                     writes.append((d, self.rd(a) * self.rd(b) * RINV % Q))

@@ -20,11 +20,19 @@ class TableMachine:
             self.team[i] = c
         self.data = data
 
-    def run(self, rounds):
+    def run(self, rounds, light=False):
+        """light: the program is one of the kernel's light ones (products and combinations only);
+        there kinds 2 / 3 are SAVE / RESTORE of the 12-slot window at slot K (programs.MPLayout)."""
         d16, team = self.data, self.team
         for off, meta in rounds:
             kind, K, levels, mn = meta & 3, (meta >> 8) & 0xFF, (meta >> 16) & 3, (meta >> 18) & 0xFF
             writes = []
+            if light and kind >= 2:
+                if kind == 2:
+                    self.stash = team[K:K + 12]
+                else:
+                    team[K:K + 12] = self.stash
+                continue
             if kind != 1:
                 for lane in range(64):
                     a, b, d, _ = d16[off + 4 * lane: off + 4 * lane + 4]

@@ -155,7 +155,7 @@ def test_packed_tables_decode_like_the_kernel(golden):
             s.team[P.PX + i] = x
         s.run([r for n in tb["mscript"] for r in sr[n]])
         singles.append([s.team[P.F + i] for i in range(12)])
-    m.run([r for n in tb["mpscript"] for r in sr[n]])
+    m.run([r for n in tb["mpscript"] for r in sr[n]], light=True)
     got = finish([m.team[tb["mplay"].F + i] for i in range(12)])
     acc = singles[0]
     for nxt in singles[1:]:
