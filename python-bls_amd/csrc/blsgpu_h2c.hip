@@ -12,7 +12,10 @@ constexpr int H1_TEAM_DW = BLSVM_H1_SLOTS * 12;
 constexpr int H2_TEAM_DW = BLSVM_H2_SLOTS * 12;
 
 __device__ __forceinline__ void team_init_consts_h2c(const VmTables& T, uint32_t* team, uint32_t lane) {
-    for (uint32_t i = lane; i < BLSVM_NCONST_H2C * 12; i += 64) team[i] = T.consts[i];
+    // shared constants [0, HC_SLOT0), then the extra ones (kept behind the final exponentiation's in the table)
+    for (uint32_t i = lane; i < BLSVM_HC_SLOT0 * 12; i += 64) team[i] = T.consts[i];
+    for (uint32_t i = lane; i < (BLSVM_NCONST_H2C - BLSVM_HC_SLOT0) * 12; i += 64)
+        team[BLSVM_HC_SLOT0 * 12 + i] = T.consts[BLSVM_HC_TBL0 * 12 + i];
 }
 
 // SHA-256 (FIPS 180-4) of one 40-byte message = one block, for the hash512 chain of
@@ -247,7 +250,8 @@ __global__ void __launch_bounds__(64) k_h2c_clear_reg(VmTables T, const uint32_t
         }
         S[s] = {{c[0], c[1]}, {c[2], c[3]}, {c[4], fe_zero()}};
     }
-    const fe2 psix = {cfe(BLSVM_HC_PSIX), cfe(BLSVM_HC_PSIX + 1)}, psiy = {cfe(BLSVM_HC_PSIY), cfe(BLSVM_HC_PSIY + 1)};
+    constexpr uint32_t PSIX = BLSVM_HC_PSIX - BLSVM_HC_SLOT0 + BLSVM_HC_TBL0, PSIY = BLSVM_HC_PSIY - BLSVM_HC_SLOT0 + BLSVM_HC_TBL0;
+    const fe2 psix = {cfe(PSIX), cfe(PSIX + 1)}, psiy = {cfe(PSIY), cfe(PSIY + 1)};
     auto psi = [&](const pt& P) { return pt{f2_mul(f2_conj(P.X), psix), f2_mul(f2_conj(P.Y), psiy), f2_conj(P.Z)}; };
     const pt P = padd(S[0], S[1]);
     const pt T0 = mul_x(P);                                      // [x] P       (ec.py:540-550)

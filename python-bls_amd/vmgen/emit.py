@@ -271,10 +271,12 @@ def generate(path=None, verbose=False):
     w("#define BLSVM_MP_F %d\n#define BLSVM_MP_CORE %d\n#define BLSVM_MP_Q %d\n" % (mplay.F, mplay.CORE, mplay.Q))
     flat("BLSVM_MP_FLAT", [r for n in mpscript for r in seg_rounds[n]])
     w("#define BLSVM_H1_NE %d\n#define BLSVM_H1_SLOTS %d\n" % (H1_NE, h1lay.TEMP0 + max(s.ntemp for s in h1segs.values())))
-    w("#define BLSVM_H2_NM %d\n#define BLSVM_H2_SLOTS %d\n" % (H2_NM, h2lay.TEMP0 + max(s.ntemp for s in h2segs.values())))
+    w("#define BLSVM_H2_NM %d\n#define BLSVM_H2_SLOTS %d\n" % (H2_NM, HP.h2_team_slots(h2segs, h2lay)))
     w("#define BLSVM_H1_T %d\n#define BLSVM_H1_TH %d\n#define BLSVM_H1_S %d\n#define BLSVM_H2_S %d\n#define BLSVM_H2_OUT %d\n" % (h1lay.T, h1lay.TH, h1lay.S, h2lay.S, h2lay.OUT))
     w("#define BLSVM_H1_ACC %d\n#define BLSVM_H1_BASE %d\n#define BLSVM_H1_STATE0 %d\n#define BLSVM_H1_STATE1 %d\n" % (h1lay.ACC, h1lay.BASE, h1lay.T, h1lay.TEMP0))
     w("#define BLSVM_NCONST_H2C %d\n#define BLSVM_HC_PSIX %d\n#define BLSVM_HC_PSIY %d\n" % (HP.HC_END, HP.HC_PSIX, HP.HC_PSIY))
+    w("/* scratchpad slot of an extra constant -> its entry in the constant table */\n")
+    w("#define BLSVM_HC_SLOT0 %d\n#define BLSVM_HC_TBL0 %d\n" % (P.C_GAM, HP.HC_TBL0))
     for tag, ne, (dsegs, dlay, dscript) in (("D1", D1_NE, tb["d1"]), ("D2", D2_NE, tb["d2"])):
         w("#define BLSVM_%s_NE %d\n#define BLSVM_%s_SLOTS %d\n" % (tag, ne, tag, dlay.TEMP0 + max(s.ntemp for s in dsegs.values())))
         w("#define BLSVM_%s_X %d\n#define BLSVM_%s_BIG %d\n#define BLSVM_%s_OUT %d\n" % (tag, dlay.X, tag, dlay.BIG, tag, dlay.OUT))
@@ -301,7 +303,7 @@ def generate(path=None, verbose=False):
     w("static const uint16_t BLSVM_DATA[BLSVM_NDATA] = {\n")
     for i in range(0, len(data), 16):
         w("  " + ",".join(str(x) for x in data[i:i + 16]) + ",\n")
-    w("};\nstatic const uint32_t BLSVM_CONSTS[BLSVM_NCONST_H2C][12] = {\n")
+    w("};\nstatic const uint32_t BLSVM_CONSTS[%d][12] = {   /* [0, NCONST) shared, then the extra constants of the hashing programs */\n" % (P.NCONST + len(HP.h2c_const_table())))
     for c in consts + HP.h2c_const_table():
         w("  {" + ",".join("0x%08xu" % x for x in limbs32(c)) + "},\n")
     w("};\n")

@@ -27,18 +27,22 @@ Kernel H2 (h2_*):  NM messages per team: P = S_0 + S_1, cofactor clearing, affin
 from . import tower as tw
 from .core import Builder, schedule
 from .msm_programs import FA, padd, pdbl
-from .programs import C_ONE, C_R2, C_RAW1, C_ZERO, NCONST, NX, _fq2_pow
+from .programs import C_GAM, C_ONE, C_R2, C_RAW1, C_ZERO, NCONST, NX, _fq2_pow, const_table
 from .sim import Q, to_m
 
 SQRT_N3 = 1586958781458431025242759403266842894121773480562120986020912974854563298150952611241517463240701
 SQRT_N3M1O2 = 793479390729215512621379701633421447060886740281060493010456487427281649075476305620758731620350
 assert (SQRT_N3 * SQRT_N3 + 3) % Q == 0 and (2 * SQRT_N3M1O2 + 1 - SQRT_N3) % Q == 0
 
-# extra constants, placed right after the shared constant slots
-HC_S3, HC_H, HC_SINV, HC_INV2 = NCONST, NCONST + 1, NCONST + 2, NCONST + 3
-HC_PSIX, HC_PSIY = NCONST + 4, NCONST + 6           # Fq2 each
-HC_R3 = NCONST + 8                                  # content R^3: raw x -> x R^2 (the 2^384 place of a wide input)
-HC_END = NCONST + 9
+# extra constants.  The hashing / decompression programs never touch the Frobenius constants of
+# the final exponentiation: in their scratchpads the extra constants follow C_K1 directly (the
+# kernel copies entries [0, C_GAM) and [NCONST, NCONST + 9) of its constant table), 30 slots less
+# per team.
+HC_S3, HC_H, HC_SINV, HC_INV2 = C_GAM, C_GAM + 1, C_GAM + 2, C_GAM + 3
+HC_PSIX, HC_PSIY = C_GAM + 4, C_GAM + 6             # Fq2 each
+HC_R3 = C_GAM + 8                                   # content R^3: raw x -> x R^2 (the 2^384 place of a wide input)
+HC_END = C_GAM + 9
+HC_TBL0 = NCONST                                    # first extra constant in the kernel's constant table
 EXP_E = (Q - 3) // 4                                  # n^E: sqrt candidate n^E n, symbol n^E (n^E n)
 
 
@@ -51,6 +55,11 @@ def h2c_const_table():
     px, py = inv2(g2), inv2(g3)                       # w^(2-2q), w^(3-3q)  (ec.py:440-444)
     vals = [SQRT_N3, SQRT_N3M1O2, pow(SQRT_N3, Q - 2, Q), pow(2, Q - 2, Q), px[0], px[1], py[0], py[1]]
     return [to_m(v) for v in vals] + [pow(1 << 384, 3, Q)]
+
+
+def h2c_scratch_consts():
+    """contents of the constant slots [0, HC_END) of these programs' scratchpads"""
+    return const_table()[:C_GAM] + h2c_const_table()
 
 
 class H1Layout:
@@ -74,17 +83,30 @@ class H1Layout:
 
 
 class H2Layout:
-    """NM messages per team; points are projective triples of Fq2 (6 slots)."""
+    """NM messages per team; points are projective triples of Fq2 (6 slots).  Ordered by
+    lifetime (the scratchpad size decides how many teams a compute unit holds): the points of
+    the double-and-add loop first; the two encodings S are read by the first segment only and
+    the affine result OUT is written by the last one only, so both share the area behind the
+    points, which is temporaries for every segment in between."""
 
     def __init__(self, NM):
         self.NM = NM
         o = HC_END
-        self.S = o; o += 10 * NM           # the two encodings (x, y, z.c0; Montgomery)
         self.P = o; o += 6 * NM
         self.A = o; o += 6 * NM            # running accumulator
         self.T0 = o; o += 6 * NM           # [x]P
-        self.OUT = o; o += 4 * NM          # canonical affine result
-        self.TEMP0 = o
+        self.TEMP_LOOP = o                 # first temporary of the segments that touch neither S nor OUT
+        self.S = o                         # the two encodings (x, y, z.c0; Montgomery)
+        self.OUT = o                       # canonical affine result
+        self.TEMP_START = o + 10 * NM
+        self.TEMP_OUT = o + 4 * NM
+
+    def temp_base(self, name):
+        return {"h2_start": self.TEMP_START, "h2_affine": self.TEMP_OUT}.get(name, self.TEMP_LOOP)
+
+
+def h2_team_slots(segs, lay):
+    return max(lay.temp_base(n) + sg.ntemp for n, sg in segs.items())
 
 
 def _c2(b, base):
@@ -238,7 +260,7 @@ def build_h2(NM, cfg=None, verbose=False):
     segs = {}
 
     def done(b):
-        segs[b.name] = schedule(b, temp_base=L.TEMP0, verbose=verbose)
+        segs[b.name] = schedule(b, temp_base=L.temp_base(b.name), verbose=verbose)
 
     def psi(b, P):
         cx, cy = _c2(b, HC_PSIX), _c2(b, HC_PSIY)

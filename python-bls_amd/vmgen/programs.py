@@ -220,7 +220,7 @@ class MPLayout:
             LD = PX + 8
             QX0, QY0 = lay.Q + 4 * g, lay.Q + 4 * g + 2
             LA = lay.LA + 6 * g
-            NPX3 = None                    # -3 px is a linear expression here, not a stored value
+            NPX3 = None                    # the PX slot itself holds -3 px here (seg_init)
         return S
 
 

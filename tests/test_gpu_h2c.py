@@ -76,7 +76,7 @@ def test_large_batch_properties(engine):
 
 
 def test_one_message_per_lane_clearing(golden):
-    """The register form of the cofactor clearing (used from 57344 messages on), forced for a small
+    """The register form of the cofactor clearing (an alternative selected with BLSGPU_H2C_REG_THRESHOLD), forced for a small
     batch: reference vectors, infinity summands, ragged counts, and equality with the VM form."""
     import os
     from bls_py import _native

@@ -15,7 +15,7 @@ NE = 4
 
 @pytest.fixture(scope="module")
 def progs():
-    return P.const_table() + HP.h2c_const_table(), DP.build_d1(NE), DP.build_d2(NE)
+    return HP.h2c_scratch_consts(), DP.build_d1(NE), DP.build_d2(NE)
 
 
 def run(consts, built, deg, xs, bigs):

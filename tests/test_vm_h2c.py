@@ -17,14 +17,14 @@ NE, NM = 4, 2
 
 @pytest.fixture(scope="module")
 def progs():
-    consts = P.const_table() + HP.h2c_const_table()
+    consts = HP.h2c_scratch_consts()
     return consts, HP.build_h1(NE), HP.build_h2(NM)
 
 
 def encode(progs, ts):
     consts, (segs, L, script), _ = progs
     assert len(ts) == NE
-    m = sim.Machine(consts, L.TEMP0 + max(s.ntemp for s in segs.values()))
+    m = sim.Machine(consts, 700)
     for e, t in enumerate(ts):
         m.team[L.T + 2 * e], m.team[L.T + 2 * e + 1] = t
     for name in script:
@@ -44,7 +44,7 @@ def affine_of(s):
 def clear(progs, pairs):
     consts, _, (segs, L, script) = progs
     assert len(pairs) == NM
-    m = sim.Machine(consts, L.TEMP0 + max(s.ntemp for s in segs.values()))
+    m = sim.Machine(consts, 700)
     for i, pr in enumerate(pairs):
         for j, s in enumerate(pr):
             for k in range(5):

@@ -21,7 +21,7 @@ else:
     wid, key = which[prog]
     script = tb[key]
 rounds = [r for n in script for r in sr[n]]
-consts = P.const_table() + HP.h2c_const_table()
+consts = HP.h2c_scratch_consts()
 nslots = 900
 g1 = open(os.path.join(ROOT, "tests/golden/pairs_seed1_g1.bin"), "rb").read()
 img0 = [0] * nslots
