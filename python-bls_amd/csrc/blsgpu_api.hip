@@ -898,7 +898,7 @@ BLSGPU_EXPORT int blsgpu_debug_run(blsgpu_ctx* c, int which, unsigned nrounds, u
     HIP_TRY(hipMalloc((void**)&d, (size_t)nslots * 48));
     HIP_TRY(hipMemcpy(d, image, (size_t)nslots * 48, hipMemcpyHostToDevice));
     (void)hipFuncSetAttribute((const void*)blsgpu::k_debug_run, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nslots * 48);
-    hipLaunchKernelGGL(blsgpu::k_debug_run, dim3(1), dim3(64), (size_t)nslots * 48, 0, c->tabs, seqs[which], nrounds, nslots, d);
+    hipLaunchKernelGGL(blsgpu::k_debug_run, dim3(1), dim3(64), (size_t)nslots * 48, 0, c->tabs, seqs[which], nrounds, nslots, d, which == 1 ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(image, d, (size_t)nslots * 48, hipMemcpyDeviceToHost));

@@ -356,12 +356,17 @@ __global__ void __launch_bounds__(64, 2) k_decompress(VmTables T, const uint32_t
 
 #ifdef BLSGPU_STAMPS
 // diagnostic build only: see blsgpu_debug_run
-__global__ void __launch_bounds__(64) k_debug_run(VmTables T, const uint2* seq, uint32_t nrounds, uint32_t nslots, uint32_t* image) {
+__global__ void __launch_bounds__(64) k_debug_run(VmTables T, const uint2* seq, uint32_t nrounds, uint32_t nslots, uint32_t* image, uint32_t light) {
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = lane; i < nslots * 12; i += 64) team[i] = image[i];
     wave_fence();
-    run_rounds(T, seq, nrounds, 0, lane);
+    if (light) {                                             // the multi-pair Miller program: SAVE / RESTORE rounds
+        uint32_t stash[3] = {0u, 0u, 0u};
+        run_rounds<true>(T, seq, nrounds, 0, lane, stash);
+    } else {
+        run_rounds(T, seq, nrounds, 0, lane);
+    }
     wave_fence();
     for (uint32_t i = lane; i < nslots * 12; i += 64) image[i] = team[i];
 }
