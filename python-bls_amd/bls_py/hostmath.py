@@ -172,6 +172,8 @@ def jac_mul(F, P, c):
 def jac_to_affine(F, P):
     if P is None:
         return None
+    if P[2] == F.one:                      # already normalised (deserialised keys, GPU results): no inversion
+        return (P[0], P[1])
     zi = F.inv(P[2])
     zi2 = F.sqr(zi)
     return (F.mul(P[0], zi2), F.mul(P[1], F.mul(zi2, zi)))
