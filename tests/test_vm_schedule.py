@@ -209,3 +209,23 @@ def test_squaring_columns_of_the_generated_kernel():
             if i % 2 == 0:
                 tot += A[i // 2] ** 2 << (32 * i)
         assert tot == a * a
+
+
+def test_scratchpad_budgets():
+    """The scratchpad sizes that buy the measured occupancy: the multi-pair Miller
+    programs must fit 16 teams into a compute unit's 160 KB of LDS (512-byte allocation granules), the
+    cofactor clearing 12; the single-pair program is what the multi-pair kernel's fallback runs in the
+    same scratchpad."""
+    tb = emit.build_tables()
+    from vmgen import h2c_programs as HP
+
+    def teams(slots):
+        return (160 * 1024) // (-(-slots * 48 // 512) * 512)
+    mp = P.mp_team_slots(tb["mpsegs"])
+    single = P.TEMP0 + max(s.ntemp for n, s in tb["segs"].items()
+                           if not n.startswith(("g", "mp_", "h", "d1", "d2")))
+    assert teams(max(mp, single)) >= 16, (mp, single)
+    h2segs, h2lay, _ = tb["h2"]
+    assert teams(HP.h2_team_slots(h2segs, h2lay)) >= 12
+    # the Q window of the multi-pair layout is what three stash registers per lane hold
+    assert 4 * tb["mplay"].G * 12 <= 3 * 64
