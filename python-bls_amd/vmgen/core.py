@@ -274,12 +274,15 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False, fold_copies=True, lazy_
         if len(rl) <= lanes:
             emit("lin", rl)
         else:
-            # more ops than lanes: deal them out by length so that every round of the
-            # level keeps free lanes for splitting its long combinations (emit.py)
+            # more ops than lanes: the longest combinations together in the first round(s) -- where
+            # the emitter splits them over lanes -- and the short ones in the last, which then
+            # needs neither a split nor its merge levels (dealing them out evenly cost 120 more
+            # merge levels per three pairs for the same number of steps)
             nr = (len(rl) + lanes - 1) // lanes
             by_len = sorted(rl, key=lambda v: -len(v.terms))
+            per = (len(by_len) + nr - 1) // nr
             for r in range(nr):
-                emit("lin", by_len[r::nr])
+                emit("lin", by_len[r * per:(r + 1) * per])
 
     def choose_heavy(ready_ids, level, kinds=("inv", "sgn", "mul")):
         """the heavy ops of the next level among those whose sources are in ready_ids"""
