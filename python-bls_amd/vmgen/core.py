@@ -149,6 +149,38 @@ class Builder:
 # ---------------------------------------------------------------------------
 MAX_COEF = 31          # a micro-op adds coef * x, x = slot or its 384-bit complement
 MAX_LIN_MAG = 160      # sum of |coefficients| per linear combination
+# cost of a linear round beyond its steps, in steps (15 VALU each): the sign flip, a merge level
+FLIP_COST, LEVEL_COST = 2.5, 3.0
+
+
+def lin_round_cost(nps):
+    """What emit.plan_lin_round will make of a round with these (negative, positive) term counts:
+    (steps + flip + merge levels, levels, lanes per combination) of the cheapest way to split the
+    combinations over 1, 2 or 4 adjacent lanes within 64 lanes; None if they do not fit."""
+    best = None
+    nmax = max(n for n, _ in nps)
+    pmax = max(p for _, p in nps)
+    for lv in (0, 1, 2):
+        gmax = 1 << lv
+        for tn in range(0, nmax + 1):
+            for tp in range(0, pmax + 1):
+                c = tn + tp + (FLIP_COST if tn else 0) + LEVEL_COST * lv
+                if best is not None and c >= best[0]:
+                    break
+                gs, tot = [], 0
+                for n, p in nps:
+                    g = 1
+                    while (-(-n // g) > tn or -(-p // g) > tp) and g < gmax:
+                        g *= 2
+                    if -(-n // g) > tn or -(-p // g) > tp:
+                        tot = None
+                        break
+                    gs.append(g)
+                    tot += g
+                if tot is not None and tot <= LANES:
+                    best = (c, lv, gs)
+                    break
+    return best
 FOLD_COPY_MAX_OPS = 48  # a linear round takes folded output copies up to this many combinations
 K1_SLOT = None         # set by programs.py: slot holding -(2^384 - 1) mod q
 
@@ -280,9 +312,25 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False, fold_copies=True, lazy_
             # merge levels per three pairs for the same number of steps)
             nr = (len(rl) + lanes - 1) // lanes
             by_len = sorted(rl, key=lambda v: -len(v.terms))
-            per = (len(by_len) + nr - 1) // nr
-            for r in range(nr):
-                emit("lin", by_len[r * per:(r + 1) * per])
+            if nr == 2:
+                # the cut that costs least (steps + flips + merge levels of both rounds)
+                nps = [(sum(1 for c, _ in v.terms if c < 0), sum(1 for c, _ in v.terms if c > 0)) for v in by_len]
+                best = None
+                for cut in range(len(by_len) - lanes, lanes + 1):
+                    if cut <= 0 or cut >= len(by_len):
+                        continue
+                    ca, cb = lin_round_cost(nps[:cut]), lin_round_cost(nps[cut:])
+                    if ca is not None and cb is not None and (best is None or ca[0] + cb[0] < best[0]):
+                        best = (ca[0] + cb[0], cut)
+                emit("lin", by_len[:best[1]])
+                emit("lin", by_len[best[1]:])
+            else:
+                tail = by_len[len(by_len) - lanes:]
+                head = by_len[:len(by_len) - lanes]
+                per = (len(head) + nr - 2) // (nr - 1)
+                for r in range(nr - 1):
+                    emit("lin", head[r * per:(r + 1) * per])
+                emit("lin", tail)
 
     def choose_heavy(ready_ids, level, kinds=("inv", "sgn", "mul")):
         """the heavy ops of the next level among those whose sources are in ready_ids"""

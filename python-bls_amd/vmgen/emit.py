@@ -22,6 +22,7 @@ import os
 from . import decomp_programs as DP
 from . import h2c_programs as HP
 from . import msm_programs as MP
+from . import core
 from . import programs as P
 from .core import LANES
 
@@ -38,9 +39,6 @@ def sref(slot):
 def kpad(K):
     """u16 per lane record of a LIN round: destination, merge flags, K micro-ops"""
     return (K + 2 + 3) & ~3
-
-
-FLIP_COST, LEVEL_COST = 2.5, 3.0          # in micro-op steps (15 VALU each): sign flip ~40, merge level ~48 VALU
 
 
 def plan_lin_round(lanes):
@@ -64,30 +62,7 @@ def plan_lin_round(lanes):
         assert sum(cf for neg, cf, s in real if neg) == sum(cf for neg, cf, s in uops if s == P.C_K1), "compensation does not match"
         ops.append((d, [u for u in real if u[0]], [u for u in real if not u[0]]))
 
-    def cost(mn, mp, lv):
-        return mn + mp + (FLIP_COST if mn else 0) + LEVEL_COST * lv
-    best = None
-    nmax = max(len(n) for _, n, _ in ops)
-    pmax = max(len(p) for _, _, p in ops)
-    for lv in (0, 1, 2):
-        gmax = 1 << lv
-        for tn in range(0, nmax + 1):
-            for tp in range(0, pmax + 1):
-                if best is not None and cost(tn, tp, lv) >= best[0]:
-                    break
-                gs, tot = [], 0
-                for _, n, p in ops:
-                    g = 1
-                    while (-(-len(n) // g) > tn or -(-len(p) // g) > tp) and g < gmax:
-                        g *= 2
-                    if -(-len(n) // g) > tn or -(-len(p) // g) > tp:
-                        tot = None
-                        break
-                    gs.append(g)
-                    tot += g
-                if tot is not None and tot <= LANES:
-                    best = (cost(tn, tp, lv), lv, gs)
-                    break
+    best = core.lin_round_cost([(len(n), len(p)) for _, n, p in ops])
     assert best is not None
     _, lv, gs = best
     plan = []
