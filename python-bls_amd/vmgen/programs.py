@@ -192,22 +192,20 @@ class MPLayout:
     temporaries can start as low as possible -- the scratchpad size decides how many teams a
     compute unit holds, and every further team per CU is worth ~5 %:
       constants the Miller loop reads (C_ZERO .. C_K1) | F (12) | per pair PX PY T(6) LD(6) |
-      LA of every pair (6 each: live only from a chord step to the body that multiplies the
-      chord lines in) | the Q window (4 per pair) | temporaries.
-    Q is an input that only the five chord steps read: after the first segment has brought it
-    into Montgomery form the kernel keeps it in three registers per lane (a SAVE round) and
-    writes it back into the window in front of a chord segment (RESTORE round); everywhere
-    else the window is temporaries.  Bodies that neither read nor write LA put their
-    temporaries over it as well (TEMP_LO); the body that reads LA starts at TEMP_MID."""
+      the Q window (4 per pair) | temporaries.
+    The chord lines never reach a slot: a chord step is fused into the body that multiplies its
+    line in (seg_body_chord).  Q is an input that only those five bodies read: after the first
+    segment has brought it into Montgomery form the kernel keeps it in three registers per
+    lane (a SAVE round) and writes it back into the window in front of such a body (RESTORE
+    round); for every other segment the window is temporaries (TEMP_LO)."""
 
     def __init__(self, G):
         self.G = G
         o = C_GAM
         self.F = o; o += 12
         self.CORE = o; o += 14 * G
-        self.LA = o; o += 6 * G
         self.Q = o; o += 4 * G
-        self.TEMP_LO, self.TEMP_MID, self.TEMP_HI = self.LA, self.Q, o
+        self.TEMP_LO, self.TEMP_HI = self.Q, o
         assert 4 * G * 12 <= 3 * 64, "the Q window must fit three registers per lane"
 
     def pair(self, g):
@@ -219,7 +217,7 @@ class MPLayout:
             TX, TY, TZ = PX + 2, PX + 4, PX + 6
             LD = PX + 8
             QX0, QY0 = lay.Q + 4 * g, lay.Q + 4 * g + 2
-            LA = lay.LA + 6 * g
+            LA = None                      # chord lines live inside seg_body_chord only
             NPX3 = None                    # the PX slot itself holds -3 px here (seg_init)
         return S
 
@@ -313,21 +311,31 @@ def seg_body(cfg, cur_add, nxt, G=1, prefix="body", lay=None):
     return b
 
 
-def seg_chord(cfg, G, lay, name="mp_chord"):
-    """The chord step of every T chain on its own:  (T_g, LA_g) <- T_g + Q_g  -- what a
-    body with nxt = 1 does after its tangent step, as a separate segment so that no body has
-    to hold a tangent AND a chord step's temporaries."""
-    b = Builder(name)
+def seg_body_chord(cfg, nxt, G, lay, prefix="mp_body"):
+    """A Miller iteration whose step has a chord, for G pairs sharing the accumulator, with the
+    chord step fused in:   (T_g, LA_g) <- T_g + Q_g ;  f <- f^2 * prod_g LD_g LA_g ;
+    (T_g, LD_g) <- tangent step of T_g (nxt = 0).  The squaring and the tangent-line products
+    overlap the chord steps, and the chord lines never need a slot."""
+    assert nxt == 0
+    b = Builder("%s_c%d" % (prefix, nxt))
     zero = b.inp(C(C_ZERO))
+    f = tw.f12_sqr(cfg, in12(b, lay.F))
+    st = []
     for g in range(G):
         ps = lay.pair(g)
         Tp = (in2(b, ps.TX), in2(b, ps.TY), in2(b, ps.TZ))
         Qa = (in2(b, ps.QX0), in2(b, ps.QY0))
         px, py = b.inp(T(ps.PX)), b.inp(T(ps.PY))
-        T2, lan = t_add(cfg, Tp, Qa, px, py, True)
-        _out2z(b, T2[0], ps.TX, zero), _out2z(b, T2[1], ps.TY, zero), _out2z(b, T2[2], ps.TZ, zero)
-        for i, c in enumerate(lan):
-            _out2z(b, c, ps.LA + 2 * i, zero)
+        ld = [in2(b, ps.LD + 2 * i) for i in range(3)]
+        T2, la = t_add(cfg, Tp, Qa, px, py, True)
+        st.append((ps, T2, la, ld, px, py))
+    for ps, T2, la, ld, px, py in st:
+        f = tw.f12_mul_by_014(cfg, f, *ld)
+        f = tw.f12_mul_by_014(cfg, f, *la)
+    out12(b, f, lay.F)
+    for ps, T2, la, ld, px, py in st:
+        T3, ldn = t_double(cfg, tuple(tw.f2_mat(c) for c in T2), px, py)
+        _out_t(b, ps, T3, ldn, None, zero)
     return b
 
 
@@ -537,27 +545,23 @@ def build_multi(cfg=None, G=MP_G, verbose=False):
     cfg = cfg or tw.Cfg()
     lazy = lazy_cfg(cfg)
     lay = MPLayout(G)
-    script0, first_add = miller_script("mp_init", "mp_body")
-    # a body whose T chains take a tangent AND a chord step is the plain body followed by the
-    # chord segment: every segment then fits the scratchpad the plain doubling body needs
-    script = []
-    for name in script0:
-        script += ["mp_body_%s0" % name[-2], "mp_chord"] if name.endswith("1") else [name]
-    # (segment, first temporary, linear combinations on demand).  The body that multiplies
-    # the chord lines in reads LA, so its temporaries start above it; scheduling its linear
-    # combinations on demand (core.schedule lazy_lin) costs it a few rounds and saves ~50 slots.
-    plan = [(seg_init(lazy, first_add, G, "mp_init", lay), lay.TEMP_HI, False),
-            (seg_chord(lazy, G, lay), lay.TEMP_HI, False)]
-    for name in sorted(set(n for n in script if n.startswith("mp_body"))):
-        cur_add, nxt = int(name[-2]), int(name[-1])
-        plan.append((seg_body(lazy, cur_add, nxt, G, "mp_body", lay), lay.TEMP_MID if cur_add else lay.TEMP_LO, bool(cur_add)))
+    bits = [(NX >> p) & 1 for p in range(62, -1, -1)]
+    # step k multiplies the chord line in iff bit k is set (fields_t.py:1104); the chord step
+    # itself runs inside that body, so the T chain is a tangent step ahead only
+    script = ["mp_init"] + [("mp_body_c0" if bit else ("mp_body_02" if k + 1 == len(bits) else "mp_body_00"))
+                            for k, bit in enumerate(bits)]
+    assert bits[-1] == 0 and not any(a and b_ for a, b_ in zip(bits, bits[1:]))
+    plan = [(seg_init(lazy, False, G, "mp_init", lay), lay.TEMP_HI, False),
+            (seg_body_chord(lazy, 0, G, lay), lay.TEMP_HI, False),
+            (seg_body(lazy, 0, 0, G, "mp_body", lay), lay.TEMP_LO, False),
+            (seg_body(lazy, 0, 2, G, "mp_body", lay), lay.TEMP_LO, False)]
     segs = {}
     for b, tb, on_demand in plan:
         segs[b.name] = schedule(b, temp_base=tb, verbose=verbose, lazy_lin=on_demand)
         segs[b.name].temp_base = tb
     # the Q window travels in registers between the segments that use it (MPLayout)
     segs["mp_init"].rounds.append({"kind": "save", "K": lay.Q, "lanes": []})
-    segs["mp_chord"].rounds.insert(0, {"kind": "restore", "K": lay.Q, "lanes": []})
+    segs["mp_body_c0"].rounds.insert(0, {"kind": "restore", "K": lay.Q, "lanes": []})
     return segs, script, lay
 
 
