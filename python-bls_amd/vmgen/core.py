@@ -349,7 +349,7 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False, fold_copies=True, lazy_
 
     level = 0
     while pending:
-        if lazy_lin is True and any(heavy(v) for v in pending):
+        if lazy_lin and any(heavy(v) for v in pending):
             # LIN phase, on demand: decide the next level's heavy ops first (looking through
             # the linear ops that COULD run now), then run only the linear ops they read;
             # the others wait for their own consumers, which spreads the linear work over
@@ -387,31 +387,6 @@ def schedule(b, temp_base=0, lanes=LANES, verbose=False, fold_copies=True, lazy_
             rl = [v for v in pending if v.kind == "lin" and all(s.id in done for s in srcs(v))]
             if not rl:
                 break
-            if lazy_lin == "overflow" and len(rl) > lanes and any(heavy(v) for v in pending):
-                # more ready combinations than lanes: run what the next level's heavy ops read
-                # (looking through the linear ops that could run now) and as many of the others
-                # as fit the same number of rounds; the rest waits for a later linear phase
-                reach = set(done)
-                grew = True
-                lin_pending = [v for v in pending if v.kind == "lin"]
-                while grew:
-                    grew = False
-                    for v in lin_pending:
-                        if v.id not in reach and all(s.id in reach for s in srcs(v)):
-                            reach.add(v.id)
-                            grew = True
-                need, stack = set(), [s for _, ch in choose_heavy(reach, level + 1) for v in ch for s in srcs(v)]
-                while stack:
-                    x = stack.pop()
-                    if x.id in done or x.id in need or x.kind != "lin":
-                        continue
-                    need.add(x.id)
-                    stack += srcs(x)
-                now = [v for v in rl if v.id in need]
-                if now:
-                    cap = lanes * ((len(now) + lanes - 1) // lanes)
-                    rest = sorted([v for v in rl if v.id not in need], key=lambda v: -prio[v.id])
-                    rl = now + rest[:cap - len(now)]
             emit_lins(rl)
         if not pending:
             break
