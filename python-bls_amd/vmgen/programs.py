@@ -329,8 +329,9 @@ def seg_body_chord(cfg, nxt, G, lay, prefix="mp_body"):
         ld = [in2(b, ps.LD + 2 * i) for i in range(3)]
         T2, la = t_add(cfg, Tp, Qa, px, py, True)
         st.append((ps, T2, la, ld, px, py))
-    for ps, T2, la, ld, px, py in st:
+    for ps, T2, la, ld, px, py in st:                # the tangent lines are there at once,
         f = tw.f12_mul_by_014(cfg, f, *ld)
+    for ps, T2, la, ld, px, py in st:                # the chord lines four product levels later
         f = tw.f12_mul_by_014(cfg, f, *la)
     out12(b, f, lay.F)
     for ps, T2, la, ld, px, py in st:
