@@ -13,11 +13,30 @@
  *   G1    affine x || y, 96 bytes    -- the (x, y) of fq_ate_pairing_multi's Ps
  *   G2    affine x.c0 || x.c1 || y.c0 || y.c1, 192 bytes -- the ((x0,x1),(y0,y1)) of Qs
  * Infinity is the reference's coordinate encoding (0,0) (fields_t.py:609-622).
+ *   inf   optional n x 2 bytes, (P flag, Q flag) per pair -- the third member of the
+ *         (x, y, inf) tuples fq_ate_pairing_multi takes (fields_t_c.pyx:2333-2346); NULL = all
+ *         False.  As in the reference only Q's flag has an effect (fields_t.py:676-677).
+ * Coordinates must be canonical residues (< q), as the reference assumes (no check there
+ * either).  For EVERY such input -- points of the wrong order, off the curve, zero
+ * coordinates, flags -- the pairing entry points return the reference's bytes: pairs on
+ * which the reference's special cases decide (0^-1 := 0, fields_t.py:47-55; the branches of
+ * fq2_add_line_eval :1062-1065 and fq2_add_points :673-686) are detected on the GPU and
+ * recomputed there by a reference-faithful program (k_miller_slow).
  *
  * All functions return 0 on success or a negative errno-style code;
  * blsgpu_last_error() describes the last failure on the calling thread.
  * Buffers are caller-allocated; nothing owned by the library crosses the ABI
- * except the opaque context.  A context may be used from one thread at a time.
+ * except the opaque context.
+ *
+ * Threading and streams.  A context is used by ONE host thread at a time (the reference's
+ * native module is not re-entrant either: module-global scratch pools,
+ * fields_t_c.pyx:2401-2412); different contexts are independent.  Every `_dev` entry point
+ * enqueues on the caller's stream and returns; all of a context's work shares one
+ * workspace, so a call on another stream than the context's previous call first waits (on
+ * the device) for that earlier work -- for concurrency use one context per stream.  The
+ * workspace only grows: a buffer that a larger one replaces is kept until
+ * blsgpu_ctx_trim / blsgpu_ctx_destroy, so growth never invalidates enqueued work and never
+ * synchronises the device inside a pipeline; blsgpu_ctx_reserve sizes it up front.
  */
 #ifndef BLSGPU_H
 #define BLSGPU_H
@@ -47,6 +66,8 @@ int blsgpu_ctx_create(int device, blsgpu_ctx **out);
 void blsgpu_ctx_destroy(blsgpu_ctx *ctx);
 /* Pre-size the per-context workspace for batches of up to max_pairs pairs. */
 int blsgpu_ctx_reserve(blsgpu_ctx *ctx, size_t max_pairs);
+/* Wait for the context's enqueued work and free the buffers that larger ones replaced. */
+int blsgpu_ctx_trim(blsgpu_ctx *ctx);
 /* Batches of at least `pairs` pairs run the throughput-oriented Miller kernel
  * (several pairs per wavefront sharing one accumulator); smaller batches the
  * latency-oriented one (one pair per wavefront).  Default 4096; 0 = always the
@@ -55,21 +76,37 @@ int blsgpu_ctx_set_mp_threshold(blsgpu_ctx *ctx, size_t pairs);
 
 /* fq_ate_pairing_multi(Ps, Qs) -- fields_t.py:1114-1121 / fields_t_c.pyx:2333-2391.
  * Host buffers in, 576 result bytes out; synchronous.  n == 0 returns one. */
-int blsgpu_pairing_multi(blsgpu_ctx *ctx, const uint8_t *g1, const uint8_t *g2,
+int blsgpu_pairing_multi(blsgpu_ctx *ctx, const uint8_t *g1, const uint8_t *g2, const uint8_t *inf,
                          size_t n, uint8_t out[BLSGPU_FQ12_BYTES]);
 
 /* Same computation on device-resident buffers, enqueued on `stream`
  * (a hipStream_t, or NULL for the default stream); asynchronous.
  * d_out receives 576 bytes. */
-int blsgpu_pairing_multi_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2,
+int blsgpu_pairing_multi_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2, const void *d_inf,
                              size_t n, void *d_out, void *stream);
+
+/* fq_miller_loop(px, py, pinf, qx, qy, qinf) -- fields_t.py:1091-1111 / fields_t_c.pyx:2295-2319
+ * (pairing.miller_loop, pairing.py:51-65) for n pairs at once: out receives n x 576 bytes,
+ * the reference's own Miller values bit for bit (computed by the reference-faithful program:
+ * affine twist point, one inversion per step; the throughput path is blsgpu_pairing_multi). */
+int blsgpu_miller_loop_batch(blsgpu_ctx *ctx, const uint8_t *g1, const uint8_t *g2, const uint8_t *inf,
+                             size_t n, uint8_t *out);
+int blsgpu_miller_loop_batch_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2, const void *d_inf,
+                                 size_t n, void *d_out, void *stream);
+
+/* fq2_double_line_eval(R, P) -- fields_t.py:1035-1049 / fields_t_c.pyx:1416-1445 (q == NULL) and
+ * fq2_add_line_eval(R, Q, P) -- fields_t.py:1052-1078 / fields_t_c.pyx:1448-1511 (pairing.double_line_eval,
+ * pairing.add_line_eval, pairing.py:16-48), for n triples at once: r, q: n x 192 bytes (twist
+ * points), p: n x 96 bytes; out: n x 576 bytes, the reference's Fq12 line values. */
+int blsgpu_line_eval_batch(blsgpu_ctx *ctx, const uint8_t *r, const uint8_t *q, const uint8_t *p, size_t n,
+                           uint8_t *out);
 
 /* Sharded form (one rank per GPU).  Step 1: the product of the n Miller-loop
  * values of this shard (fq_miller_loop, fields_t.py:1091-1111, folded with
  * fq12_mul as in :1119-1120) as ONE partial of BLSGPU_PARTIAL_WORDS uint32.
  * Step 2, after the partials of all ranks were gathered: their product and the
  * final exponentiation (fq12_final_exp, fields_t.py:1124-1128) -> 576 bytes. */
-int blsgpu_miller_product_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2,
+int blsgpu_miller_product_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2, const void *d_inf,
                               size_t n, void *d_partial, void *stream);
 int blsgpu_final_exp_product_dev(blsgpu_ctx *ctx, const void *d_partials, size_t m,
                                  void *d_out, void *stream);
@@ -85,18 +122,18 @@ int blsgpu_final_exp_batch(blsgpu_ctx *ctx, const uint8_t *in, size_t m, uint8_t
  * launch sequence (e.g. 10 000 threshold verifications of 2 pairs: BLS.verify,
  * bls.py:153-201, once per group).  Pairs are stored group after group;
  * out receives groups x 576 bytes. */
-int blsgpu_pairing_multi_batch(blsgpu_ctx *ctx, const uint8_t *g1, const uint8_t *g2, size_t gsz,
-                               size_t groups, uint8_t *out);
-int blsgpu_pairing_multi_batch_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2, size_t gsz,
-                                   size_t groups, void *d_out, void *stream);
+int blsgpu_pairing_multi_batch(blsgpu_ctx *ctx, const uint8_t *g1, const uint8_t *g2, const uint8_t *inf,
+                               size_t gsz, size_t groups, uint8_t *out);
+int blsgpu_pairing_multi_batch_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2, const void *d_inf,
+                                   size_t gsz, size_t groups, void *d_out, void *stream);
 
 /* Sharded form of the batch: every rank holds gsz pairs of each of the `groups`
  * multi-pairings.  Step 1 writes one partial per group (groups x
  * BLSGPU_PARTIAL_WORDS uint32).  Step 2 takes the all-gathered buffer of m ranks
  * (partial of rank i, group g at index i * groups + g), multiplies per group and
  * applies fq12_final_exp (fields_t.py:1116-1121 per group) -> groups x 576 bytes. */
-int blsgpu_miller_product_batch_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2, size_t gsz,
-                                    size_t groups, void *d_partials, void *stream);
+int blsgpu_miller_product_batch_dev(blsgpu_ctx *ctx, const void *d_g1, const void *d_g2, const void *d_inf,
+                                    size_t gsz, size_t groups, void *d_partials, void *stream);
 int blsgpu_final_exp_product_batch_dev(blsgpu_ctx *ctx, const void *d_partials, size_t m,
                                        size_t groups, void *d_out, void *stream);
 
@@ -151,7 +188,8 @@ int blsgpu_g2_decompress_dev(blsgpu_ctx *ctx, const void *d_in, size_t n, void *
  * between reads).  blsgpu_timing_read waits for them and returns, per launch,
  * the duration in ms and the kernel kind: 0 = k_miller (Miller loops + workgroup
  * product), 1 = k_reduce (partial products), 2 = k_reduce with the final
- * exponentiation.  Reading resets the ring. */
+ * exponentiation, 3 = k_miller_slow (degenerate pairs; empty work list normally).
+ * Reading resets the ring. */
 int blsgpu_timing_enable(blsgpu_ctx *ctx, int enable);
 int blsgpu_timing_read(blsgpu_ctx *ctx, float *ms, int *kind, size_t cap, size_t *count);
 

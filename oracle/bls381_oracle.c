@@ -672,6 +672,20 @@ EXPORT int oracle_miller_loop(const uint8_t g1[96], const uint8_t g2[192], int q
     fq12_to_bytes(out, &f);
     return 0;
 }
+/* fq2_double_line_eval(R, P) (q == NULL) / fq2_add_line_eval(R, Q, P), fields_t.py:1035-1078 */
+EXPORT int oracle_line_eval(const uint8_t r[192], const uint8_t *q, const uint8_t p[96], uint8_t out[576]) {
+    ensure_init();
+    g1aff P; g2aff R, Qp; fq12 l;
+    g1_from_bytes(&P, p); g2_from_bytes(&R, r);
+    if (q) {
+        g2_from_bytes(&Qp, q);
+        add_line_eval(&l, &R.x, &R.y, &Qp.x, &Qp.y, &P.x, &P.y);
+    } else {
+        double_line_eval(&l, &R.x, &R.y, &P.x, &P.y);
+    }
+    fq12_to_bytes(out, &l);
+    return 0;
+}
 EXPORT int oracle_final_exp(const uint8_t in[576], uint8_t out[576]) {
     ensure_init();
     fq12 x, r;

@@ -24,6 +24,7 @@ def lib():
         c_p = ctypes.c_char_p
         L.oracle_miller_loop.argtypes = [c_p, c_p, ctypes.c_int, c_p]
         L.oracle_final_exp.argtypes = [c_p, c_p]
+        L.oracle_line_eval.argtypes = [c_p, c_p, c_p, c_p]
         L.oracle_pairing_multi.argtypes = [c_p, c_p, c_p, ctypes.c_size_t, c_p]
         L.oracle_pairing_multi_mt.argtypes = [c_p, c_p, c_p, ctypes.c_size_t, ctypes.c_int, c_p]
         L.oracle_field_op.argtypes = [ctypes.c_int, ctypes.c_int, c_p, c_p, c_p]
@@ -43,6 +44,13 @@ def _out(n):
 def miller_loop(g1: bytes, g2: bytes, qinf: bool = False) -> bytes:
     o = _out(576)
     assert lib().oracle_miller_loop(g1, g2, int(qinf), o) == 0
+    return o.raw
+
+
+def line_eval(r: bytes, q, p: bytes) -> bytes:
+    """fq2_double_line_eval(R, P) when q is None, else fq2_add_line_eval(R, Q, P)."""
+    o = _out(576)
+    assert lib().oracle_line_eval(r, q, p, o) == 0
     return o.raw
 
 

@@ -22,6 +22,7 @@ SYMBOLS = (
     "blsgpu_miller_product_batch_dev", "blsgpu_final_exp_product_batch_dev",
     "blsgpu_g1_decompress", "blsgpu_g2_decompress", "blsgpu_g1_decompress_dev", "blsgpu_g2_decompress_dev",
     "blsgpu_hash_to_g2", "blsgpu_hash_to_g2_dev",
+    "blsgpu_miller_loop_batch", "blsgpu_miller_loop_batch_dev", "blsgpu_line_eval_batch", "blsgpu_ctx_trim",
 )
 
 _lib = None
@@ -60,9 +61,13 @@ def load_library(path=None):
         L.blsgpu_ctx_destroy.restype = None
         L.blsgpu_ctx_reserve.argtypes = [vp, sz]
         L.blsgpu_ctx_set_mp_threshold.argtypes = [vp, sz]
-        L.blsgpu_pairing_multi.argtypes = [vp, cp, cp, sz, cp]
-        L.blsgpu_pairing_multi_dev.argtypes = [vp, vp, vp, sz, vp, vp]
-        L.blsgpu_miller_product_dev.argtypes = [vp, vp, vp, sz, vp, vp]
+        L.blsgpu_ctx_trim.argtypes = [vp]
+        L.blsgpu_pairing_multi.argtypes = [vp, cp, cp, cp, sz, cp]
+        L.blsgpu_pairing_multi_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+        L.blsgpu_miller_loop_batch.argtypes = [vp, cp, cp, cp, sz, cp]
+        L.blsgpu_miller_loop_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+        L.blsgpu_line_eval_batch.argtypes = [vp, cp, cp, cp, sz, cp]
+        L.blsgpu_miller_product_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
         L.blsgpu_final_exp_product_dev.argtypes = [vp, vp, sz, vp, vp]
         L.blsgpu_final_exp.argtypes = [vp, cp, cp]
         for f in (L.blsgpu_g1_msm, L.blsgpu_g2_msm):
@@ -70,9 +75,9 @@ def load_library(path=None):
         for f in (L.blsgpu_g1_msm_dev, L.blsgpu_g2_msm_dev):
             f.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp]
         L.blsgpu_final_exp_batch.argtypes = [vp, cp, sz, cp]
-        L.blsgpu_pairing_multi_batch.argtypes = [vp, cp, cp, sz, sz, cp]
-        L.blsgpu_pairing_multi_batch_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp]
-        L.blsgpu_miller_product_batch_dev.argtypes = [vp, vp, vp, sz, sz, vp, vp]
+        L.blsgpu_pairing_multi_batch.argtypes = [vp, cp, cp, cp, sz, sz, cp]
+        L.blsgpu_pairing_multi_batch_dev.argtypes = [vp, vp, vp, vp, sz, sz, vp, vp]
+        L.blsgpu_miller_product_batch_dev.argtypes = [vp, vp, vp, vp, sz, sz, vp, vp]
         L.blsgpu_final_exp_product_batch_dev.argtypes = [vp, vp, sz, sz, vp, vp]
         L.blsgpu_g1_decompress.argtypes = [vp, cp, sz, cp, cp]
         L.blsgpu_g2_decompress.argtypes = [vp, cp, sz, cp, cp]
@@ -127,12 +132,41 @@ class Engine:
     def reserve(self, max_pairs):
         self._check(self.lib.blsgpu_ctx_reserve(self.h, max_pairs), "blsgpu_ctx_reserve")
 
-    def pairing_multi(self, g1: bytes, g2: bytes, n: int) -> bytes:
+    def trim(self):
+        self._check(self.lib.blsgpu_ctx_trim(self.h), "blsgpu_ctx_trim")
+
+    @staticmethod
+    def _inf(inf, n):
+        """n x (P flag, Q flag) bytes, or None"""
+        if inf is None:
+            return None
+        inf = bytes(inf)
+        if len(inf) != 2 * n:
+            raise ValueError("inf must hold 2 flags per pair")
+        return inf
+
+    def pairing_multi(self, g1: bytes, g2: bytes, n: int, inf=None) -> bytes:
         if len(g1) != 96 * n or len(g2) != 192 * n:
             raise ValueError("g1/g2 length does not match n")
         out = ctypes.create_string_buffer(576)
-        self._check(self.lib.blsgpu_pairing_multi(self.h, g1, g2, n, out), "blsgpu_pairing_multi")
+        self._check(self.lib.blsgpu_pairing_multi(self.h, g1, g2, self._inf(inf, n), n, out), "blsgpu_pairing_multi")
         return out.raw
+
+    def miller_loop_batch(self, g1: bytes, g2: bytes, n: int, inf=None) -> bytes:
+        """n x 576 bytes: the reference's fq_miller_loop value of every pair."""
+        if len(g1) != 96 * n or len(g2) != 192 * n:
+            raise ValueError("g1/g2 length does not match n")
+        out = ctypes.create_string_buffer(max(1, 576 * n))
+        self._check(self.lib.blsgpu_miller_loop_batch(self.h, g1, g2, self._inf(inf, n), n, out), "blsgpu_miller_loop_batch")
+        return out.raw[:576 * n]
+
+    def line_eval_batch(self, r: bytes, q, p: bytes, n: int) -> bytes:
+        """fq2_double_line_eval(R, P) (q None) / fq2_add_line_eval(R, Q, P) for n triples -> n x 576 bytes."""
+        if len(r) != 192 * n or len(p) != 96 * n or (q is not None and len(q) != 192 * n):
+            raise ValueError("buffer lengths do not match n")
+        out = ctypes.create_string_buffer(max(1, 576 * n))
+        self._check(self.lib.blsgpu_line_eval_batch(self.h, r, q, p, n, out), "blsgpu_line_eval_batch")
+        return out.raw[:576 * n]
 
     def final_exp(self, x: bytes) -> bytes:
         if len(x) != 576:
@@ -148,12 +182,12 @@ class Engine:
         self._check(self.lib.blsgpu_final_exp_batch(self.h, xs, len(xs) // 576, out), "blsgpu_final_exp_batch")
         return out.raw[:len(xs)]
 
-    def pairing_multi_batch(self, g1: bytes, g2: bytes, gsz: int, groups: int) -> bytes:
+    def pairing_multi_batch(self, g1: bytes, g2: bytes, gsz: int, groups: int, inf=None) -> bytes:
         n = gsz * groups
         if len(g1) != 96 * n or len(g2) != 192 * n:
             raise ValueError("g1/g2 length does not match gsz * groups")
         out = ctypes.create_string_buffer(max(1, 576 * groups))
-        self._check(self.lib.blsgpu_pairing_multi_batch(self.h, g1, g2, gsz, groups, out), "blsgpu_pairing_multi_batch")
+        self._check(self.lib.blsgpu_pairing_multi_batch(self.h, g1, g2, self._inf(inf, n), gsz, groups, out), "blsgpu_pairing_multi_batch")
         return out.raw[:576 * groups]
 
     def _decompress(self, fn, name, insz, data):
@@ -216,7 +250,7 @@ class Engine:
 
     def timing_read(self):
         """[(kind, ms)] for every kernel launched since the last read; kinds:
-        0 k_miller, 1 k_reduce, 2 k_reduce + final exponentiation."""
+        0 k_miller, 1 k_reduce, 2 k_reduce + final exponentiation, 3 k_miller_slow."""
         cap = 1024
         ms = (ctypes.c_float * cap)()
         kind = (ctypes.c_int * cap)()
@@ -225,24 +259,29 @@ class Engine:
         return [(kind[i], ms[i]) for i in range(cnt.value)]
 
     # device-pointer forms (integers: tensor.data_ptr(), stream.cuda_stream)
-    def pairing_multi_dev(self, d_g1, d_g2, n, d_out, stream=0):
-        self._check(self.lib.blsgpu_pairing_multi_dev(self.h, d_g1, d_g2, n, d_out, stream),
+    # (d_inf: device pointer to n x 2 flag bytes, or None)
+    def pairing_multi_dev(self, d_g1, d_g2, n, d_out, stream=0, d_inf=None):
+        self._check(self.lib.blsgpu_pairing_multi_dev(self.h, d_g1, d_g2, d_inf, n, d_out, stream),
                     "blsgpu_pairing_multi_dev")
 
-    def miller_product_dev(self, d_g1, d_g2, n, d_partial, stream=0):
-        self._check(self.lib.blsgpu_miller_product_dev(self.h, d_g1, d_g2, n, d_partial, stream),
+    def miller_loop_batch_dev(self, d_g1, d_g2, n, d_out, stream=0, d_inf=None):
+        self._check(self.lib.blsgpu_miller_loop_batch_dev(self.h, d_g1, d_g2, d_inf, n, d_out, stream),
+                    "blsgpu_miller_loop_batch_dev")
+
+    def miller_product_dev(self, d_g1, d_g2, n, d_partial, stream=0, d_inf=None):
+        self._check(self.lib.blsgpu_miller_product_dev(self.h, d_g1, d_g2, d_inf, n, d_partial, stream),
                     "blsgpu_miller_product_dev")
 
     def final_exp_product_dev(self, d_partials, m, d_out, stream=0):
         self._check(self.lib.blsgpu_final_exp_product_dev(self.h, d_partials, m, d_out, stream),
                     "blsgpu_final_exp_product_dev")
 
-    def pairing_multi_batch_dev(self, d_g1, d_g2, gsz, groups, d_out, stream=0):
-        self._check(self.lib.blsgpu_pairing_multi_batch_dev(self.h, d_g1, d_g2, gsz, groups, d_out, stream),
+    def pairing_multi_batch_dev(self, d_g1, d_g2, gsz, groups, d_out, stream=0, d_inf=None):
+        self._check(self.lib.blsgpu_pairing_multi_batch_dev(self.h, d_g1, d_g2, d_inf, gsz, groups, d_out, stream),
                     "blsgpu_pairing_multi_batch_dev")
 
-    def miller_product_batch_dev(self, d_g1, d_g2, gsz, groups, d_partials, stream=0):
-        self._check(self.lib.blsgpu_miller_product_batch_dev(self.h, d_g1, d_g2, gsz, groups, d_partials, stream),
+    def miller_product_batch_dev(self, d_g1, d_g2, gsz, groups, d_partials, stream=0, d_inf=None):
+        self._check(self.lib.blsgpu_miller_product_batch_dev(self.h, d_g1, d_g2, d_inf, gsz, groups, d_partials, stream),
                     "blsgpu_miller_product_batch_dev")
 
     def final_exp_product_batch_dev(self, d_partials, m, groups, d_out, stream=0):

@@ -13,14 +13,20 @@ class HipProvider:
         from . import _native
         self._eng = _native.engine(device)
 
-    def pairing_multi(self, g1: bytes, g2: bytes, n: int) -> bytes:
-        return self._eng.pairing_multi(g1, g2, n)
+    def pairing_multi(self, g1: bytes, g2: bytes, n: int, inf=None) -> bytes:
+        return self._eng.pairing_multi(g1, g2, n, inf)
+
+    def miller_loop_batch(self, g1: bytes, g2: bytes, n: int, inf=None) -> bytes:
+        return self._eng.miller_loop_batch(g1, g2, n, inf)
+
+    def line_eval_batch(self, r: bytes, q, p: bytes, n: int) -> bytes:
+        return self._eng.line_eval_batch(r, q, p, n)
 
     def final_exp(self, x: bytes) -> bytes:
         return self._eng.final_exp(x)
 
-    def pairing_multi_batch(self, g1: bytes, g2: bytes, gsz: int, groups: int) -> bytes:
-        return self._eng.pairing_multi_batch(g1, g2, gsz, groups)
+    def pairing_multi_batch(self, g1: bytes, g2: bytes, gsz: int, groups: int, inf=None) -> bytes:
+        return self._eng.pairing_multi_batch(g1, g2, gsz, groups, inf)
 
     def g1_msm(self, pts: bytes, scalars, k: int, groups: int = 1):
         return self._eng.g1_msm(pts, scalars, k, groups)
@@ -42,7 +48,8 @@ class HipProvider:
 
 
 def use(provider):
-    """Install a provider object with pairing_multi(g1, g2, n), final_exp(x),
+    """Install a provider object with pairing_multi(g1, g2, n, inf=None), final_exp(x),
+    miller_loop_batch(g1, g2, n, inf=None), line_eval_batch(r, q|None, p, n),
     g1_msm / g2_msm(pts, scalars|None, k, groups) -> (bytes, [is_inf]),
     map_to_g2(t: n x 192 bytes) -> n x 192 bytes,
     g1_decompress / g2_decompress(bytes) -> (affine bytes, [accepted])."""

@@ -1,17 +1,18 @@
-"""Drop-in for the hot functions of the reference's native module
+"""Drop-in for the pairing functions of the reference's native module
 `bls_py.fields_t_c` (extmod/bls_py/fields_t_c.pyx), backed by libblsgpu.so.
 
 Same names, argument shapes and return types as the functions that
 bls_py/fields_t.py:1256-1263 re-binds from the native module:
 
-    fq_ate_pairing_multi(Ps, Qs) -> 12-tuple of ints   (fields_t.py:1114-1121)
-    fq12_final_exp(t)            -> 12-tuple of ints   (fields_t.py:1124-1128)
+    fq_ate_pairing_multi(Ps, Qs)                    -> 12-tuple of ints   (fields_t.py:1114-1121)
+    fq_miller_loop(px, py, pinf, qx, qy, qinf)      -> 12-tuple of ints   (fields_t.py:1091-1111)
+    fq12_final_exp(t)                               -> 12-tuple of ints   (fields_t.py:1124-1128)
+    fq2_double_line_eval(rx, ry, px, py)            -> 12-tuple of ints   (fields_t.py:1035-1049)
+    fq2_add_line_eval(rx, ry, qx, qy, px, py)       -> 12-tuple of ints   (fields_t.py:1052-1078)
 
-Ps = tuple of (x, y, inf), Qs = tuple of ((x0, x1), (y0, y1), inf), ints in
-[0, q).  Like the reference, P's flag is not consulted; infinity is the (0,0)
-coordinate pair that AffinePoint / to_affine produce (fields_t.py:609-622).
-A flagged Q with NON-zero coordinates (never produced by the reference's own
-objects) is rejected with ValueError instead of being mis-evaluated.
+Ps = tuple of (x, y, inf), Qs = tuple of ((x0, x1), (y0, y1), inf), ints in [0, q).  The flags
+are passed on as they are: like the reference, the engine never reads P's, and a flagged Q skips
+the chord updates whatever its coordinates are (fields_t.py:676-677).
 
 There is no CPU fallback: if the GPU library is missing these raise.
 """
@@ -24,23 +25,40 @@ def _fq(v):
     return int(v % Q).to_bytes(48, "big")
 
 
+def _fq2(t):
+    return _fq(t[0]) + _fq(t[1])
+
+
 def _unpack12(b):
     return tuple(int.from_bytes(b[48 * i:48 * (i + 1)], "big") for i in range(12))
 
 
-def fq_ate_pairing_multi(Ps, Qs, device=0):
+def _pack(Ps, Qs):
     n = len(Qs)
-    g1 = bytearray()
-    g2 = bytearray()
-    for i in range(n):
-        px, py, _pinf = Ps[i]
-        (x0, x1), (y0, y1), qinf = Qs[i]
-        if qinf and (x0 or x1 or y0 or y1):
-            raise ValueError("Q[%d] is flagged infinite but has non-zero coordinates" % i)
-        g1 += _fq(px) + _fq(py)
-        g2 += _fq(x0) + _fq(x1) + _fq(y0) + _fq(y1)
-    return _unpack12(_native.engine(device).pairing_multi(bytes(g1), bytes(g2), n))
+    g1 = b"".join(_fq(Ps[i][0]) + _fq(Ps[i][1]) for i in range(n))
+    g2 = b"".join(_fq2(Qs[i][0]) + _fq2(Qs[i][1]) for i in range(n))
+    inf = bytes(b for i in range(n) for b in (int(bool(Ps[i][2])), int(bool(Qs[i][2]))))
+    return g1, g2, (inf if any(inf) else None), n
+
+
+def fq_ate_pairing_multi(Ps, Qs, device=0):
+    g1, g2, inf, n = _pack(Ps, Qs)
+    return _unpack12(_native.engine(device).pairing_multi(g1, g2, n, inf))
+
+
+def fq_miller_loop(px, py, pinf, qx_t, qy_t, qinf, device=0):
+    g1, g2, inf, _ = _pack(((px, py, pinf),), ((qx_t, qy_t, qinf),))
+    return _unpack12(_native.engine(device).miller_loop_batch(g1, g2, 1, inf))
 
 
 def fq12_final_exp(t_x, device=0):
     return _unpack12(_native.engine(device).final_exp(b"".join(_fq(v) for v in t_x)))
+
+
+def fq2_double_line_eval(rx_t, ry_t, px, py, device=0):
+    return _unpack12(_native.engine(device).line_eval_batch(_fq2(rx_t) + _fq2(ry_t), None, _fq(px) + _fq(py), 1))
+
+
+def fq2_add_line_eval(rx_t, ry_t, qx_t, qy_t, px, py, device=0):
+    return _unpack12(_native.engine(device).line_eval_batch(_fq2(rx_t) + _fq2(ry_t), _fq2(qx_t) + _fq2(qy_t),
+                                                            _fq(px) + _fq(py), 1))

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/blsgpu.h"
 #include "blsgpu_kernels.hip"
@@ -47,6 +48,8 @@ struct blsgpu_ctx {
     void* d_io = nullptr;              // staging for the host-buffer entry points
     size_t io_cap = 0;
     uint32_t* d_out = nullptr;         // 576-byte result staging
+    uint32_t* d_degen = nullptr;       // [0] count, [1 ..] block indices of degenerate pairs (k_miller_slow's work list)
+    size_t degen_cap = 0;
     size_t mp_threshold = 4096;        // pairs from which k_miller_mp is used
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
@@ -64,6 +67,16 @@ struct blsgpu_ctx {
     hipEvent_t* ev1 = nullptr;
     int* ev_kind = nullptr;            // 0 k_miller, 1 k_reduce, 2 k_reduce with final exponentiation
     size_t ev_count = 0;
+    // Workspace buffers only ever GROW: the buffer a larger one replaces is kept until the
+    // context is destroyed (or trimmed by blsgpu_ctx_reserve on an idle context), so work
+    // already enqueued on it stays valid and no hipFree -- a device-wide synchronisation --
+    // happens inside a pipeline.
+    std::vector<void*> retired;
+    // The workspace is shared by everything a context launches: a call on another stream than
+    // the previous one first waits for that one's work (StreamGuard).
+    hipStream_t last_stream = nullptr;
+    hipEvent_t last_event = nullptr;
+    bool used = false;
 };
 
 namespace {
@@ -89,19 +102,55 @@ static size_t default_mp_threshold() {
     return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4096;
 }
 static bool use_mp(const blsgpu_ctx* c, size_t n) { return n >= c->mp_threshold; }
+// grow-only (see blsgpu_ctx::retired): *p gets at least `bytes`; contents are scratch, not copied
+static int grow_buffer(blsgpu_ctx* c, void** p, size_t* cap_bytes, size_t bytes) {
+    if (bytes <= *cap_bytes) return 0;
+    size_t want = bytes + bytes / 4;                     // headroom: fewer regrowths
+    void* n = nullptr;
+    if (hipMalloc(&n, want) != hipSuccess) {
+        want = bytes;
+        HIP_TRY(hipMalloc(&n, want));
+    }
+    if (*p) c->retired.push_back(*p);
+    *p = n;
+    *cap_bytes = want;
+    return 0;
+}
+template <class T>
+static int grow_elems(blsgpu_ctx* c, T** p, size_t* cap_elems, size_t elems) {
+    if (elems <= *cap_elems) return 0;
+    size_t bytes = *cap_elems * sizeof(T);
+    int rc = grow_buffer(c, (void**)p, &bytes, elems * sizeof(T));
+    if (rc) return rc;
+    *cap_elems = bytes / sizeof(T);
+    return 0;
+}
 static int ensure_workspace(blsgpu_ctx* c, size_t max_pairs) {
     size_t need = (max_pairs + 2) / 3 + (max_pairs + MILLER_WAVES - 1) / MILLER_WAVES + 1;
     if (need > c->part_cap) {
-        for (int i = 0; i < 2; i++) {
-            if (c->d_part[i]) (void)hipFree(c->d_part[i]);
-            c->d_part[i] = nullptr;
-        }
-        c->part_cap = 0;
-        for (int i = 0; i < 2; i++) HIP_TRY(hipMalloc((void**)&c->d_part[i], need * 144 * sizeof(uint32_t)));
-        c->part_cap = need;
+        size_t cap0 = c->part_cap * 144, cap1 = c->part_cap * 144;     // in u32
+        int rc = grow_elems(c, &c->d_part[0], &cap0, need * 144);
+        if (!rc) rc = grow_elems(c, &c->d_part[1], &cap1, need * 144);
+        if (rc) return rc;
+        c->part_cap = (cap0 < cap1 ? cap0 : cap1) / 144;
     }
-    return 0;
+    // one work-list entry per Miller block at most (+ the counter)
+    return grow_elems(c, &c->d_degen, &c->degen_cap, c->part_cap + 2);
 }
+namespace {
+// Serialises the use of the context's workspace across streams (blsgpu_ctx::last_stream).
+struct StreamGuard {
+    blsgpu_ctx* c; hipStream_t st;
+    StreamGuard(blsgpu_ctx* c_, hipStream_t st_) : c(c_), st(st_) {
+        if (c->used && c->last_stream != st && c->last_event) (void)hipStreamWaitEvent(st, c->last_event, 0);
+    }
+    ~StreamGuard() {
+        if (c->last_event) (void)hipEventRecord(c->last_event, st);
+        c->last_stream = st;
+        c->used = true;
+    }
+};
+}  // namespace
 
 // fixed-exponent powers on a stage image (blsgpu_h2c.hip)
 static int launch_pow(blsgpu_ctx* c, uint32_t* img, uint32_t img_slots, uint32_t base_off, uint32_t acc_off, size_t teams, uint32_t cnt,
@@ -119,16 +168,11 @@ template <int DEG>
 int decompress_dev(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out, void* d_ok, hipStream_t st) {
     using C = blsgpu::DecompCfg<DEG>;
     if (n == 0) return 0;
+    StreamGuard sg(c, st);
     if (n > 0x0FFFFFF0ull) return fail(-EINVAL, "batch too large");
     const size_t teams = (n + C::NE - 1) / C::NE;
     size_t need = teams * C::IMG * 12;
-    if (need > c->msm_part_cap) {
-        if (c->d_msm_part) (void)hipFree(c->d_msm_part);
-        c->d_msm_part = nullptr;
-        c->msm_part_cap = 0;
-        HIP_TRY(hipMalloc((void**)&c->d_msm_part, need * sizeof(uint32_t)));
-        c->msm_part_cap = need;
-    }
+    if (int rc_ = grow_elems(c, &c->d_msm_part, &c->msm_part_cap, need)) return rc_;
     uint32_t* img = c->d_msm_part;
     const size_t lds = (size_t)C::SLOTS * 48;
     constexpr uint32_t BASE = C::BASE - C::STATE0, ACC = C::ACC - C::STATE0;
@@ -155,13 +199,7 @@ int decompress_host(blsgpu_ctx* c, const uint8_t* in, size_t n, uint8_t* out, ui
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
     size_t need = n * (48 * DEG + 96 * DEG + 1) + 64;
-    if (need > c->io_cap) {
-        if (c->d_io) (void)hipFree(c->d_io);
-        c->d_io = nullptr;
-        c->io_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_io, need));
-        c->io_cap = need;
-    }
+    if (int rc_ = grow_buffer(c, &c->d_io, &c->io_cap, need)) return rc_;
     char* din = (char*)c->d_io;
     char* dout = din + n * 48 * DEG;
     char* dok = dout + n * 96 * DEG;
@@ -183,6 +221,7 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
             void* d_out_inf, hipStream_t st) {
     using C = blsgpu::MsmCfg<DEG>;
     if (groups == 0) return 0;
+    StreamGuard sg(c, st);
     if (k == 0) {                                   // empty sums: infinity
         HIP_TRY(hipMemsetAsync(d_out, 0, groups * 96 * DEG, st));
         if (d_out_inf) HIP_TRY(hipMemsetAsync(d_out_inf, 1, groups, st));
@@ -204,13 +243,7 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
         size_t chunks = (k + chunk - 1) / chunk;
         const size_t fold_n = (lane_path && chunks > 96) ? (chunks + 63) / 64 : 0;
         size_t need = (chunks + 1) * groups * blsgpu::PIP_W * 36 * DEG + n * 36 * DEG;
-        if (need > c->msm_part_cap) {
-            if (c->d_msm_part) (void)hipFree(c->d_msm_part);
-            c->d_msm_part = nullptr;
-            c->msm_part_cap = 0;
-            HIP_TRY(hipMalloc((void**)&c->d_msm_part, need * sizeof(uint32_t)));
-            c->msm_part_cap = need;
-        }
+        if (int rc_ = grow_elems(c, &c->d_msm_part, &c->msm_part_cap, need)) return rc_;
         uint32_t* d_win = c->d_msm_part + chunks * groups * blsgpu::PIP_W * 36 * DEG;
         uint32_t* d_prep = d_win + groups * blsgpu::PIP_W * 36 * DEG;
         size_t pblocks = (n + (size_t)MSM_WAVES * C::NP - 1) / ((size_t)MSM_WAVES * C::NP);
@@ -221,13 +254,7 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
             // one (group, chunk, window) per lane, buckets in HBM
             const size_t lanes = groups * chunks * blsgpu::PIP_W;
             const size_t bneed = lanes * (blsgpu::PIP_NB - 1) * 36 * DEG + fold_n * groups * blsgpu::PIP_W * 36 * DEG;
-            if (bneed > c->bucket_cap) {
-                if (c->d_buckets) (void)hipFree(c->d_buckets);
-                c->d_buckets = nullptr;
-                c->bucket_cap = 0;
-                HIP_TRY(hipMalloc((void**)&c->d_buckets, bneed * sizeof(uint32_t)));
-                c->bucket_cap = bneed;
-            }
+            if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, bneed)) return rc_;
             hipLaunchKernelGGL(blsgpu::k_msm_lane<DEG>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, d_prep,
                                (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, (uint32_t)chunks, (uint32_t)lanes, c->d_buckets,
                                c->d_msm_part);
@@ -271,13 +298,7 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
     size_t bpg = (k + chunk - 1) / chunk;
     size_t blocks = bpg * groups;
     size_t need = blocks * 36 * DEG;
-    if (need > c->msm_part_cap) {
-        if (c->d_msm_part) (void)hipFree(c->d_msm_part);
-        c->d_msm_part = nullptr;
-        c->msm_part_cap = 0;
-        HIP_TRY(hipMalloc((void**)&c->d_msm_part, need * sizeof(uint32_t)));
-        c->msm_part_cap = need;
-    }
+    if (int rc_ = grow_elems(c, &c->d_msm_part, &c->msm_part_cap, need)) return rc_;
     size_t lds = (size_t)MSM_WAVES * blsgpu::TEAM_BYTES;
     hipLaunchKernelGGL(blsgpu::k_msm<DEG>, dim3((unsigned)blocks), dim3(MSM_WAVES * 64), lds, st, c->tabs,
                        (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, (uint32_t)bpg,
@@ -299,13 +320,7 @@ int msm_host(blsgpu_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t k
     HIP_TRY(hipSetDevice(c->device));
     size_t pb = n * 96 * DEG, sb = scalars ? n * 32 : 0, ob = groups * 96 * DEG;
     size_t need = pb + sb + ob + groups + 64;
-    if (need > c->io_cap) {
-        if (c->d_io) (void)hipFree(c->d_io);
-        c->d_io = nullptr;
-        c->io_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_io, need));
-        c->io_cap = need;
-    }
+    if (int rc_ = grow_buffer(c, &c->d_io, &c->io_cap, need)) return rc_;
     char* dp = (char*)c->d_io;
     char* ds = dp + pb;
     char* dout = ds + ((sb + 15) & ~size_t(15));
@@ -351,7 +366,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     size_t o_mp = o_m + al(sizeof(BLSVM_MILLER_FLAT));
     size_t o_h2 = o_mp + al(sizeof(BLSVM_MP_FLAT));
     size_t o_f = o_h2 + al(sizeof(BLSVM_H2_FLAT));
-    size_t o_s = o_f + al(sizeof(BLSVM_FEXP_FLAT));
+    size_t o_sl = o_f + al(sizeof(BLSVM_FEXP_FLAT));
+    size_t o_s = o_sl + al(sizeof(BLSVM_SLOW_FLAT));
     size_t o_data = o_s + al(sizeof(BLSVM_SEG_FLAT));
     size_t o_c = o_data + al(sizeof(BLSVM_DATA));
     size_t total = o_c + al(sizeof(BLSVM_CONSTS));
@@ -364,6 +380,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
         {o_m, BLSVM_MILLER_FLAT, sizeof(BLSVM_MILLER_FLAT)}, {o_mp, BLSVM_MP_FLAT, sizeof(BLSVM_MP_FLAT)},
         {o_h2, BLSVM_H2_FLAT, sizeof(BLSVM_H2_FLAT)},
         {o_f, BLSVM_FEXP_FLAT, sizeof(BLSVM_FEXP_FLAT)},
+        {o_sl, BLSVM_SLOW_FLAT, sizeof(BLSVM_SLOW_FLAT)},
         {o_s, BLSVM_SEG_FLAT, sizeof(BLSVM_SEG_FLAT)},       {o_data, BLSVM_DATA, sizeof(BLSVM_DATA)},
         {o_c, BLSVM_CONSTS, sizeof(BLSVM_CONSTS)}};
     for (auto& p : parts) {
@@ -377,6 +394,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     c->tabs.mpflat = (const uint2*)(base + o_mp);
     c->tabs.h2flat = (const uint2*)(base + o_h2);
     c->tabs.fflat = (const uint2*)(base + o_f);
+    c->tabs.sflat = (const uint2*)(base + o_sl);
     c->tabs.segflat = (const uint2*)(base + o_s);
     c->tabs.data = (const uint16_t*)(base + o_data);
     c->tabs.consts = (const uint32_t*)(base + o_c);
@@ -423,6 +441,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     (void)hipFuncSetAttribute((const void*)blsgpu::k_msm_finish<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * blsgpu::TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_msm_finish<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * blsgpu::TEAM_BYTES);
     int rc = ensure_workspace(c, 4096);
+    if (!rc && hipEventCreateWithFlags(&c->last_event, hipEventDisableTiming) != hipSuccess) rc = fail(-EIO, "hipEventCreate failed");
     if (rc) {
         blsgpu_ctx_destroy(c);
         return rc;
@@ -441,6 +460,9 @@ BLSGPU_EXPORT void blsgpu_ctx_destroy(blsgpu_ctx* c) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_msm_part) (void)hipFree(c->d_msm_part);
     if (c->d_buckets) (void)hipFree(c->d_buckets);
+    if (c->d_degen) (void)hipFree(c->d_degen);
+    for (void* q : c->retired) (void)hipFree(q);
+    if (c->last_event) (void)hipEventDestroy(c->last_event);
     if (c->ev0) {
         for (int i = 0; i < blsgpu_ctx::TIMING_SLOTS; i++) { (void)hipEventDestroy(c->ev0[i]); (void)hipEventDestroy(c->ev1[i]); }
         delete[] c->ev0; delete[] c->ev1; delete[] c->ev_kind;
@@ -488,6 +510,16 @@ BLSGPU_EXPORT int blsgpu_ctx_reserve(blsgpu_ctx* c, size_t max_pairs) {
     return ensure_workspace(c, max_pairs);
 }
 
+// Waits for the context's enqueued work and releases the buffers that larger ones replaced.
+BLSGPU_EXPORT int blsgpu_ctx_trim(blsgpu_ctx* c) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->used && c->last_event) HIP_TRY(hipEventSynchronize(c->last_event));
+    for (void* q : c->retired) (void)hipFree(q);
+    c->retired.clear();
+    return 0;
+}
+
 // For each of `groups` groups fold its m partials down to one; the last launch
 // optionally applies the final exponentiation and writes 576 bytes per group to
 // d_out_bytes, otherwise one partial per group to d_out_partial.  Partial i of
@@ -521,35 +553,49 @@ static int reduce_chain(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_t gr
     return 0;
 }
 
-// Miller loops of `groups` runs of gsz pairs; returns the partials per group (bpg)
-static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t gsz, size_t groups, uint32_t* d_partials,
-                         hipStream_t st, size_t* bpg_out) {
-    const bool mp = use_mp(c, gsz * groups);
-    size_t bpg = mp ? (gsz + BLSVM_MP_G - 1) / BLSVM_MP_G : (gsz + MILLER_WAVES - 1) / MILLER_WAVES;
+// Miller loops of `groups` runs of gsz pairs; returns the partials per group (bpg).
+// Then k_miller_slow: it rewrites the partials of the blocks that met a degenerate pair with the
+// reference-faithful program (normally none: every wavefront leaves at once).
+constexpr unsigned SLOW_GRID = 1024;
+static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups, bool one_per_block,
+                         uint32_t* d_partials, hipStream_t st, size_t* bpg_out) {
+    const bool mp = !one_per_block && use_mp(c, gsz * groups);
+    const size_t per_block = one_per_block ? 1 : (mp ? (size_t)BLSVM_MP_G : (size_t)MILLER_WAVES);
+    size_t bpg = (gsz + per_block - 1) / per_block;
     *bpg_out = bpg;
     if (bpg * groups > 0x7FFFFFFFull) return fail(-EINVAL, "batch too large");
+    if (bpg * groups + 2 > c->degen_cap) return fail(-ENOMEM, "work list too small");
+    blsgpu::DegenList dg{c->d_degen, c->d_degen + 1, (const uint8_t*)d_inf};
+    HIP_TRY(hipMemsetAsync(c->d_degen, 0, sizeof(uint32_t), st));
     if (mp) {
         KernelTimer kt(c, st, 0);
         hipLaunchKernelGGL(blsgpu::k_miller_mp, dim3((unsigned)(bpg * groups)), dim3(64), (size_t)blsgpu::MP_TEAM_BYTES, st, c->tabs,
-                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, d_partials);
+                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, d_partials, dg);
     } else {
-        size_t lds = (size_t)MILLER_WAVES * blsgpu::TEAM_BYTES;
+        size_t lds = per_block * blsgpu::TEAM_BYTES;
         KernelTimer kt(c, st, 0);
-        hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)(bpg * groups)), dim3(MILLER_WAVES * 64), lds, st, c->tabs,
-                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, d_partials);
+        hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)(bpg * groups)), dim3((unsigned)per_block * 64), lds, st, c->tabs,
+                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, d_partials, dg);
+    }
+    HIP_TRY(hipGetLastError());
+    {
+        KernelTimer kt(c, st, 3);
+        hipLaunchKernelGGL(blsgpu::k_miller_slow, dim3(SLOW_GRID), dim3(64), (size_t)blsgpu::SLOW_TEAM_BYTES, st, c->tabs,
+                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, (uint32_t)per_block, d_partials, dg);
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // Miller loops + per-group product; final exponentiation iff d_out_bytes
-static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t gsz, size_t groups, uint32_t* d_out_partial,
-                           void* d_out_bytes, hipStream_t st) {
+static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups,
+                           uint32_t* d_out_partial, void* d_out_bytes, hipStream_t st) {
     constexpr size_t MAX_GROUPS = 32768;               // groups ride on gridDim.y: larger batches go in slices
     if (groups > MAX_GROUPS) {
         for (size_t g0 = 0; g0 < groups; g0 += MAX_GROUPS) {
             const size_t gn = groups - g0 < MAX_GROUPS ? groups - g0 : MAX_GROUPS;
-            int rc = grouped_pairing(c, (const char*)d_g1 + g0 * gsz * BLSGPU_G1_BYTES, (const char*)d_g2 + g0 * gsz * BLSGPU_G2_BYTES, gsz,
+            int rc = grouped_pairing(c, (const char*)d_g1 + g0 * gsz * BLSGPU_G1_BYTES, (const char*)d_g2 + g0 * gsz * BLSGPU_G2_BYTES,
+                                     d_inf ? (const char*)d_inf + g0 * gsz * 2 : nullptr, gsz,
                                      gn, d_out_partial ? d_out_partial + g0 * 144 : nullptr,
                                      d_out_bytes ? (char*)d_out_bytes + g0 * BLSGPU_FQ12_BYTES : nullptr, st);
             if (rc) return rc;
@@ -563,25 +609,26 @@ static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, si
     }
     size_t bpg = 0;
     if (gsz > 0) {
-        int rc = launch_miller(c, d_g1, d_g2, gsz, groups, c->d_part[0], st, &bpg);
+        int rc = launch_miller(c, d_g1, d_g2, d_inf, gsz, groups, false, c->d_part[0], st, &bpg);
         if (rc) return rc;
     }
     return reduce_chain(c, c->d_part[0], bpg, groups, 1, bpg, d_out_bytes != nullptr, d_out_partial, d_out_bytes, st);
 }
 
-BLSGPU_EXPORT int blsgpu_miller_product_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t n, void* d_partial,
-                              void* stream) {
-    return blsgpu_miller_product_batch_dev(c, d_g1, d_g2, n, 1, d_partial, stream);
+BLSGPU_EXPORT int blsgpu_miller_product_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t n,
+                              void* d_partial, void* stream) {
+    return blsgpu_miller_product_batch_dev(c, d_g1, d_g2, d_inf, n, 1, d_partial, stream);
 }
 
-BLSGPU_EXPORT int blsgpu_miller_product_batch_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t gsz, size_t groups,
-                                                  void* d_partials, void* stream) {
+BLSGPU_EXPORT int blsgpu_miller_product_batch_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz,
+                                                  size_t groups, void* d_partials, void* stream) {
     if (!c || (groups && !d_partials)) return fail(-EINVAL, "NULL argument");
     if (groups == 0) return 0;
     if (gsz > 0 && (!d_g1 || !d_g2)) return fail(-EINVAL, "NULL point buffer");
     if (gsz > 0xFFFFFFF0ull || gsz * groups > 0xFFFFFFF0ull) return fail(-EINVAL, "batch too large");
     HIP_TRY(hipSetDevice(c->device));
-    return grouped_pairing(c, d_g1, d_g2, gsz, groups, (uint32_t*)d_partials, nullptr, (hipStream_t)stream);
+    StreamGuard sg(c, (hipStream_t)stream);
+    return grouped_pairing(c, d_g1, d_g2, d_inf, gsz, groups, (uint32_t*)d_partials, nullptr, (hipStream_t)stream);
 }
 
 BLSGPU_EXPORT int blsgpu_final_exp_product_dev(blsgpu_ctx* c, const void* d_partials, size_t m, void* d_out, void* stream) {
@@ -596,6 +643,7 @@ BLSGPU_EXPORT int blsgpu_final_exp_product_batch_dev(blsgpu_ctx* c, const void* 
     if (groups == 0) return 0;
     if (m > 0 && !d_partials) return fail(-EINVAL, "NULL partials");
     HIP_TRY(hipSetDevice(c->device));
+    StreamGuard sg(c, (hipStream_t)stream);
     if (((m + REDUCE_PER_BLOCK - 1) / REDUCE_PER_BLOCK) * groups + 1 > c->part_cap) {
         int rc = ensure_workspace(c, m * groups * MILLER_WAVES);
         if (rc) return rc;
@@ -603,36 +651,93 @@ BLSGPU_EXPORT int blsgpu_final_exp_product_batch_dev(blsgpu_ctx* c, const void* 
     return reduce_chain(c, (const uint32_t*)d_partials, m, groups, groups, 1, true, nullptr, d_out, (hipStream_t)stream);
 }
 
-BLSGPU_EXPORT int blsgpu_pairing_multi_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t n, void* d_out,
-                             void* stream) {
+BLSGPU_EXPORT int blsgpu_pairing_multi_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t n,
+                             void* d_out, void* stream) {
     if (!c || !d_out) return fail(-EINVAL, "NULL argument");
     if (n > 0 && (!d_g1 || !d_g2)) return fail(-EINVAL, "NULL point buffer");
     if (n > 0xFFFFFFF0ull) return fail(-EINVAL, "n too large");
     HIP_TRY(hipSetDevice(c->device));
-    return grouped_pairing(c, d_g1, d_g2, n, 1, nullptr, d_out, (hipStream_t)stream);
+    StreamGuard sg(c, (hipStream_t)stream);
+    return grouped_pairing(c, d_g1, d_g2, d_inf, n, 1, nullptr, d_out, (hipStream_t)stream);
 }
 
-BLSGPU_EXPORT int blsgpu_pairing_multi(blsgpu_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t out[576]) {
+BLSGPU_EXPORT int blsgpu_pairing_multi(blsgpu_ctx* c, const uint8_t* g1, const uint8_t* g2, const uint8_t* inf, size_t n,
+                                       uint8_t out[576]) {
     if (!c || !out) return fail(-EINVAL, "NULL argument");
     if (n > 0 && (!g1 || !g2)) return fail(-EINVAL, "NULL point buffer");
     HIP_TRY(hipSetDevice(c->device));
-    size_t need = n * (BLSGPU_G1_BYTES + BLSGPU_G2_BYTES);
-    if (need > c->io_cap) {
-        if (c->d_io) (void)hipFree(c->d_io);
-        c->d_io = nullptr;
-        c->io_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_io, need));
-        c->io_cap = need;
-    }
+    size_t need = n * (BLSGPU_G1_BYTES + BLSGPU_G2_BYTES + 2);
+    if (int rc_ = grow_buffer(c, &c->d_io, &c->io_cap, need)) return rc_;
     char* d1 = (char*)c->d_io;
     char* d2 = d1 + n * BLSGPU_G1_BYTES;
+    char* di = d2 + n * BLSGPU_G2_BYTES;
     if (n) {
         HIP_TRY(hipMemcpyAsync(d1, g1, n * BLSGPU_G1_BYTES, hipMemcpyHostToDevice, 0));
         HIP_TRY(hipMemcpyAsync(d2, g2, n * BLSGPU_G2_BYTES, hipMemcpyHostToDevice, 0));
+        if (inf) HIP_TRY(hipMemcpyAsync(di, inf, n * 2, hipMemcpyHostToDevice, 0));
     }
-    int rc = blsgpu_pairing_multi_dev(c, d1, d2, n, c->d_out, nullptr);
+    int rc = blsgpu_pairing_multi_dev(c, d1, d2, inf ? di : nullptr, n, c->d_out, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, c->d_out, BLSGPU_FQ12_BYTES, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// fq_miller_loop (fields_t.py:1091-1111) of every pair: n x 576 bytes, the reference's own
+// Miller values (not multiples of them).
+BLSGPU_EXPORT int blsgpu_miller_loop_batch_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t n,
+                                               void* d_out, void* stream) {
+    if (!c || (n && (!d_g1 || !d_g2 || !d_out))) return fail(-EINVAL, "NULL argument");
+    if (n == 0) return 0;
+    if (n > 0x7FFFFFF0ull) return fail(-EINVAL, "n too large");
+    HIP_TRY(hipSetDevice(c->device));
+    StreamGuard sg(c, (hipStream_t)stream);
+    const unsigned grid = (unsigned)(n < 16384 ? n : 16384);
+    hipLaunchKernelGGL(blsgpu::k_miller_exact, dim3(grid), dim3(64), (size_t)blsgpu::SLOW_TEAM_BYTES, (hipStream_t)stream, c->tabs,
+                       (const uint32_t*)d_g1, (const uint32_t*)d_g2, (const uint8_t*)d_inf, (uint32_t)n, (uint32_t*)d_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+BLSGPU_EXPORT int blsgpu_miller_loop_batch(blsgpu_ctx* c, const uint8_t* g1, const uint8_t* g2, const uint8_t* inf, size_t n,
+                                           uint8_t* out) {
+    if (!c || (n && (!g1 || !g2 || !out))) return fail(-EINVAL, "NULL argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t need = n * (BLSGPU_G1_BYTES + BLSGPU_G2_BYTES + BLSGPU_FQ12_BYTES + 2) + 64;
+    if (int rc_ = grow_buffer(c, &c->d_io, &c->io_cap, need)) return rc_;
+    char* dout = (char*)c->d_io;
+    char* d1 = dout + n * BLSGPU_FQ12_BYTES;
+    char* d2 = d1 + n * BLSGPU_G1_BYTES;
+    char* di = d2 + n * BLSGPU_G2_BYTES;
+    HIP_TRY(hipMemcpyAsync(d1, g1, n * BLSGPU_G1_BYTES, hipMemcpyHostToDevice, 0));
+    HIP_TRY(hipMemcpyAsync(d2, g2, n * BLSGPU_G2_BYTES, hipMemcpyHostToDevice, 0));
+    if (inf) HIP_TRY(hipMemcpyAsync(di, inf, n * 2, hipMemcpyHostToDevice, 0));
+    int rc = blsgpu_miller_loop_batch_dev(c, d1, d2, inf ? di : nullptr, n, dout, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, dout, n * BLSGPU_FQ12_BYTES, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// fq2_double_line_eval (q == NULL) / fq2_add_line_eval on n (R, [Q,] P) triples
+BLSGPU_EXPORT int blsgpu_line_eval_batch(blsgpu_ctx* c, const uint8_t* r, const uint8_t* q, const uint8_t* p, size_t n, uint8_t* out) {
+    if (!c || (n && (!r || !p || !out))) return fail(-EINVAL, "NULL argument");
+    if (n == 0) return 0;
+    if (n > 0x00FFFFF0ull) return fail(-EINVAL, "n too large");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t need = n * (2 * BLSGPU_G2_BYTES + BLSGPU_G1_BYTES + BLSGPU_FQ12_BYTES) + 64;
+    if (int rc_ = grow_buffer(c, &c->d_io, &c->io_cap, need)) return rc_;
+    StreamGuard sg(c, nullptr);
+    char* dout = (char*)c->d_io;
+    char* dr = dout + n * BLSGPU_FQ12_BYTES;
+    char* dq = dr + n * BLSGPU_G2_BYTES;
+    char* dp = dq + n * BLSGPU_G2_BYTES;
+    HIP_TRY(hipMemcpyAsync(dr, r, n * BLSGPU_G2_BYTES, hipMemcpyHostToDevice, 0));
+    if (q) HIP_TRY(hipMemcpyAsync(dq, q, n * BLSGPU_G2_BYTES, hipMemcpyHostToDevice, 0));
+    HIP_TRY(hipMemcpyAsync(dp, p, n * BLSGPU_G1_BYTES, hipMemcpyHostToDevice, 0));
+    const unsigned grid = (unsigned)(n < 16384 ? n : 16384);
+    hipLaunchKernelGGL(blsgpu::k_line_eval, dim3(grid), dim3(64), (size_t)blsgpu::SLOW_TEAM_BYTES, 0, c->tabs, (const uint32_t*)dr,
+                       q ? (const uint32_t*)dq : (const uint32_t*)nullptr, (const uint32_t*)dp, (uint32_t)n, (uint32_t*)dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, n * BLSGPU_FQ12_BYTES, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -642,15 +747,10 @@ BLSGPU_EXPORT int blsgpu_final_exp_batch(blsgpu_ctx* c, const uint8_t* in, size_
     if (m == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
     size_t need = m * 576 * 2 + 64;
-    if (need > c->io_cap) {
-        if (c->d_io) (void)hipFree(c->d_io);
-        c->d_io = nullptr;
-        c->io_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_io, need));
-        c->io_cap = need;
-    }
+    if (int rc_ = grow_buffer(c, &c->d_io, &c->io_cap, need)) return rc_;
     int rc = ensure_workspace(c, m * MILLER_WAVES);
     if (rc) return rc;
+    StreamGuard sg(c, nullptr);
     char* din = (char*)c->d_io;
     char* dout = din + m * 576;
     HIP_TRY(hipMemcpy(din, in, m * 576, hipMemcpyHostToDevice));
@@ -673,8 +773,8 @@ BLSGPU_EXPORT int blsgpu_final_exp(blsgpu_ctx* c, const uint8_t in[576], uint8_t
 // `groups` independent multi-pairings of gsz pairs each (pairs stored group after
 // group): out[g] = fq_ate_pairing_multi of group g.  One wavefront per pair for
 // the Miller loops, one wavefront per group for product + final exponentiation.
-BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, size_t gsz, size_t groups,
-                                                 void* d_out, void* stream) {
+BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz,
+                                                 size_t groups, void* d_out, void* stream) {
     if (!c || (groups && !d_out)) return fail(-EINVAL, "NULL argument");
     if (groups == 0) return 0;
     size_t n = gsz * groups;
@@ -682,15 +782,15 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1
     if (n > 0x3FFFFFF0ull) return fail(-EINVAL, "batch too large");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
-    if (gsz >= BATCH_TREE_MIN_GROUP) return grouped_pairing(c, d_g1, d_g2, gsz, groups, nullptr, d_out, st);
+    StreamGuard sg(c, st);
+    if (gsz >= BATCH_TREE_MIN_GROUP) return grouped_pairing(c, d_g1, d_g2, d_inf, gsz, groups, nullptr, d_out, st);
     int rc = ensure_workspace(c, (n + 1) * MILLER_WAVES);      // one partial per PAIR here
     if (rc) return rc;
     if (n) {
-        KernelTimer kt(c, st, 0);
-        hipLaunchKernelGGL(blsgpu::k_miller, dim3((unsigned)n), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs,
-                           (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n, (uint32_t)n, c->d_part[0]);
+        size_t bpg = 0;
+        rc = launch_miller(c, d_g1, d_g2, d_inf, n, 1, true, c->d_part[0], st, &bpg);
+        if (rc) return rc;
     }
-    HIP_TRY(hipGetLastError());
     size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
     unsigned blocks = (unsigned)((groups + REDUCE_WAVES - 1) / REDUCE_WAVES);
     {
@@ -702,29 +802,25 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1
     return 0;
 }
 
-BLSGPU_EXPORT int blsgpu_pairing_multi_batch(blsgpu_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t gsz, size_t groups,
-                                             uint8_t* out) {
+BLSGPU_EXPORT int blsgpu_pairing_multi_batch(blsgpu_ctx* c, const uint8_t* g1, const uint8_t* g2, const uint8_t* inf, size_t gsz,
+                                             size_t groups, uint8_t* out) {
     if (!c || (groups && !out)) return fail(-EINVAL, "NULL argument");
     if (groups == 0) return 0;
     size_t n = gsz * groups;
     if (n && (!g1 || !g2)) return fail(-EINVAL, "NULL point buffer");
     HIP_TRY(hipSetDevice(c->device));
-    size_t need = n * (BLSGPU_G1_BYTES + BLSGPU_G2_BYTES) + groups * 576 + 64;
-    if (need > c->io_cap) {
-        if (c->d_io) (void)hipFree(c->d_io);
-        c->d_io = nullptr;
-        c->io_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_io, need));
-        c->io_cap = need;
-    }
+    size_t need = n * (BLSGPU_G1_BYTES + BLSGPU_G2_BYTES + 2) + groups * 576 + 64;
+    if (int rc_ = grow_buffer(c, &c->d_io, &c->io_cap, need)) return rc_;
     char* d1 = (char*)c->d_io;
     char* d2 = d1 + n * BLSGPU_G1_BYTES;
     char* dout = d2 + n * BLSGPU_G2_BYTES;
+    char* di = dout + groups * 576;
     if (n) {
         HIP_TRY(hipMemcpyAsync(d1, g1, n * BLSGPU_G1_BYTES, hipMemcpyHostToDevice, 0));
         HIP_TRY(hipMemcpyAsync(d2, g2, n * BLSGPU_G2_BYTES, hipMemcpyHostToDevice, 0));
+        if (inf) HIP_TRY(hipMemcpyAsync(di, inf, n * 2, hipMemcpyHostToDevice, 0));
     }
-    int rc = blsgpu_pairing_multi_batch_dev(c, d1, d2, gsz, groups, dout, nullptr);
+    int rc = blsgpu_pairing_multi_batch_dev(c, d1, d2, inf ? di : nullptr, gsz, groups, dout, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, dout, groups * 576, hipMemcpyDeviceToHost));
     return 0;
@@ -758,15 +854,10 @@ BLSGPU_EXPORT int blsgpu_g2_msm_dev(blsgpu_ctx* c, const void* d_pts, const void
 static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out, hipStream_t st, bool from_hashes) {
     if (n == 0) return 0;
     if (n > 0x03FFFFF0ull) return fail(-EINVAL, "batch too large");
+    StreamGuard sg(c, st);
     const size_t teams = (2 * n + BLSVM_H1_NE - 1) / BLSVM_H1_NE;
     size_t need = teams * blsgpu::H1_IMG * 12 + (from_hashes ? n * 64 : 0);     // stage image (+ digests), u32
-    if (need > c->msm_part_cap) {
-        if (c->d_msm_part) (void)hipFree(c->d_msm_part);
-        c->d_msm_part = nullptr;
-        c->msm_part_cap = 0;
-        HIP_TRY(hipMalloc((void**)&c->d_msm_part, need * sizeof(uint32_t)));
-        c->msm_part_cap = need;
-    }
+    if (int rc_ = grow_elems(c, &c->d_msm_part, &c->msm_part_cap, need)) return rc_;
     uint32_t* img = c->d_msm_part;
     const size_t lds = (size_t)blsgpu::H1_TEAM_DW * 4;
     constexpr uint32_t BASE = BLSVM_H1_BASE - BLSVM_H1_STATE0, ACC = BLSVM_H1_ACC - BLSVM_H1_STATE0;
@@ -822,13 +913,7 @@ BLSGPU_EXPORT int blsgpu_hash_to_g2(blsgpu_ctx* c, const uint8_t* msg_hashes, si
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
     size_t need = n * (32 + 192) + 64;
-    if (need > c->io_cap) {
-        if (c->d_io) (void)hipFree(c->d_io);
-        c->d_io = nullptr;
-        c->io_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_io, need));
-        c->io_cap = need;
-    }
+    if (int rc_ = grow_buffer(c, &c->d_io, &c->io_cap, need)) return rc_;
     char* din = (char*)c->d_io;
     char* dout = din + ((n * 32 + 63) & ~(size_t)63);
     HIP_TRY(hipMemcpy(din, msg_hashes, n * 32, hipMemcpyHostToDevice));
@@ -843,13 +928,7 @@ BLSGPU_EXPORT int blsgpu_map_to_g2(blsgpu_ctx* c, const uint8_t* t, size_t n, ui
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
     size_t need = n * 192 * 2 + 64;
-    if (need > c->io_cap) {
-        if (c->d_io) (void)hipFree(c->d_io);
-        c->d_io = nullptr;
-        c->io_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_io, need));
-        c->io_cap = need;
-    }
+    if (int rc_ = grow_buffer(c, &c->d_io, &c->io_cap, need)) return rc_;
     char* din = (char*)c->d_io;
     char* dout = din + n * 192;
     HIP_TRY(hipMemcpy(din, t, n * 192, hipMemcpyHostToDevice));

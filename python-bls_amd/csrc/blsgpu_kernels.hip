@@ -33,6 +33,7 @@ struct VmTables {
     const uint2* mpflat;      // Miller loop, BLSVM_MP_G pairs per team
     const uint2* h2flat;      // hash to G2: sum + cofactor clearing
     const uint2* fflat;       // final exponentiation
+    const uint2* sflat;       // reference-faithful Miller loop (vmgen/slow_programs.py)
     const uint2* segflat;     // directly called segments (BLSVM_SEGF_*)
     const uint16_t* data;
     const uint32_t* consts;   // BLSVM_NCONST x 12 limbs
@@ -137,10 +138,14 @@ BLSGPU_DPP_ABSORB(0xAA, "[2,2,2,2]")       // lane 0 += lane 2
 // the inversion and sign code is left out of the kernel.
 // (in the multi-pair Miller programs kinds 2 / 3 are SAVE / RESTORE: the 12-slot window at
 // slot K of the round header <-> `stash`, three registers per lane -- programs.MPLayout.)
-template <bool LIGHT = false>
-__device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __restrict__ seq_, uint32_t n, uint32_t base16, uint32_t lane,
-                                           uint32_t* stash = nullptr) {
-    if (n == 0) return;
+// CHK: a wave-uniform test made once, after the first `check_at` rounds (the Miller kernels look
+// at the on-curve residual their first segment leaves); a false result ends the walk there and
+// is returned.  One call site instead of two keeps a single copy of the interpreter per program.
+struct NoCheck { __device__ __forceinline__ bool operator()() const { return true; } };
+template <bool LIGHT = false, class CHK = NoCheck>
+__device__ __forceinline__ bool run_rounds(const VmTables& T, const uint2* __restrict__ seq_, uint32_t n, uint32_t base16, uint32_t lane,
+                                           uint32_t* stash = nullptr, uint32_t check_at = 0xFFFFFFFFu, CHK chk = CHK()) {
+    if (n == 0) return true;
     gptr_u2 seq = (gptr_u2)seq_;
     gptr_u16 gdata = (gptr_u16)T.data;
     uint2 h0 = ld2(seq, 0);
@@ -327,13 +332,16 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
         // from the prefetch buffer to the current one (8 x 64 bit per round)
         uint2 nb[LIN_CHUNKS];
         while (true) {
+            if (i == check_at && !chk()) return false;
             round(nx, nb);
             if (i >= n) break;
+            if (i == check_at && !chk()) return false;
             round(nb, nx);
             if (i >= n) break;
         }
     } else {
         while (i < n) {
+            if (i == check_at && !chk()) return false;
             uint2 ch[LIN_CHUNKS];
 #pragma unroll
             for (int c = 0; c < LIN_CHUNKS; c++) ch[c] = nx[c];
@@ -344,6 +352,7 @@ __device__ __forceinline__ void run_rounds(const VmTables& T, const uint2* __res
     if (T.stamps && blockIdx.x == 0 && threadIdx.x == 0)
         for (int k2 = 0; k2 < 3; k2++) { atomicAdd(&T.stamps[k2], st_acc[k2]); atomicAdd(&T.stamps[3 + k2], st_cnt[k2]); atomicAdd(&T.stamps[6 + k2], st_lin[k2]); }
 #endif
+    return true;
 }
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
@@ -359,6 +368,56 @@ __device__ __forceinline__ void team_set_acc(uint32_t* team, uint32_t lane, bool
         if (one && i < 12) v = team[BLSVM_SLOT_C_ONE * 12 + i];
         team[F_DW + i] = v;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Degenerate pairs.  The fast Miller programs equal the reference only while (a) Q is a point
+// of the twist (the projective formulas use the curve equation, the reference's affine ones do
+// not), (b) no step of the loop degenerates -- then the reference's 0^-1 := 0 and the branches
+// of fq2_add_line_eval / fq2_add_points decide (fields_t.py:47-55, 1062-1065, 673-686) -- and
+// (c) Q carries no infinity flag (:676-677).  (b) is exactly "the final projective Z is not
+// zero": Z' = 8 Y^3 Z in a tangent step, Z' = Z (X - xq Z)^3 in a chord step, zero is
+// absorbing.  A team that sees any of the three puts its BLOCK on a work list, and
+// k_miller_slow recomputes that block's partial with the reference-faithful program.
+struct DegenList {
+    uint32_t* count;          // entries used (zeroed before every Miller launch)
+    uint32_t* blocks;         // block indices
+    const uint8_t* inf;       // n x 2 flags (P, Q) as in fq_ate_pairing_multi's tuples, or nullptr
+};
+
+// wave-uniform: bit i set iff slot (slot0 + i) holds a value != 0 mod q   (i < n <= 64; relaxed values)
+__device__ __forceinline__ uint64_t slots_nonzero(uint32_t base16, uint32_t slot0, uint32_t n, uint32_t lane) {
+    bool nz = false;
+    if (lane < n) {
+        uint32_t X[12];
+        lds_load12(X, base16 + (slot0 + lane) * 3);
+        bls::fq_canon(X);
+        nz = !bls::fq_is_zero(X);
+    }
+    return __ballot(nz);
+}
+__device__ __forceinline__ bool q_flagged(const DegenList& dg, size_t pair) {
+    return dg.inf != nullptr && dg.inf[2 * pair + 1] != 0;
+}
+__device__ __forceinline__ void degen_push(const DegenList& dg, uint32_t lane) {
+    if (lane == 0) {
+        uint32_t at = atomicAdd(dg.count, 1u);
+        dg.blocks[at] = blockIdx.x;
+    }
+}
+
+// One pair (raw values already in the PX.. slots of the single-pair layout) through the fast
+// single-pair program.  Returns false -- accumulator undefined -- when the pair is degenerate.
+struct OnCurveCheck {                       // the n residual slots from slot0 are all zero
+    uint32_t base16, slot0, n, lane;
+    __device__ __forceinline__ bool operator()() const { return slots_nonzero(base16, slot0, n, lane) == 0; }
+};
+__device__ __forceinline__ bool miller_single(const VmTables& T, uint32_t base16, uint32_t lane, bool qflag) {
+    if (qflag) return false;
+    const OnCurveCheck chk{base16, BLSVM_SLOT_REG0 + 1, 2, lane};
+    if (!run_rounds<true>(T, T.mflat, BLSVM_MILLER_FLAT_LEN, base16, lane, nullptr, BLSVM_MILLER_INIT_LEN, chk)) return false;
+    wave_fence();
+    return slots_nonzero(base16, BLSVM_SLOT_TX + 4, 2, lane) != 0;                                // final Z != 0
 }
 
 // In-workgroup product tree over the teams' accumulators; on return team 0's
@@ -394,8 +453,9 @@ __device__ __forceinline__ void wg_product_tree(const VmTables& T, uint32_t* sme
 // group b / bpg and never mixes groups (bpg = blocks per group), so partials
 // [g * bpg, (g + 1) * bpg) belong to group g.  A single multi-pairing is one group.
 __global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
-                                                uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials) {
+                                                uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials, DegenList dg) {
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
+    __shared__ uint32_t any_degen;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nwaves = blockDim.x >> 6;
@@ -404,7 +464,9 @@ __global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, c
     const size_t pair = (size_t)grp * gsz + in_grp;
     uint32_t* team = smem + wave * TEAM_DW;
     const uint32_t base16 = wave * (TEAM_BYTES / 16);
+    if (threadIdx.x == 0) any_degen = 0;
     team_init_consts(T, team, lane);
+    bool ok = true;
     if (in_grp < gsz) {
         // coalesced load of the 72 big-endian dwords of the pair
         uint32_t w0, w1 = 0;
@@ -413,8 +475,6 @@ __global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, c
             w0 = (d < 24) ? g1[pair * 24 + d] : g2[pair * 48 + (d - 24)];
             if (lane < 8) w1 = g2[pair * 48 + (lane + 40)];
         }
-        uint64_t nz0 = __ballot(w0 != 0);
-        uint64_t nz1 = __ballot(lane < 8 && w1 != 0);
         {
             uint32_t d = lane, e = d / 12, w = d % 12;
             team[(BLSVM_SLOT_PX + e) * 12 + (11 - w)] = bswap32(w0);
@@ -423,26 +483,21 @@ __global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, c
                 team[(BLSVM_SLOT_PX + e) * 12 + (11 - w)] = bswap32(w1);
             }
         }
-        const bool p_zero = (nz0 & 0xFFFFFFull) == 0;
-        const bool py_zero = (nz0 & 0xFFF000ull) == 0;
-        const bool q_zero = (nz0 >> 24) == 0 && nz1 == 0;
         wave_fence();
-        if (q_zero) {
-            team_set_acc(team, lane, !py_zero);
-        } else if (p_zero) {
-            team_set_acc(team, lane, true);
-        } else {
-            run_rounds<true>(T, T.mflat, BLSVM_MILLER_FLAT_LEN, base16, lane);
-        }
+        ok = miller_single(T, base16, lane, q_flagged(dg, pair));
     } else {
         wave_fence();
-        team_set_acc(team, lane, true);
     }
+    if (!ok || in_grp >= gsz) team_set_acc(team, lane, true);
+    __syncthreads();
+    if (!ok && lane == 0) any_degen = 1;
     wave_fence();
     wg_product_tree(T, smem, wave, nwaves, lane);
     if (wave == 0) {
         wave_fence();
+        // (a listed block's partial is rewritten by k_miller_slow before anything reads it)
         for (uint32_t i = lane; i < 144; i += 64) partials[(size_t)blockIdx.x * 144 + i] = team[F_DW + i];
+        if (any_degen) degen_push(dg, lane);
     }
 }
 
@@ -466,20 +521,9 @@ __device__ __forceinline__ void load_pair_raw(uint32_t* team, uint32_t p_slot, u
         team[slot * 12 + (11 - k)] = bswap32(w);
     }
 }
-// bit0: P == (0,0); bit1: P.y == 0; bit2: Q == (0,0)   (wave-uniform result)
-__device__ __forceinline__ uint32_t pair_flags(const uint32_t* team, uint32_t p_slot, uint32_t q_slot, uint32_t lane) {
-    uint32_t vp = (lane < 24) ? team[p_slot * 12 + lane] : 0u;     // 24 dwords of P
-    uint32_t vq = (lane < 48) ? team[q_slot * 12 + lane] : 0u;     // 48 dwords of Q
-    uint64_t nzp = __ballot(vp != 0), nzq = __ballot(vq != 0);
-    uint32_t f = 0;
-    if (nzp == 0) f |= 1u;
-    if ((nzp & 0xFFF000ull) == 0) f |= 2u;
-    if (nzq == 0) f |= 4u;
-    return f;
-}
 
 __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
-                                                     uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials) {
+                                                     uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials, DegenList dg) {
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t grp = blockIdx.x / bpg;                       // groups as in k_miller
@@ -488,25 +532,39 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
     const uint32_t cnt = min((uint32_t)BLSVM_MP_G, gsz - in_grp);
     team_init_consts(T, team, lane);
     wave_fence();
-    // the multi-pair programs have their own scratchpad layout (vmgen/programs.MPLayout)
-    uint32_t special = (cnt < (uint32_t)BLSVM_MP_G) ? 1u : 0u;
-    for (uint32_t g = 0; g < cnt; ++g) {
-        load_pair_raw(team, BLSVM_MP_CORE + 14u * g, BLSVM_MP_Q + 4u * g, g1, g2, first + g, lane);
-        wave_fence();
-        special |= pair_flags(team, BLSVM_MP_CORE + 14u * g, BLSVM_MP_Q + 4u * g, lane);
-    }
-    if (!special) {
-        uint32_t stash[3] = {0u, 0u, 0u};                        // Q of the team's pairs between the chord steps
-        run_rounds<true>(T, T.mpflat, BLSVM_MP_FLAT_LEN, 0, lane, stash);
-    } else {
-        bool have = false;
+    bool ok = true;
+    uint32_t f_dw = (uint32_t)(BLSVM_MP_F * 12);
+    if (cnt == (uint32_t)BLSVM_MP_G) {
+        // the multi-pair programs have their own scratchpad layout (vmgen/programs.MPLayout)
         for (uint32_t g = 0; g < cnt; ++g) {
+            load_pair_raw(team, BLSVM_MP_CORE + 14u * g, BLSVM_MP_Q + 4u * g, g1, g2, first + g, lane);
+            ok = ok && !q_flagged(dg, first + g);
+        }
+        wave_fence();
+        uint32_t stash[3] = {0u, 0u, 0u};                        // Q of the team's pairs between the chord steps
+        const OnCurveCheck chk{0u, BLSVM_MP_F + 1, 2 * BLSVM_MP_G, lane};                // every Q on the twist
+        if (ok) ok = run_rounds<true>(T, T.mpflat, BLSVM_MP_FLAT_LEN, 0, lane, stash, BLSVM_MP_INIT_LEN, chk);
+        if (ok) {
+            wave_fence();
+            // final Z of pair g in slots CORE + 14 g + 6, + 7: zero iff both are
+            bool nz = false;
+            if (lane < 2u * BLSVM_MP_G) {
+                uint32_t X[12];
+                lds_load12(X, (BLSVM_MP_CORE + 14u * (lane >> 1) + 6u + (lane & 1u)) * 3u);
+                bls::fq_canon(X);
+                nz = !bls::fq_is_zero(X);
+            }
+            const uint64_t m = __ballot(nz);
+            for (uint32_t g = 0; g < (uint32_t)BLSVM_MP_G; ++g) ok = ok && ((m >> (2u * g)) & 3ull) != 0;
+        }
+    } else {
+        // ragged last team of a group: its pairs one by one through the single-pair program
+        f_dw = (uint32_t)F_DW;
+        bool have = false;
+        for (uint32_t g = 0; g < cnt && ok; ++g) {
             load_pair_raw(team, BLSVM_SLOT_PX, BLSVM_SLOT_QX0, g1, g2, first + g, lane);
             wave_fence();
-            const uint32_t fl = pair_flags(team, BLSVM_SLOT_PX, BLSVM_SLOT_QX0, lane);
-            if (fl & 4u) team_set_acc(team, lane, !(fl & 2u));
-            else if (fl & 1u) team_set_acc(team, lane, true);
-            else run_rounds<true>(T, T.mflat, BLSVM_MILLER_FLAT_LEN, 0, lane);
+            ok = miller_single(T, 0, lane, q_flagged(dg, first + g));
             wave_fence();
             if (have) run_rounds<true>(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, 0, lane);
             run_rounds<true>(T, T.segflat + BLSVM_SEGF_COPY_1_0_OFF, BLSVM_SEGF_COPY_1_0_LEN, 0, lane);
@@ -515,8 +573,103 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
         if (!have) team_set_acc(team, lane, true);
     }
     wave_fence();
-    const uint32_t f_dw = special ? (uint32_t)F_DW : (uint32_t)(BLSVM_MP_F * 12);
     for (uint32_t i = lane; i < 144; i += 64) partials[(size_t)blockIdx.x * 144 + i] = team[f_dw + i];
+    if (!ok) degen_push(dg, lane);                               // k_miller_slow rewrites this partial
+}
+
+// ---------------------------------------------------------------------------
+// The reference-faithful Miller loop for one pair (vmgen/slow_programs.py): affine twist point,
+// one field inversion per step with 0^-1 := 0, the reference's branches as 0/1 selections.
+// Leaves fq_miller_loop(P, Q) itself (fields_t.py:1091-1111; Montgomery form) in register 0.
+constexpr int SLOW_TEAM_BYTES = BLSVM_SLOW_SLOTS * 48;
+__device__ __forceinline__ void miller_exact_one(const VmTables& T, uint32_t* team, uint32_t lane, const uint32_t* __restrict__ g1,
+                                                 const uint32_t* __restrict__ g2, const uint8_t* __restrict__ inf, size_t pair) {
+    load_pair_raw(team, BLSVM_SLOT_PX, BLSVM_SLOT_QX0, g1, g2, pair, lane);
+    const bool qf = inf != nullptr && inf[2 * pair + 1] != 0;
+    if (lane < 12) team[BLSVM_SLOT_QINF * 12 + lane] = qf ? team[BLSVM_SLOT_C_ONE * 12 + lane] : 0u;
+    wave_fence();
+    run_rounds(T, T.sflat, BLSVM_SLOW_FLAT_LEN, 0, lane);
+    wave_fence();
+}
+
+// Rewrites the partials of the blocks a Miller kernel listed: block b held the pairs
+// [grp * gsz + (b - grp * bpg) * per_block, ... + per_block) clipped to its group.  One
+// wavefront per listed block; every wavefront leaves the loop at the same bound.
+__global__ void __launch_bounds__(64) k_miller_slow(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+                                                    uint32_t gsz, uint32_t bpg, uint32_t per_block, uint32_t* __restrict__ partials,
+                                                    DegenList dg) {
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
+    if (blockIdx.x >= total) return;
+    team_init_consts(T, team, lane);
+    for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
+        const uint32_t b = __builtin_amdgcn_readfirstlane(dg.blocks[e]);
+        const uint32_t grp = b / bpg;
+        const uint32_t in_grp = (b - grp * bpg) * per_block;
+        const uint32_t cnt = min(per_block, gsz - in_grp);
+        const size_t first = (size_t)grp * gsz + in_grp;
+        for (uint32_t g = 0; g < cnt; ++g) {
+            wave_fence();
+            miller_exact_one(T, team, lane, g1, g2, dg.inf, first + g);
+            if (g) run_rounds<true>(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, 0, lane);
+            run_rounds<true>(T, T.segflat + BLSVM_SEGF_COPY_1_0_OFF, BLSVM_SEGF_COPY_1_0_LEN, 0, lane);
+        }
+        wave_fence();
+        for (uint32_t i = lane; i < 144; i += 64) partials[(size_t)b * 144 + i] = team[F_DW + i];
+    }
+}
+
+// register 0 (Montgomery, relaxed) of the team at the start of LDS -> 576 canonical big-endian bytes
+__device__ __forceinline__ void write_acc_bytes(const VmTables& T, uint32_t* team, uint32_t lane, uint32_t* __restrict__ dst) {
+    run_rounds<true>(T, T.segflat + BLSVM_SEGF_FROM_MONT_1_0_OFF, BLSVM_SEGF_FROM_MONT_1_0_LEN, 0, lane);
+    if (lane < 12) {                             // relaxed (< 2q) -> canonical residues
+        uint32_t X[12];
+        lds_load12(X, (BLSVM_SLOT_REG0 + 12 + lane) * 3);
+        bls::fq_canon(X);
+        lds_store12(X, (BLSVM_SLOT_REG0 + 12 + lane) * 3);
+    }
+    wave_fence();
+    for (uint32_t k = lane; k < 144; k += 64) {
+        uint32_t c = k / 12, w = k % 12;
+        dst[k] = bswap32(team[R1_DW + c * 12 + (11 - w)]);
+    }
+}
+
+// fq_miller_loop for every pair (blsgpu_miller_loop_batch): out[p] = 576 canonical big-endian
+// bytes of the reference's own Miller value -- not a multiple of it.
+__global__ void __launch_bounds__(64) k_miller_exact(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+                                                     const uint8_t* __restrict__ inf, uint32_t n, uint32_t* __restrict__ out_bytes) {
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    team_init_consts(T, team, lane);
+    for (uint32_t p = blockIdx.x; p < n; p += gridDim.x) {
+        wave_fence();
+        miller_exact_one(T, team, lane, g1, g2, inf, p);
+        write_acc_bytes(T, team, lane, out_bytes + (size_t)p * 144);
+    }
+}
+
+// fq2_double_line_eval(R, P) (fields_t.py:1035-1049; q == nullptr) / fq2_add_line_eval(R, Q, P)
+// (:1052-1078) for n triples: r, q n x 192 bytes, p n x 96 bytes -> n x 576 bytes.
+__global__ void __launch_bounds__(64) k_line_eval(VmTables T, const uint32_t* __restrict__ r, const uint32_t* __restrict__ q,
+                                                  const uint32_t* __restrict__ p, uint32_t n, uint32_t* __restrict__ out_bytes) {
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    team_init_consts(T, team, lane);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        wave_fence();
+        if (lane < 24) team[(BLSVM_SLOT_PX + lane / 12) * 12 + (11 - lane % 12)] = bswap32(p[(size_t)i * 24 + lane]);
+        if (lane < 48) {
+            team[(BLSVM_SLOT_TX + lane / 12) * 12 + (11 - lane % 12)] = bswap32(r[(size_t)i * 48 + lane]);
+            if (q) team[(BLSVM_SLOT_QX0 + lane / 12) * 12 + (11 - lane % 12)] = bswap32(q[(size_t)i * 48 + lane]);
+        }
+        wave_fence();
+        if (q) run_rounds(T, T.segflat + BLSVM_SEGF_LINE_ADD_OFF, BLSVM_SEGF_LINE_ADD_LEN, 0, lane);
+        else run_rounds(T, T.segflat + BLSVM_SEGF_LINE_DBL_OFF, BLSVM_SEGF_LINE_DBL_LEN, 0, lane);
+        wave_fence();
+        write_acc_bytes(T, team, lane, out_bytes + (size_t)i * 144);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -24,6 +24,7 @@ from . import h2c_programs as HP
 from . import msm_programs as MP
 from . import core
 from . import programs as P
+from . import slow_programs as SP
 from .core import LANES
 
 KIND = {"mul": 0, "lin": 1, "inv": 2, "sgn": 3}
@@ -171,7 +172,7 @@ def limbs32(v):
     return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(12)]
 
 
-DIRECT_SEGS = ["mul_0_1", "from_mont_1_0", "to_mont_0_1", "copy_1_0",     # called by name from the kernels
+DIRECT_SEGS = ["mul_0_1", "from_mont_1_0", "to_mont_0_1", "copy_1_0", "line_dbl", "line_add",     # called by name from the kernels
                "h1_a", "h1w_a", "h1_b", "h1_c", "d1_a", "d1_c", "d2_a", "d2_b", "d2_c"]
 POW_SEG = re.compile(r"^(h1_(sqr|mul)[23]|d1_(sqr|mul)|d2[pq]_(sqr|mul))$")
 MSM_NP = {1: 6, 2: 2}                                         # points per team in the MSM kernels
@@ -196,6 +197,8 @@ def build_tables(verbose=False):
     h2segs, h2lay, h2script = HP.build_h2(H2_NM, verbose=verbose)
     segs.update(h1segs)
     segs.update(h2segs)
+    slowsegs, slowscript = SP.build(verbose=verbose)
+    segs.update(slowsegs)
     d1segs, d1lay, d1script = DP.build_d1(D1_NE, verbose=verbose)
     d2segs, d2lay, d2script = DP.build_d2(D2_NE, verbose=verbose)
     segs.update(d1segs)
@@ -207,6 +210,7 @@ def build_tables(verbose=False):
     return dict(segs=segs, mscript=mscript, fscript=fscript, mpsegs=mpsegs, mpscript=mpscript, mplay=mplay, msm=msm,
                 h1=(h1segs, h1lay, h1script), h1w=(h1segs, h1lay, h1wscript), h2=(h2segs, h2lay, h2script),
                 d1=(d1segs, d1lay, d1script), d2=(d2segs, d2lay, d2script), order=order,
+                slow=(slowsegs, slowscript),
                 seg_rounds=seg_rounds, data=data)
 
 
@@ -216,8 +220,7 @@ def generate(path=None, verbose=False):
     (h1segs, h1lay, h1script), (h2segs, h2lay, h2script) = tb["h1"], tb["h2"]
     order, seg_rounds, data = tb["order"], tb["seg_rounds"], tb["data"]
     team_slots = P.TEMP0 + max(s.ntemp for n, s in segs.items()
-                               if not n.startswith("g") and not n.startswith("mp_") and not n.startswith("h")
-                               and not n.startswith("d1") and not n.startswith("d2"))
+                               if not n.startswith(("g", "mp_", "h", "d1", "d2", "slow_", "line_")))
     mplay = tb["mplay"]
     # (the kernel's fallback for special pairs runs the single-pair program in the same scratchpad)
     mp_team_slots = max(team_slots, P.mp_team_slots(mpsegs))
@@ -245,6 +248,13 @@ def generate(path=None, verbose=False):
     w("/* multi-pair scratchpad (programs.MPLayout): accumulator, pair g's PX PY at CORE + 14 g, its Q at Q + 4 g */\n")
     w("#define BLSVM_MP_F %d\n#define BLSVM_MP_CORE %d\n#define BLSVM_MP_Q %d\n" % (mplay.F, mplay.CORE, mplay.Q))
     flat("BLSVM_MP_FLAT", [r for n in mpscript for r in seg_rounds[n]])
+    w("/* rounds of the first segment: the kernels look at the on-curve residual (accumulator coefficients 1 .. 2 G) after it */\n")
+    w("#define BLSVM_MILLER_INIT_LEN %d\n#define BLSVM_MP_INIT_LEN %d\n" % (len(seg_rounds[mscript[0]]), len(seg_rounds[mpscript[0]])))
+    slowsegs, slowscript = tb["slow"]
+    w("/* the reference-faithful Miller program (vmgen/slow_programs.py): affine R in the TX/TY slots, Q's flag as 0/1 in QINF */\n")
+    w("#define BLSVM_SLOW_SLOTS %d\n#define BLSVM_SLOT_QINF %d\n" % (SP.team_slots(slowsegs), SP.QINF))
+    flat("BLSVM_SLOW_FLAT", [r for n in slowscript for r in seg_rounds[n]])
+    assert all(n.startswith("slow_") for n in slowscript)
     w("#define BLSVM_H1_NE %d\n#define BLSVM_H1_SLOTS %d\n" % (H1_NE, h1lay.TEMP0 + max(s.ntemp for s in h1segs.values())))
     w("#define BLSVM_H2_NM %d\n#define BLSVM_H2_SLOTS %d\n" % (H2_NM, HP.h2_team_slots(h2segs, h2lay)))
     w("#define BLSVM_H1_T %d\n#define BLSVM_H1_TH %d\n#define BLSVM_H1_S %d\n#define BLSVM_H2_S %d\n#define BLSVM_H2_OUT %d\n" % (h1lay.T, h1lay.TH, h1lay.S, h2lay.S, h2lay.OUT))

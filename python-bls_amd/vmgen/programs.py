@@ -28,7 +28,8 @@ NX = 0xd201000000010000                   # |x|  (fields_t.py:25)
 C_ZERO, C_ONE, C_R2, C_RAW1 = 0, 1, 2, 3
 C_K1 = 4                                  # -(2^384 - 1) mod q  (LIN complement surplus)
 C_GAM = 5                                 # gamma_i^j, i=1..3, j=1..5: Fq2 each (final exponentiation only)
-NCONST = C_GAM + 3 * 5 * 2                # 35
+C_HALF = C_GAM + 3 * 5 * 2                # 1/2 (the reference-faithful Miller program: xi^-1 = (1 - u)/2)
+NCONST = C_HALF + 1                       # 36
 # The multi-pair Miller programs never touch the gamma constants: their scratchpad
 # (MPLayout) starts right after C_K1.
 # named values
@@ -80,6 +81,7 @@ def const_table():
             g = gamma(i, j)
             k = C_GAM + ((i - 1) * 5 + (j - 1)) * 2
             c[k], c[k + 1] = to_m(g[0]), to_m(g[1])
+    c[C_HALF] = to_m((Q + 1) // 2)
     return c
 
 
@@ -244,8 +246,9 @@ def seg_init(cfg, first_add, G=1, name="init", lay=None):
     zero = b.inp(C(C_ZERO))
     slots = lay.pair if lay else PairSlots
     Fb = slots(0).F
+    assert 2 * G <= 11
     b.out(one, T(Fb))
-    for i in range(1, 12):
+    for i in range(1 + 2 * G, 12):
         b.out(zero, T(Fb + i))
     for g in range(G):
         ps = slots(g)
@@ -265,6 +268,15 @@ def seg_init(cfg, first_add, G=1, name="init", lay=None):
             b.out(px3n, T(ps.NPX3))
         Tp = ((q[0], q[1]), (q[2], q[3]), (one, b.zero()))
         Qa = ((q[0], q[1]), (q[2], q[3]))
+        # Is Q on the twist?  d = qy^2 - qx^3 - 4 xi goes where the accumulator's zero
+        # coefficients 1 + 2g, 2 + 2g would: for a point of the curve that IS a zero (possibly
+        # in its relaxed form q), and the kernel looks at it right after this segment -- the
+        # projective formulas below use the curve equation, the reference's affine ones do not,
+        # so a pair with d != 0 is handed to the reference-faithful program (slow_programs.py)
+        x3 = cfg.mul2(cfg.sqr2(Qa[0]), Qa[0])
+        yy = cfg.sqr2(Qa[1])
+        for c in range(2):
+            b.out(yy[c] - x3[c] - one * 4, T(Fb + 1 + 2 * g + c))
         # Z = (1, 0): products with the zero imaginary part vanish at trace time
         T2, ld = t_double(cfg, Tp, px3n, py)
         la = None

@@ -269,6 +269,166 @@ def gen_pairing(big):
 
 
 # --------------------------------------------------------------------------
+# --------------------------------------------------------------------------
+def gen_degenerate():
+    """Inputs on which the reference's special cases decide the result: the vertical-line
+    branch of fq2_add_line_eval (fields_t.py:1062-1065), the branches of fq2_add_points
+    (:673-686), 0^-1 := 0 (:47-55) and Q's infinity flag (:676-677).  The input points are
+    plain data (built with the repo's host integer code); every expected value is the
+    reference's own fq_miller_loop / fq_ate_pairing_multi output.
+
+    Chord steps of the loop add Q to R = kQ for k = 2, 12, 104, 53760, 230901736800256, so
+    (k+1)Q = 0 hits the vertical line and (k-1)Q = 0 the doubling inside the addition:
+      * order 13 on the twist E'(Fq2) (13^2 divides its cofactor): R = -Q at k = 12;
+      * order 3 and order 11 points of E(Fq): y^2 = x^3 + 4 taken as Fq2 coordinates --
+        off the twist, but the reference's affine formulas never use b: R = -Q at k = 2,
+        R = Q at k = 12;
+      * (x, 0), (0, y), arbitrary off-curve and zero coordinates, with and without flags."""
+    import random
+    from bls_py import bls12381 as C
+    from bls_py.ec import y_for_x
+    rng = random.Random(20261004)
+    g1, g2 = generator_Fq(), generator_Fq2()
+
+    def low_order(ec, FE, order, r):
+        while True:
+            x = FE(Q, rng.randrange(Q), rng.randrange(Q)) if FE is Fq2 else FE(Q, rng.randrange(Q))
+            try:
+                y = y_for_x(x, ec, FE)[0]
+            except ValueError:
+                continue
+            re = r
+            while order % (re * r) == 0:
+                re *= r
+            pt = (order // re) * AffinePoint(x, y, False, ec)      # the point's r-part
+            if pt.infinity:
+                continue
+            while not (r * pt).infinity:
+                pt = r * pt
+            assert pt.is_on_curve()
+            return pt
+    q13p = low_order(default_ec_twist, Fq2, C.h_twist * C.n, 13)
+    p3p = low_order(default_ec, Fq, C.h * C.n, 3)
+    p11p = low_order(default_ec, Fq, C.h * C.n, 11)
+    q13 = (q13p.x.ZT, q13p.y.ZT)
+    q13n = (q13p.x.ZT, q13p.negate().y.ZT)
+    p3, p11 = (p3p.x.Z, p3p.y.Z), (p11p.x.Z, p11p.y.Z)
+    assert p3[0] == 0
+    G1t, G2t = g1_tuple(g1), g2_tuple(g2)
+    P2, Q3 = g1_tuple(2 * g1), g2_tuple(3 * g2)
+    P5, Q7 = g1_tuple(5 * g1), g2_tuple(7 * g2)
+
+    def tq(a, flag=False):
+        return (tuple(int(c) % Q for c in a[0]), tuple(int(c) % Q for c in a[1]), flag)
+
+    def emb(p, flag=False):                         # a point of E(Fq) as Fq2 coordinates
+        return ((p[0], 0), (p[1], 0), flag)
+
+    def rq():
+        return rng.randrange(Q)
+    q13t, q3t, q11t = tq(q13), emb(p3), emb(p11)
+    off = ((rq(), rq()), (rq(), rq()), False)
+    y0 = ((rq(), rq()), (0, 0), False)
+    x0 = ((0, 0), (rq(), rq()), False)
+    zq = ((0, 0), (0, 0), False)
+    cases = {
+        "ord13": ([G1t], [q13t]),
+        "ord13_neg": ([P2], [tq(q13n)]),
+        "ord13_p_zero": ([(0, 0, False)], [q13t]),
+        "ord13_px_zero": ([(0, 2, False)], [q13t]),
+        "ord13_in_team": ([P2, G1t, P5], [Q3, q13t, Q7]),
+        "ord13_first_of_4": ([G1t, P2, P5, G1t], [q13t, Q3, Q7, G2t]),
+        "ord13_twice": ([G1t, P2], [q13t, q13t]),
+        "ord3_embedded": ([G1t], [q3t]),
+        "ord11_embedded": ([G1t], [q11t]),
+        "ord11_in_team": ([P2, P5, G1t], [Q3, Q7, q11t]),
+        "off_curve": ([G1t], [off]),
+        "off_curve_in_team": ([G1t, P2, P5], [G2t, off, Q7]),
+        "qy_zero": ([G1t], [y0]),
+        "qx_zero": ([G1t], [x0]),
+        "q_zero_px_zero": ([(0, 2, False)], [zq]),
+        "q_zero_p_order3": ([(p3[0], p3[1], False)], [zq]),
+        "p_zero_off_curve": ([(0, 0, False)], [off]),
+        "flag_on_valid": ([G1t], [(G2t[0], G2t[1], True)]),
+        "flag_in_team": ([P2, G1t, P5], [Q3, (G2t[0], G2t[1], True), Q7]),
+        "flag_on_ord13": ([G1t], [(q13t[0], q13t[1], True)]),
+        "flag_on_off_curve": ([G1t], [(off[0], off[1], True)]),
+        "pflag_only": ([(G1t[0], G1t[1], True)], [G2t]),
+        "all_kinds": ([G1t, P2, P5, G1t, P2, (0, 0, False), P5],
+                      [q13t, Q3, off, q11t, (G2t[0], G2t[1], True), Q7, y0]),
+    }
+    out = {"info": {"q13_order": 13, "twist_order_cofactor": hex(C.h_twist)}, "cases": {}}
+    for name, (Ps, Qs) in cases.items():
+        print("degenerate case", name)
+        out["cases"][name] = pair_record(Ps, Qs, with_miller=True)
+    zero, one = tup_hex(ft.FQ12_ZERO_TUPLE), tup_hex(ft.FQ12_ONE_TUPLE)
+    # what round 1's projective program got wrong: these are neither zero nor one
+    for k in ("ord13", "ord13_in_team", "ord11_embedded"):
+        assert out["cases"][k]["out"] not in (zero, one), k
+    dump("pairing_degenerate.json", out)
+
+
+def gen_lines():
+    """fq2_double_line_eval / fq2_add_line_eval (fields_t.py:1035-1078) on generic and special inputs."""
+    import random
+    rng = random.Random(7)
+    g1, g2 = generator_Fq(), generator_Fq2()
+    P = g1_tuple(5 * g1)
+    R, Qp = g2_tuple(3 * g2), g2_tuple(7 * g2)
+
+    def neg2(t):
+        return tuple((-c) % Q for c in t)
+
+    def rq():
+        return (rng.randrange(Q), rng.randrange(Q))
+    cases = {
+        "generic": (R, Qp, P),
+        "r_eq_q": (R, R, P),
+        "r_eq_neg_q": (R, (R[0], neg2(R[1]), False), P),
+        "both_negated": ((neg2(Qp[0]), neg2(Qp[1]), False), Qp, P),       # the branch of :1062-1065
+        "r_zero": (((0, 0), (0, 0), False), Qp, P),
+        "all_zero": (((0, 0), (0, 0), False), ((0, 0), (0, 0), False), (0, 0, False)),
+        "ry_zero": ((rq(), (0, 0), False), Qp, P),
+        "off_curve": ((rq(), rq(), False), (rq(), rq(), False), (rng.randrange(Q), rng.randrange(Q), False)),
+        "p_zero": (R, Qp, (0, 0, False)),
+    }
+    out = {}
+    for name, (r, qq, p) in cases.items():
+        out[name] = {"r": tup_hex(r[0]) + tup_hex(r[1]), "q": tup_hex(qq[0]) + tup_hex(qq[1]), "p": fq_hex(p[0]) + fq_hex(p[1]),
+                     "dbl": tup_hex(ft.fq2_double_line_eval(r[0], r[1], p[0], p[1])),
+                     "add": tup_hex(ft.fq2_add_line_eval(r[0], r[1], qq[0], qq[1], p[0], p[1]))}
+    dump("lines.json", out)
+
+
+def gen_seeded_digest(n=8192):
+    """SHA-256 of the reference's multi-pairing of the first n PRF-seeded pairs (SURVEY 8c F-PAIR),
+    with digests of the inputs so that a test can rebuild them from the PRF alone."""
+    g1, g2 = generator_Fq(), generator_Fq2()
+    a = [prf_scalar(b"blsgpu/a", 1, i) for i in range(n)]
+    b = [prf_scalar(b"blsgpu/b", 1, i) for i in range(n)]
+    print("scalar-multiplying", n, "pairs ...")
+    Pp = [g1_tuple(a[i] * g1) for i in range(n)]
+    Qq = [g2_tuple(b[i] * g2) for i in range(n)]
+    blob1 = b"".join(bytes.fromhex(fq_hex(p[0]) + fq_hex(p[1])) for p in Pp)
+    blob2 = b"".join(bytes.fromhex(tup_hex(q[0]) + tup_hex(q[1])) for q in Qq)
+    print("reference multi-pairing n =", n)
+    prod = ft.FQ12_ONE_TUPLE
+    for i in range(n):
+        prod = ft.fq12_mul(prod, ft.fq_miller_loop(Pp[i][0], Pp[i][1], False, Qq[i][0], Qq[i][1], False))
+        if i % 512 == 511:
+            print("  ", i + 1, flush=True)
+    res = ft.fq12_final_exp(prod)
+    e11 = ft.fq12_final_exp(ft.fq_miller_loop(*g1_tuple(g1), *g2_tuple(g2)))
+    s = sum(x * y for x, y in zip(a, b)) % N_ORDER
+    assert tuple(res) == tuple(ft.fq12_pow(e11, s))
+    dump("pairing_seeded_%d.json" % n, {
+        "n": n, "seed": 1, "out": tup_hex(res),
+        "sha256_out": hashlib.sha256(bytes.fromhex(tup_hex(res))).hexdigest(),
+        "sha256_g1": hashlib.sha256(blob1).hexdigest(), "sha256_g2": hashlib.sha256(blob2).hexdigest(),
+        "sum_ab_mod_n": hex(s)})
+
+
+
 def sig_rec(sig):
     return sig.serialize().hex()
 
@@ -513,7 +673,10 @@ if __name__ == "__main__":
     gens = {"fields": gen_fields, "pairing": lambda: gen_pairing(big),
             "verify4": gen_verify4, "scheme": gen_scheme,
             "hash": gen_hash_to_curve, "threshold": lambda: gen_threshold(big),
-            "msm": lambda: gen_msm(big), "points": gen_points}
+            "msm": lambda: gen_msm(big), "points": gen_points, "degenerate": gen_degenerate, "lines": gen_lines}
+    if "seeded8192" in only:                # opt-in: ~10 minutes of pure Python
+        gen_seeded_digest(8192)
+        only = [a for a in only if a != "seeded8192"] or ["-"]
     for name, fn in gens.items():
         if not only or name in only:
             print("==", name)

@@ -32,18 +32,164 @@ def test_small_multiples(engine, golden):
         assert engine.pairing_multi(cat(v["g1"][:n]), cat(v["g2"][:n]), n) == ref(cat(v["g1"][:n]), cat(v["g2"][:n]), n)
 
 
-# flag_on_valid: a VALID point carrying inf=True.  The reference lets Q's flag
-# skip the chord updates (fields_t.py:676-677); the C ABI carries coordinates
-# only (infinity = (0,0), fields_t.py:609-622), so that input is not expressible.
+# every edge case of the reference-generated fixture, flags included (flag_on_valid: a VALID point
+# carrying inf=True -- the reference lets Q's flag skip the chord updates, fields_t.py:676-677)
 EDGE = ["empty", "p_inf", "q_inf", "both_inf", "q_inf_py_zero", "both_inf_in_batch", "p_zero_noflag",
-        "q_zero_noflag", "mixed", "repeat", "q_and_negq", "p_and_negp"]
+        "q_zero_noflag", "flag_on_valid", "mixed", "repeat", "q_and_negq", "p_and_negp"]
+
+
+def flags(v):
+    return bytes(int(b) for pr in v["inf"] for b in pr)
 
 
 @pytest.mark.parametrize("name", EDGE)
 def test_edge_cases(engine, golden, name):
     v = golden("pairing.json")["edge"][name]
     n = len(v["g1"])
-    assert engine.pairing_multi(cat(v["g1"]), cat(v["g2"]), n).hex() == v["out"]
+    assert engine.pairing_multi(cat(v["g1"]), cat(v["g2"]), n, flags(v)).hex() == v["out"]
+    if "miller" in v:                  # blsgpu_miller_loop_batch: the reference's Miller values themselves
+        assert engine.miller_loop_batch(cat(v["g1"]), cat(v["g2"]), n, flags(v)).hex() == "".join(v["miller"])
+
+
+DEGEN = ["ord13", "ord13_neg", "ord13_p_zero", "ord13_px_zero", "ord13_in_team", "ord13_first_of_4", "ord13_twice",
+         "ord3_embedded", "ord11_embedded", "ord11_in_team", "off_curve", "off_curve_in_team", "qy_zero", "qx_zero",
+         "q_zero_px_zero", "q_zero_p_order3", "p_zero_off_curve", "flag_on_valid", "flag_in_team", "flag_on_ord13",
+         "flag_on_off_curve", "pflag_only", "all_kinds"]
+
+
+@pytest.mark.parametrize("mp", [1 << 30, 0])
+@pytest.mark.parametrize("name", DEGEN)
+def test_degenerate_pairs(engine, golden, name, mp):
+    """Inputs on which the reference's special cases decide (low-order, off-curve, zero, flagged:
+    tests/golden/pairing_degenerate.json, reference-generated).  The fast kernels must notice and
+    k_miller_slow must reproduce the reference's bytes -- through k_miller (mp = huge threshold:
+    one pair per wavefront) and through k_miller_mp (threshold 0: three pairs per wavefront)."""
+    v = golden("pairing_degenerate.json")["cases"][name]
+    n = len(v["g1"])
+    try:
+        engine.set_mp_threshold(mp)
+        assert engine.pairing_multi(cat(v["g1"]), cat(v["g2"]), n, flags(v)).hex() == v["out"]
+    finally:
+        engine.set_mp_threshold(4096)
+
+
+def test_degenerate_pairs_inside_large_batches(engine, golden, seeded_pairs, oracle):
+    """the same pairs hidden in ordinary batches: 300 seeded pairs with degenerate ones spliced in
+    (every third team of k_miller_mp gets one), and as groups of a batch call"""
+    g1, g2 = seeded_pairs
+    d = golden("pairing_degenerate.json")["cases"]
+    a, b, inf = bytearray(), bytearray(), bytearray()
+    picks = [d[k] for k in ("ord13", "ord11_embedded", "off_curve", "flag_on_valid", "qy_zero", "qx_zero")]
+    for i in range(300):
+        a += g1[96 * i:96 * (i + 1)]; b += g2[192 * i:192 * (i + 1)]; inf += bytes(2)
+        if i % 9 == 4:
+            c = picks[(i // 9) % len(picks)]
+            a += bytes.fromhex(c["g1"][0]); b += bytes.fromhex(c["g2"][0]); inf += bytes(int(x) for x in c["inf"][0])
+    n = len(a) // 96
+    want = oracle.pairing_multi(bytes(a), bytes(b), n, threads=8, inf=bytes(inf))
+    for mp in (1 << 30, 0):
+        try:
+            engine.set_mp_threshold(mp)
+            assert engine.pairing_multi(bytes(a), bytes(b), n, bytes(inf)) == want, mp
+        finally:
+            engine.set_mp_threshold(4096)
+    # batch entry: groups of 3 (one k_miller wavefront per pair) and of 27 (per-group product tree)
+    for gsz in (3, 27):
+        groups = n // gsz
+        m = gsz * groups
+        out = engine.pairing_multi_batch(bytes(a[:96 * m]), bytes(b[:192 * m]), gsz, groups, bytes(inf[:2 * m]))
+        for g in range(groups):
+            sl = slice(gsz * g, gsz * (g + 1))
+            want = oracle.pairing_multi(bytes(a[96 * sl.start:96 * sl.stop]), bytes(b[192 * sl.start:192 * sl.stop]), gsz,
+                                        inf=bytes(inf[2 * sl.start:2 * sl.stop]))
+            assert out[576 * g:576 * (g + 1)] == want, (gsz, g)
+
+
+def test_miller_loop_batch_is_the_reference_value(engine, golden, seeded_pairs, oracle):
+    """blsgpu_miller_loop_batch == fq_miller_loop bit for bit (not up to the final exponentiation)"""
+    g = golden("pairing.json")
+    assert engine.miller_loop_batch(bytes.fromhex(g["gen"]["g1"]), bytes.fromhex(g["gen"]["g2"]), 1).hex() == g["gen"]["miller"]
+    v = g["small4"]
+    assert engine.miller_loop_batch(cat(v["g1"]), cat(v["g2"]), 4).hex() == "".join(v["miller"])
+    for name, c in golden("pairing_degenerate.json")["cases"].items():
+        n = len(c["g1"])
+        assert engine.miller_loop_batch(cat(c["g1"]), cat(c["g2"]), n, flags(c)).hex() == "".join(c["miller"]), name
+    g1, g2 = seeded_pairs
+    n = 70
+    out = engine.miller_loop_batch(g1[:96 * n], g2[:192 * n], n)
+    for i in (0, 1, 33, 69):
+        assert out[576 * i:576 * (i + 1)] == oracle.miller_loop(g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)])
+    assert engine.miller_loop_batch(b"", b"", 0) == b""
+
+
+def test_line_evaluations(engine, golden, oracle, seeded_pairs):
+    """blsgpu_line_eval_batch == fq2_double_line_eval / fq2_add_line_eval (reference vectors, then the oracle)"""
+    for name, c in golden("lines.json").items():
+        r, q, p = bytes.fromhex(c["r"]), bytes.fromhex(c["q"]), bytes.fromhex(c["p"])
+        assert engine.line_eval_batch(r, None, p, 1).hex() == c["dbl"], name
+        assert engine.line_eval_batch(r, q, p, 1).hex() == c["add"], name
+    g1, g2 = seeded_pairs
+    n = 40
+    r, q, p = g2[:192 * n], g2[192 * n:192 * 2 * n], g1[:96 * n]
+    dbl, add = engine.line_eval_batch(r, None, p, n), engine.line_eval_batch(r, q, p, n)
+    for i in (0, 7, 39):
+        ri, qi, pi = r[192 * i:192 * (i + 1)], q[192 * i:192 * (i + 1)], p[96 * i:96 * (i + 1)]
+        assert dbl[576 * i:576 * (i + 1)] == oracle.line_eval(ri, None, pi)
+        assert add[576 * i:576 * (i + 1)] == oracle.line_eval(ri, qi, pi)
+
+
+def test_pairing_module_wrappers(golden):
+    """bls_py.pairing: the six functions of the reference's pairing.py:16-92 with its signatures"""
+    from bls_py import pairing as PR
+    from bls_py.ec import AffinePoint, default_ec, default_ec_twist
+    from bls_py.fields import Fq, Fq2, Fq12
+    q = default_ec.q
+    g = golden("pairing.json")["gen"]
+
+    def p1(h, inf=False):
+        b = bytes.fromhex(h)
+        return AffinePoint(Fq(q, int.from_bytes(b[:48], "big")), Fq(q, int.from_bytes(b[48:], "big")), inf, default_ec)
+
+    def p2(h, inf=False):
+        v = [int.from_bytes(bytes.fromhex(h)[48 * i:48 * (i + 1)], "big") for i in range(4)]
+        return AffinePoint(Fq2(q, v[0], v[1]), Fq2(q, v[2], v[3]), inf, default_ec_twist)
+    P, Qp = p1(g["g1"]), p2(g["g2"])
+    ml = PR.miller_loop(P, Qp)
+    assert type(ml) is Fq12 and ml.serialize().hex() == g["miller"]
+    assert PR.final_exponentiation(ml, default_ec).serialize().hex() == g["final_exp"]
+    assert PR.ate_pairing(P, Qp).serialize().hex() == g["final_exp"]
+    c = golden("lines.json")["generic"]
+    R, Q2, P5 = p2(c["r"]), p2(c["q"]), p1(c["p"])
+    assert PR.double_line_eval(R, P5).serialize().hex() == c["dbl"]
+    assert PR.add_line_eval(R, Q2, P5).serialize().hex() == c["add"]
+    v = golden("pairing.json")["edge"]["flag_on_valid"]
+    assert PR.ate_pairing_multi([p1(v["g1"][0], True)], [p2(v["g2"][0], True)]).serialize().hex() == v["out"]
+    d = golden("pairing_degenerate.json")["cases"]["ord13_in_team"]
+    assert PR.ate_pairing_multi([p1(x) for x in d["g1"]], [p2(x) for x in d["g2"]]).serialize().hex() == d["out"]
+    with pytest.raises(Exception):
+        PR.miller_loop(Qp, P)
+    with pytest.raises(Exception):
+        PR.ate_pairing_multi([P], [Qp, Qp])
+
+
+def test_seeded_8192_digest_vs_reference(engine, golden):
+    """SURVEY 8c F-PAIR: the reference's multi-pairing of the first 8192 PRF-seeded pairs (fixture made by
+    make_golden.py seeded8192).  The inputs are rebuilt here from the PRF scalars with the engine's own
+    group sums and checked against the fixture's input digests first."""
+    v = golden("pairing_seeded_8192.json")
+    n = v["n"]
+    nord = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+    def prf(tag, i):
+        return int.from_bytes(hashlib.sha256(tag + (1).to_bytes(4, "big") + i.to_bytes(4, "big")).digest(), "big") % (nord - 1) + 1
+    gen = golden("pairing.json")["gen"]
+    a = [prf(b"blsgpu/a", i) for i in range(n)]
+    b = [prf(b"blsgpu/b", i) for i in range(n)]
+    g1, _ = engine.g1_msm(bytes.fromhex(gen["g1"]) * n, a, 1, n)
+    g2, _ = engine.g2_msm(bytes.fromhex(gen["g2"]) * n, b, 1, n)
+    assert hashlib.sha256(g1).hexdigest() == v["sha256_g1"] and hashlib.sha256(g2).hexdigest() == v["sha256_g2"]
+    out = engine.pairing_multi(g1, g2, n)
+    assert out.hex() == v["out"] and hashlib.sha256(out).hexdigest() == v["sha256_out"]
 
 
 @pytest.mark.parametrize("n", [8, 65, 1025])
@@ -127,8 +273,16 @@ def test_reference_boundary_signature(golden):
     g = golden("pairing.json")["gen"]
     assert fh.fq12_final_exp(tuple(ints(g["miller"], 12))) == tuple(ints(g["final_exp"], 12))
     assert fh.fq_ate_pairing_multi((), ()) == (1,) + (0,) * 11
-    with pytest.raises(ValueError):
-        fh.fq_ate_pairing_multi((Ps[0],), ((Qs[0][0], Qs[0][1], True),))
+    # flags travel with the coordinates, as in fields_t_c.pyx:2333-2346
+    e = golden("pairing.json")["edge"]["flag_on_valid"]
+    Pf = ((ints(e["g1"][0], 2)[0], ints(e["g1"][0], 2)[1], True),)
+    Qf = (((ints(e["g2"][0], 4)[0], ints(e["g2"][0], 4)[1]), (ints(e["g2"][0], 4)[2], ints(e["g2"][0], 4)[3]), True),)
+    assert b"".join(x.to_bytes(48, "big") for x in fh.fq_ate_pairing_multi(Pf, Qf)).hex() == e["out"]
+    assert fh.fq_miller_loop(*Ps[0], *Qs[0]) == tuple(ints(v["miller"][0], 12))
+    c = golden("lines.json")["generic"]
+    r, qq, p = ints(c["r"], 4), ints(c["q"], 4), ints(c["p"], 2)
+    assert fh.fq2_double_line_eval((r[0], r[1]), (r[2], r[3]), p[0], p[1]) == tuple(ints(c["dbl"], 12))
+    assert fh.fq2_add_line_eval((r[0], r[1]), (r[2], r[3]), (qq[0], qq[1]), (qq[2], qq[3]), p[0], p[1]) == tuple(ints(c["add"], 12))
 
 
 def test_batched_independent_pairings(engine, golden, seeded_pairs, oracle):

@@ -12,8 +12,16 @@ def oracle_provider(oracle):
     from bls_py import backend
 
     class P:
-        def pairing_multi(self, g1, g2, n):
-            return oracle.pairing_multi(g1, g2, n, threads=8)
+        def pairing_multi(self, g1, g2, n, inf=None):
+            return oracle.pairing_multi(g1, g2, n, threads=8, inf=inf)
+
+        def miller_loop_batch(self, g1, g2, n, inf=None):
+            return b"".join(oracle.miller_loop(g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)], bool(inf and inf[2 * i + 1]))
+                            for i in range(n))
+
+        def line_eval_batch(self, r, q, p, n):
+            return b"".join(oracle.line_eval(r[192 * i:192 * (i + 1)], None if q is None else q[192 * i:192 * (i + 1)],
+                                             p[96 * i:96 * (i + 1)]) for i in range(n))
 
         def final_exp(self, x):
             return oracle.final_exp(x)
@@ -33,8 +41,9 @@ def oracle_provider(oracle):
         def g2_msm(self, pts, scalars, k, groups=1):
             return self._msm(oracle.g2_msm, 192, pts, scalars, k, groups)
 
-        def pairing_multi_batch(self, g1, g2, gsz, groups):
-            return b"".join(oracle.pairing_multi(g1[96 * gsz * g:96 * gsz * (g + 1)], g2[192 * gsz * g:192 * gsz * (g + 1)], gsz)
+        def pairing_multi_batch(self, g1, g2, gsz, groups, inf=None):
+            return b"".join(oracle.pairing_multi(g1[96 * gsz * g:96 * gsz * (g + 1)], g2[192 * gsz * g:192 * gsz * (g + 1)], gsz,
+                                                 inf=None if inf is None else inf[2 * gsz * g:2 * gsz * (g + 1)])
                             for g in range(groups))
 
         def g1_decompress(self, data):
@@ -198,9 +207,9 @@ def test_verify4_inputs_match_reference(golden):
         hash_to_g2 = staticmethod(inner.hash_to_g2)
         pairing_multi_batch = staticmethod(inner.pairing_multi_batch)
 
-        def pairing_multi(self, g1, g2, n):
-            seen["g1"], seen["g2"], seen["n"] = g1, g2, n
-            return inner.pairing_multi(g1, g2, n)
+        def pairing_multi(self, g1, g2, n, inf=None):
+            seen["g1"], seen["g2"], seen["n"], seen["inf"] = g1, g2, n, inf
+            return inner.pairing_multi(g1, g2, n, inf)
     backend.use(Spy())
     try:
         assert BLS.verify(agg) is True
@@ -275,3 +284,37 @@ def test_verify_batch_matches_verify_one_by_one(golden, oracle_provider):
     got = BLS.verify_batch(batch)
     assert got == [BLS.verify(s) for s in batch] == [True, True, False, True, True, False, True]
     assert BLS.verify_batch([]) == []
+
+
+def test_pairing_wrappers_host_logic(golden):
+    """bls_py.pairing (the reference's pairing.py:16-92): unwrapping, flags and type checks --
+    the arithmetic here is the injected oracle's, on the GPU it is tests/test_gpu_parity.py's."""
+    from bls_py import pairing as PR
+    from bls_py.ec import AffinePoint, default_ec, default_ec_twist
+    from bls_py.fields import Fq, Fq2
+    q = default_ec.q
+
+    def p1(h, inf=False):
+        b = bytes.fromhex(h)
+        return AffinePoint(Fq(q, int.from_bytes(b[:48], "big")), Fq(q, int.from_bytes(b[48:], "big")), inf, default_ec)
+
+    def p2(h, inf=False):
+        v = [int.from_bytes(bytes.fromhex(h)[48 * i:48 * (i + 1)], "big") for i in range(4)]
+        return AffinePoint(Fq2(q, v[0], v[1]), Fq2(q, v[2], v[3]), inf, default_ec_twist)
+    g = golden("pairing.json")["gen"]
+    P, Qp = p1(g["g1"]), p2(g["g2"])
+    assert PR.miller_loop(P, Qp).serialize().hex() == g["miller"]
+    assert PR.ate_pairing(P, Qp).serialize().hex() == g["final_exp"]
+    c = golden("lines.json")["generic"]
+    assert PR.double_line_eval(p2(c["r"]), p1(c["p"])).serialize().hex() == c["dbl"]
+    assert PR.add_line_eval(p2(c["r"]), p2(c["q"]), p1(c["p"])).serialize().hex() == c["add"]
+    # a VALID point that carries inf=True keeps its coordinates on the way down (pairing.py:90-91)
+    v = golden("pairing.json")["edge"]["flag_on_valid"]
+    assert PR.ate_pairing_multi([p1(v["g1"][0], True)], [p2(v["g2"][0], True)]).serialize().hex() == v["out"]
+    d = golden("pairing_degenerate.json")["cases"]["flag_in_team"]
+    Ps = [p1(x, f[0]) for x, f in zip(d["g1"], d["inf"])]
+    Qs = [p2(x, f[1]) for x, f in zip(d["g2"], d["inf"])]
+    assert PR.ate_pairing_multi(Ps, Qs).serialize().hex() == d["out"]
+    for bad in (lambda: PR.miller_loop(Qp, P), lambda: PR.ate_pairing_multi([P], [Qp, Qp]), lambda: PR.double_line_eval(P, P)):
+        with pytest.raises(Exception):
+            bad()

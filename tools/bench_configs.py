@@ -68,7 +68,7 @@ def main():
         pg2 = (bytes.fromhex(th["combined_affine"]) + H.g2_affine_bytes(hm)) * groups
         v1, v2 = up(pg1), up(pg2)
         vout = torch.zeros(groups * 576, dtype=torch.uint8, device=dev)
-        dtv = timed(lambda: lib.blsgpu_pairing_multi_batch_dev(h, v1.data_ptr(), v2.data_ptr(), 2, groups, vout.data_ptr(), 0), 2)
+        dtv = timed(lambda: lib.blsgpu_pairing_multi_batch_dev(h, v1.data_ptr(), v2.data_ptr(), None, 2, groups, vout.data_ptr(), 0), 2)
         one = (1).to_bytes(48, "big") + bytes(48 * 11)
         okv = bytes(vout.cpu().numpy()) == one * groups
         print(json.dumps({"config": "C4: threshold k=67 combine + verify, 10000 groups", "combine_s": dt, "verify_s": dtv,

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity soak (GPU box): random subsets of the seeded pairs, random sizes and
-group shapes, degenerate coordinates sprinkled in, through both Miller kernels and the batch
-entry point, every result against the CPU oracle.  Not part of the test-suite (minutes of
+group shapes, through both Miller kernels and the batch entry point, every result against the
+CPU oracle.  Sprinkled in: zero coordinates, points off the twist (random, (x, 0), (0, y)), the
+low-order points of tests/golden/pairing_degenerate.json (order 13 on the twist, orders 3 and
+11 of E(Fq) as Fq2 coordinates), their negatives, and infinity flags on valid points.  Not part of the test-suite (minutes of
 oracle time); prints one line per trial and a summary."""
 import os
 import random
@@ -25,46 +27,69 @@ def main():
     rng = random.Random(20261003)
     bad = 0
     t0 = time.time()
+    import json
+    Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    dc = json.load(open(os.path.join(gold, "pairing_degenerate.json")))["cases"]
+    low = [bytes.fromhex(dc[k]["g2"][0]) for k in ("ord13", "ord13_neg", "ord3_embedded", "ord11_embedded")]
+
+    def fq():
+        return rng.randrange(Q).to_bytes(48, "big")
 
     def pick(n, degenerate):
-        a, b = [], []
+        a, b, f = [], [], bytearray()
         for _ in range(n):
             i = rng.randrange(1025)
-            p, q = g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)]
-            if degenerate and rng.random() < 0.05:
-                kind = rng.randrange(3)
+            p, q, fl = g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)], (0, 0)
+            if degenerate and rng.random() < 0.08:
+                kind = rng.randrange(10)
                 if kind == 0:
-                    p = bytes(96)                       # P = (0, 0): factor 1
+                    p = bytes(96)                       # P = (0, 0)
                 elif kind == 1:
                     q = bytes(192)                      # Q = (0, 0)
-                else:
+                elif kind == 2:
                     p, q = bytes(96), bytes(192)
+                elif kind == 3:
+                    q = fq() + fq() + fq() + fq()       # off the twist
+                elif kind == 4:
+                    q = fq() + fq() + bytes(96)         # (x, 0)
+                elif kind == 5:
+                    q = bytes(96) + fq() + fq()         # (0, y)
+                elif kind == 6:
+                    q = rng.choice(low)                 # low order: a step of the loop degenerates
+                elif kind == 7:
+                    fl = (rng.randrange(2), 1)          # flagged valid Q
+                elif kind == 8:
+                    q, fl = rng.choice(low), (0, 1)
+                else:
+                    p = bytes(48) + fq()                # P.x = 0
             a.append(p)
             b.append(q)
-        return b"".join(a), b"".join(b)
+            f += bytes(fl)
+        return b"".join(a), b"".join(b), bytes(f)
 
     for t in range(trials):
         mode = t % 3
         if mode == 0:                                   # one multi-pairing, one-pair kernel
             n = rng.choice([1, 2, 3, 5, 63, 64, 65, 127, 200, 257])
-            a, b = pick(n, t % 2 == 1)
+            a, b, f = pick(n, t % 2 == 1)
             eng.set_mp_threshold(1 << 40)
-            got = eng.pairing_multi(a, b, n)
-            want = O.pairing_multi(a, b, n, threads=16)
+            got = eng.pairing_multi(a, b, n, f)
+            want = O.pairing_multi(a, b, n, threads=16, inf=f)
             ok = got == want
         elif mode == 1:                                 # one multi-pairing, three-pair kernel
             n = rng.choice([3, 4, 7, 100, 191, 192, 193, 500, 1025])
-            a, b = pick(n, t % 2 == 0)
+            a, b, f = pick(n, t % 2 == 0)
             eng.set_mp_threshold(0)
-            got = eng.pairing_multi(a, b, n)
-            want = O.pairing_multi(a, b, n, threads=16)
+            got = eng.pairing_multi(a, b, n, f)
+            want = O.pairing_multi(a, b, n, threads=16, inf=f)
             ok = got == want
         else:                                           # batch of equal-sized groups
             gsz, groups = rng.choice([(1, 40), (2, 33), (5, 17), (23, 9), (24, 9), (25, 8), (67, 5), (130, 3)])
-            a, b = pick(gsz * groups, t % 2 == 0)
+            a, b, f = pick(gsz * groups, t % 2 == 0)
             eng.set_mp_threshold(rng.choice([0, 4096, 1 << 40]))
-            got = eng.pairing_multi_batch(a, b, gsz, groups)
-            want = b"".join(O.pairing_multi(a[96 * gsz * g:96 * gsz * (g + 1)], b[192 * gsz * g:192 * gsz * (g + 1)], gsz, threads=16)
+            got = eng.pairing_multi_batch(a, b, gsz, groups, f)
+            want = b"".join(O.pairing_multi(a[96 * gsz * g:96 * gsz * (g + 1)], b[192 * gsz * g:192 * gsz * (g + 1)], gsz, threads=16,
+                                            inf=f[2 * gsz * g:2 * gsz * (g + 1)])
                             for g in range(groups))
             ok = got == want
             n = gsz * groups
