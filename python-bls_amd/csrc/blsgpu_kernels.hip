@@ -581,7 +581,9 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
 // The reference-faithful Miller loop for one pair (vmgen/slow_programs.py): affine twist point,
 // one field inversion per step with 0^-1 := 0, the reference's branches as 0/1 selections.
 // Leaves fq_miller_loop(P, Q) itself (fields_t.py:1091-1111; Montgomery form) in register 0.
-constexpr int SLOW_TEAM_BYTES = BLSVM_SLOW_SLOTS * 48;
+// (the scratchpad also runs the general segments mul_0_1 / copy_1_0 / from_mont_1_0, whose temporaries
+// BLSVM_TEAM_SLOTS covers)
+constexpr int SLOW_TEAM_BYTES = (BLSVM_SLOW_SLOTS > BLSVM_TEAM_SLOTS ? BLSVM_SLOW_SLOTS : BLSVM_TEAM_SLOTS) * 48;
 __device__ __forceinline__ void miller_exact_one(const VmTables& T, uint32_t* team, uint32_t lane, const uint32_t* __restrict__ g1,
                                                  const uint32_t* __restrict__ g2, const uint8_t* __restrict__ inf, size_t pair) {
     load_pair_raw(team, BLSVM_SLOT_PX, BLSVM_SLOT_QX0, g1, g2, pair, lane);
