@@ -1,23 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- BLS12-381 pairings/sec through the HIP multi-pairing engine.
 
-One "step" = one pass of the hot path over one batch that is already resident in
-HBM: B independent aggregate verifications (default 32), each the BASELINE.json
-configs[1] shape -- fq_ate_pairing_multi over 1025 (pk, H(m)) pairs per GPU (1024
-signatures + the (-G1, aggregate) pair): Miller loops, Fq12 product, its own
-final exponentiation.  One launch sequence per step (blsgpu_miller_product_batch_dev
-+ blsgpu_final_exp_product_batch_dev, the sharded form of blsgpu_pairing_multi_batch_dev).
-With N ranks every rank holds 1025 pairs of EACH verification (weak scaling):
-Miller products per rank, one RCCL all-gather of the B x 576-byte Fq12 partials,
-B final exponentiations on every rank.  A single verification alone is latency
-bound (one wavefront runs its final exponentiation); its latency is reported in
-"single_verification".
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5|h2c]
 
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts itself under
+`python -m torch.distributed.run` as a CHILD process (before anything touches a GPU) and
+exits with the child's code; under an external torchrun it just reads RANK / WORLD_SIZE.
+
+A "step" is one pass of the hot path over one batch already resident in HBM.
+
+  c2 (default, headline; BASELINE.json configs[1] shape x 32, weak scaling)
+      B = 32 independent aggregate verifications per step, each fq_ate_pairing_multi over 1025
+      (pk, H(m)) pairs per GPU (1024 signatures + the (-G1, aggregate) pair): Miller loops,
+      Fq12 products, B final exponentiations.  The 32 x 1025 pairs of a rank are 32 800 DIFFERENT
+      PRF-seeded points; verification 0 on rank 0 is the batch whose result the
+      reference produced (tests/golden/pairing.json).  N ranks: Miller products per rank, ONE RCCL
+      all-gather of B x 576 bytes per rank, the B final exponentiations on every rank.
+  c3  (BASELINE configs[2]; strong scaling) ONE multi-pairing of 65 536 pairs, sharded N ways
+      (8 192 per GPU at N = 8): one Miller product per rank, all-gather of one 576-byte partial
+      per rank, one final exponentiation on every rank.
+  c4  threshold k = 67 of n = 100: 10 000 combines (G2 multi-scalar sums) + 10 000 two-pair verifies.
+  c5  one G1 multi-scalar sum over 2^20 different points (aggregate_pub_keys, secure = True).
+  h2c hash 16 384 message hashes to G2.
+
+Every configuration checks its results (reference golden vectors where they exist, bilinearity /
+linearity identities evaluated by the engine itself otherwise) and aborts on a mismatch.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,107 +42,242 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PAIRS_PER_GPU = 1025
 VERIFICATIONS_PER_STEP = 32
-# algorithmic work, SURVEY.md section 8(d): 6754 Fq-mults per pairing at 300
-# 32-bit MACs each, plus ~9.5k Fq-mults per final exponentiation
-MAC_PER_PAIRING = 6754 * 300
-MAC_PER_FINAL_EXP = 9500 * 300
+C3_PAIRS = 65536
+# algorithmic work, SURVEY.md section 8(d): 6754 Fq-mults per pairing at 300 32-bit MACs each,
+# ~9.5k Fq-mults per final exponentiation; G2 / G1 mixed additions at 36 / 11 Fq-mults
+MAC_PER_FQ_MUL = 300
+MAC_PER_PAIRING = 6754 * MAC_PER_FQ_MUL
+MAC_PER_FINAL_EXP = 9500 * MAC_PER_FQ_MUL
 HBM_BYTES_PER_PAIRING = 288
 PEAK_TMACS = 34.65        # measured v_mad_u64_u32 rate, profiles/r01_intrate_microbench.txt
 PEAK_HBM_GBS = 8000.0
+N_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+def prf_scalar(tag, seed, i):
+    """counter-mode PRF scalar in [1, n-1] (same as tests/golden/make_golden.py)."""
+    h = hashlib.sha256(tag + seed.to_bytes(4, "big") + i.to_bytes(4, "big"))
+    return int.from_bytes(h.digest(), "big") % (N_ORDER - 1) + 1
+
+
+def self_launch(args):
+    """--gpus N without a launcher: run this script under torch.distributed.run as a child (this
+    process has not touched a GPU) and hand its exit code on."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def pmc_traffic(kernel, pairings_per_launch):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc passes
-    (FETCH_SIZE + WRITE_SIZE, KB per dispatch; profiles/r01_bench_pmc_summary.csv, collected by
+    (FETCH_SIZE + WRITE_SIZE, KB per dispatch; profiles/r0N_bench_pmc_summary.csv, collected by
     tools/profile_round.sh on this same workload).  Counters cannot be read inside this process,
     so the figure is only reported for the profiled shape (32 800 pairings per k_miller_mp launch);
     FETCH_SIZE is left uncorrected (dword table loads are outside the guide's x2 calibration)."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.csv")
-    if kernel != "k_miller_mp" or pairings_per_launch != 32800 or not os.path.exists(path):
-        return None
-    kb = {}
-    with open(path) as f:
-        for row in f:
-            c = row.strip().split(",")
-            if len(c) == 4 and c[0].endswith(kernel) and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-                kb[c[1]] = float(c[3])
-    if len(kb) != 2:
-        return None
-    return int((kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024)
+    for name in ("r02_bench_pmc_summary.csv", "r01_bench_pmc_summary.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if kernel != "k_miller_mp" or pairings_per_launch != 32800 or not os.path.exists(path):
+            continue
+        kb = {}
+        with open(path) as f:
+            for row in f:
+                c = row.strip().split(",")
+                if len(c) == 4 and c[0].endswith(kernel) and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    kb[c[1]] = float(c[3])
+        if len(kb) == 2:
+            return int((kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), "profiles/" + name
+    return None, None
 
 
-def cpu_baseline(g1, g2, n):
-    """The oracle (CPU restatement of the reference's algorithm) on the host
-    cores of this box; bounded sample = the same 1025-pair batch, once."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(g1, g2, n, gpu_out):
+    """The oracle (CPU restatement of the reference's algorithm: affine lines with an Fq12 inversion
+    per step, 1268-bit final exponentiation) on THIS box's host cores, bounded sample: a single
+    thread on the first 48 pairs, then every core on two copies of the 1025-pair batch.  The
+    all-core result is compared with the GPU's (squared)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     O.build()
     cores = os.cpu_count() or 1
+    n1 = min(48, n)
     t = time.perf_counter()
-    out = O.pairing_multi(g1, g2, n, threads=cores)
+    O.pairing_multi(g1[:96 * n1], g2[:192 * n1], n1, threads=1)
+    d1 = time.perf_counter() - t
+    t = time.perf_counter()
+    out = O.pairing_multi(g1 * 2, g2 * 2, 2 * n, threads=cores)
     dt = time.perf_counter() - t
-    return {"value": n / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
-            "sample": "one %d-pair multi-pairing (same batch), %.2f s wall" % (n, dt)}, out
+    ok = gpu_out is None or out == O.fq12_pow(gpu_out, 2)
+    return {"value": 2 * n / dt, "unit": "pairings/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": "two copies of the %d-pair batch on %d threads, %.2f s wall" % (n, cores, dt),
+            "single_thread": {"value": n1 / d1, "unit": "pairings/s", "cores": 1,
+                              "sample": "%d pairs + one final exponentiation, %.2f s wall" % (n1, d1)},
+            "reference_measured_in_build_container": "BASELINE.md: native Cython+GMP 259 pairings/s, pure Python 24-33 pairings/s, 1 core",
+            "matches_gpu": ok}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per verification")
-    ap.add_argument("--verifications", type=int, default=VERIFICATIONS_PER_STEP,
-                    help="independent aggregate verifications per step (one launch sequence)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="steps in flight (the final exponentiations of one step overlap the Miller loops of the next)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo: CPU-side collective, for rehearsing the multi-rank path on one GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Env:
+    """process group, device, engine streams"""
 
-    import torch
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        ndev = torch.cuda.device_count()
+        self.local_dev = local % max(1, ndev)
+        torch.cuda.set_device(self.local_dev)
+        self.dev = torch.device("cuda", self.local_dev)
+        self.dist = None
+        self.backend = args.backend
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group("gloo")
+            assert dist.get_world_size() == self.world
+
+    def up(self, b):
+        return self.torch.frombuffer(bytearray(b), dtype=self.torch.uint8).to(self.dev)
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if not self.dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_objects(self, obj):
+        if not self.dist:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def all_gather_partials(self, stream, src, dst, words):
+        """one all-gather of `words` int32 per rank (RCCL; gloo = rehearsal through host memory)"""
+        torch = self.torch
+        with torch.cuda.stream(stream):
+            if self.backend == "nccl":
+                self.dist.all_gather_into_tensor(dst, src)
+            else:
+                stream.synchronize()
+                host = [torch.zeros(words, dtype=torch.int32) for _ in range(self.world)]
+                self.dist.all_gather(host, src.cpu())
+                dst.copy_(torch.cat(host).to(self.dev))
+
+    def finish(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def seeded_points(eng, gen1, gen2, idx):
+    """P_i = a_i G1, Q_i = b_i G2 for the PRF indices idx (seed 1), computed with the engine's own
+    group sums (k = 1 per group); returns (g1 bytes, g2 bytes, a, b)."""
+    a = [prf_scalar(b"blsgpu/a", 1, i) for i in idx]
+    b = [prf_scalar(b"blsgpu/b", 1, i) for i in idx]
+    m = len(idx)
+    g1, _ = eng.g1_msm(gen1 * m, a, 1, m)
+    g2, _ = eng.g2_msm(gen2 * m, b, 1, m)
+    return g1, g2, a, b
+
+
+def timed_steps(env, args, step, engs, streams):
+    """W warm-up steps, barrier, K timed steps, barrier: (seconds max over ranks, per-step ms, kernel times)"""
+    torch = env.torch
+    S = len(streams)
+    torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    env.barrier()
+    for e in engs:
+        e.timing_enable(True)         # HIP events around every kernel, on the stream it runs on
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(streams[i % S])
+        step(i)
+        ev[i][1].record(streams[i % S])
+    env.barrier()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    ktimes = [t for e in engs for t in e.timing_read()]
+    for e in engs:
+        e.timing_enable(False)
+    return dt, step_ms, ktimes
+
+
+def bilinear_expectation(eng, gen1, gen2, sums):
+    """e(G1, G2)^s for every s in sums, as the engine's pairing of (s G1, G2): the check of SURVEY 8c
+    (prod e(a_i G1, b_i G2) = e(G1, G2)^(sum a_i b_i)), independent of any oracle."""
+    m = len(sums)
+    pts, _ = eng.g1_msm(gen1 * m, [s % N_ORDER for s in sums], 1, m)
+    out = eng.pairing_multi_batch(pts, gen2 * m, 1, m)
+    return [out[576 * i:576 * (i + 1)] for i in range(m)]
+
+
+def latency_probe(env, eng, t1, t2, n, stream, reps=4):
+    torch = env.torch
+    out = torch.zeros(576, dtype=torch.uint8, device=env.dev)
+    ms = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        eng.pairing_multi_dev(t1.data_ptr(), t2.data_ptr(), n, out.data_ptr(), stream.cuda_stream)
+        b.record(stream)
+        stream.synchronize()
+        ms.append(a.elapsed_time(b))
+    return min(ms)
+
+
+def run_pairing(env, args):
+    torch = env.torch
     from bls_py import _native
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    ndev = torch.cuda.device_count()
-    local_dev = local % max(1, ndev)
-    torch.cuda.set_device(local_dev)
-    dev = torch.device("cuda", local_dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+    world, rank, dev = env.world, env.rank, env.dev
+    c3 = args.config == "c3"
     S = max(1, args.streams)
-    B = max(1, args.verifications)
-    engs = [_native.Engine(local_dev) for _ in range(S)]
+    engs = [_native.Engine(env.local_dev) for _ in range(S)]
     eng = engs[0]
-
     gold = os.path.join(ROOT, "tests", "golden")
-    with open(os.path.join(gold, "pairs_seed1_g1.bin"), "rb") as f:
-        g1_all = f.read()
-    with open(os.path.join(gold, "pairs_seed1_g2.bin"), "rb") as f:
-        g2_all = f.read()
-    n = args.pairs
-    reps = (n + 1024) // 1025
-    g1 = (g1_all * reps)[:96 * n]
-    g2 = (g2_all * reps)[:192 * n]
-
-    def shard(v, r):
-        """Pairs of verification v held by rank r: a rotation of the seeded batch
-        (different data per verification and per rank; a rotation keeps the product)."""
-        rot = (v * 37 + r * 131) % n
-        return g1[96 * rot:] + g1[:96 * rot], g2[192 * rot:] + g2[:192 * rot]
-    mine = [shard(v, rank) for v in range(B)]
-    t1 = torch.frombuffer(bytearray(b"".join(a for a, _ in mine)), dtype=torch.uint8).to(dev)
-    t2 = torch.frombuffer(bytearray(b"".join(b for _, b in mine)), dtype=torch.uint8).to(dev)
+    with open(os.path.join(gold, "pairing.json")) as f:
+        gj = json.load(f)
+    gen1, gen2 = bytes.fromhex(gj["gen"]["g1"]), bytes.fromhex(gj["gen"]["g2"])
+    if c3:
+        total = args.pairs_total
+        lo, hi = total * rank // world, total * (rank + 1) // world
+        n, B = hi - lo, 1
+        idx = list(range(lo, hi))                       # rank r holds pairs [lo, hi) of the ONE verification
+    else:
+        n, B = args.pairs, max(1, args.verifications)
+        # verification v of rank r: PRF indices ((v * world + r) * n ...): all different; v = 0 on rank 0
+        # is the batch of tests/golden/pairing.json "seeded"
+        idx = [((v * world + rank) * n + j) for v in range(B) for j in range(n)]
+    g1, g2, a, b = seeded_points(eng, gen1, gen2, idx)
+    t1, t2 = env.up(g1), env.up(g2)
     outs = [torch.zeros(B * 576, dtype=torch.uint8, device=dev) for _ in range(S)]
     parts = [torch.zeros(B * 144, dtype=torch.int32, device=dev) for _ in range(S)]
     gath = [torch.zeros(world * B * 144, dtype=torch.int32, device=dev) for _ in range(S)]
@@ -136,10 +286,10 @@ def main():
         e.reserve((n + 3) * B)
         e.set_mp_threshold(0 if n * B >= 2048 else 1 << 40)    # throughput kernel once the batch can fill the GPU
 
-    # A step = Miller loops + per-verification products (stream k), then the B final
-    # exponentiations.  Miller launches of consecutive steps are serialised with an
-    # event (they would only stretch each other), so the final exponentiations of
-    # step i (B wavefronts, latency bound) overlap the Miller loops of step i + 1.
+    # A step = Miller loops + per-verification products (stream k), [all-gather,] then the B final
+    # exponentiations.  Miller launches of consecutive steps are serialised with an event (they would
+    # only stretch each other), so the final exponentiations of step i (B wavefronts, latency bound)
+    # overlap the Miller loops of step i + 1.
     miller_done = [None]
 
     def step(i):
@@ -155,122 +305,297 @@ def main():
         if world == 1:
             engs[k].final_exp_product_batch_dev(parts[k].data_ptr(), 1, B, outs[k].data_ptr(), st)
         else:
-            with torch.cuda.stream(stream):
-                if args.backend == "nccl":
-                    dist.all_gather_into_tensor(gath[k], parts[k])       # RCCL: B x 576 bytes per rank
-                else:
-                    stream.synchronize()
-                    host = [torch.zeros(B * 144, dtype=torch.int32) for _ in range(world)]
-                    dist.all_gather(host, parts[k].cpu())
-                    gath[k].copy_(torch.cat(host).to(dev))
+            env.all_gather_partials(stream, parts[k], gath[k], B * 144)     # B x 576 bytes per rank
             engs[k].final_exp_product_batch_dev(gath[k].data_ptr(), world, B, outs[k].data_ptr(), st)
 
-    torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    for e in engs:
-        e.timing_enable(True)         # HIP events around every kernel, on the stream it runs on
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record(streams[i % S])
-        step(i)
-        ev[i][1].record(streams[i % S])
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-    if dist:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    dt, step_ms, ktimes = timed_steps(env, args, step, engs, streams)
     results = [bytes(o.cpu().numpy()) for o in outs[:min(S, args.steps)]]
-    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    ktimes = [t for e in engs for t in e.timing_read()]        # every kernel of the timed region
-    for e in engs:
-        e.timing_enable(False)
+    assert all(r == results[0] for r in results), "streams disagree"
+    per = [results[0][576 * v:576 * (v + 1)] for v in range(B)]
     miller_ms = [ms for k, ms in ktimes if k == 0]
     reduce_ms = [ms for k, ms in ktimes if k == 1]
     fexp_ms = [ms for k, ms in ktimes if k == 2]
-    solo_out = torch.zeros(B * 576, dtype=torch.uint8, device=dev)
-    # single verification alone on the GPU (latency view of the same workload)
-    one_ms = []
+    slow_ms = [ms for k, ms in ktimes if k == 3]
+    miller_avg = sum(miller_ms) / len(miller_ms)
+    # every rank's sums of a_i b_i per verification and its kernel time go to rank 0
+    sums = [sum(x * y for x, y in zip(a[v * n:(v + 1) * n], b[v * n:(v + 1) * n])) % N_ORDER for v in range(B)]
+    info = env.gather_objects({"rank": rank, "sums": sums, "k_miller_ms_avg": miller_avg, "pairs": n * B,
+                               "device": torch.cuda.get_device_name(dev)})
+    # latency views of the literal configs on this GPU alone: one 1025-pair verification, one 8192-pair shard
     eng.set_mp_threshold(4096)
-    for i in range(4):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(streams[0])
-        eng.pairing_multi_dev(t1.data_ptr(), t2.data_ptr(), n, solo_out.data_ptr(), streams[0].cuda_stream)
-        b.record(streams[0])
-        streams[0].synchronize()
-        one_ms.append(a.elapsed_time(b))
-    assert all(r == results[0] for r in results), "streams disagree"
-    result = results[0]
+    lat = {}
+    if rank == 0 and not args.no_latency:
+        for m in (1025, 8192):
+            reps = (m + len(g1) // 96 - 1) // (len(g1) // 96)
+            x1, x2 = env.up((g1 * reps)[:96 * m]), env.up((g2 * reps)[:192 * m])
+            ms = latency_probe(env, eng, x1, x2, m, streams[0])
+            lat["%d_pairs" % m] = {"latency_ms": ms, "pairings_per_s": m / (ms * 1e-3)}
 
     if rank == 0:
-        total_pairs = n * B * world * args.steps
+        total_pairs = sum(i["pairs"] for i in info) * args.steps
         value = total_pairs / dt
-        # correctness gate.  N=1 with the seeded 1025 pairs: every verification is a
-        # rotation of the batch whose result the reference produced (committed golden
-        # vector).  Other shapes: verification 0 against a single-GPU pass over the
-        # concatenation of every rank's shard, and all B verifications the same power.
-        check = "unchecked"
-        per = [result[576 * v:576 * (v + 1)] for v in range(B)]
-        if world == 1 and n == 1025:
-            with open(os.path.join(gold, "pairing.json")) as f:
-                want = bytes.fromhex(json.load(f)["seeded"]["1025"]["out"])
-            check = "golden-ok" if all(p == want for p in per) else "MISMATCH"
-        else:
-            cat1 = b"".join(shard(0, r)[0] for r in range(world))
-            cat2 = b"".join(shard(0, r)[1] for r in range(world))
-            ok = eng.pairing_multi(cat1, cat2, n * world) == per[0] and all(p == per[0] for p in per)
-            check = "single-gpu-ok" if ok else "MISMATCH"
+        tot = [sum(i["sums"][v] for i in info) % N_ORDER for v in range(B)]
+        want = bilinear_expectation(eng, gen1, gen2, tot)
+        check = "bilinear-ok" if per == want else "MISMATCH"
+        if not c3 and n == 1025 and check != "MISMATCH" and world == 1:
+            # verification 0 = the batch whose result the reference produced
+            check = "golden+bilinear-ok" if per[0].hex() == gj["seeded"]["1025"]["out"] else "MISMATCH"
+        if len(set(per)) != B:
+            check = "MISMATCH"                       # different batches must give different results
         if check == "MISMATCH":
             raise SystemExit("result mismatch -- bench invalid")
-        # dominant kernel = the Miller kernel (all the per-pairing work): algorithmic
-        # MACs of one launch (B x n pairings) over its average duration in the timed
-        # region (launches do not overlap each other, see step())
-        miller_avg = sum(miller_ms) / len(miller_ms)
+        # dominant kernel = the Miller kernel (all the per-pairing work): algorithmic MACs of one launch
+        # over its average duration in the timed region (launches do not overlap each other, see step())
         ach = MAC_PER_PAIRING * n * B / (miller_avg * 1e-3) / 1e12
         kname = "k_miller_mp" if n * B >= 2048 else "k_miller"
+        traffic, traffic_src = pmc_traffic(kname, n * B)
+        if c3:
+            workload = ("ONE multi-pairing of %d pairs sharded over %d GPU(s) (%d pairs per GPU), one final exponentiation "
+                        "(BASELINE configs[2])" % (args.pairs_total, world, n))
+            par = "shard%d+allgather576B" % world
+        else:
+            workload = ("%d independent aggregate verifications per step, each a multi-pairing of %d (pk, H(m)) pairs per GPU "
+                        "with its own final exponentiation (BASELINE configs[1] shape x %d); %d different PRF-seeded pairs per GPU"
+                        % (B, n, B, n * B))
+            par = "shard%d+allgather%dB" % (world, 576 * B)
         line = {
             "metric": "BLS12-381 pairings/sec (aggregate_verify multi-pairing)",
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%d independent aggregate verifications per step, each a multi-pairing of %d (pk, H(m)) "
-                                   "pairs per GPU with its own final exponentiation (BASELINE configs[1] shape x %d)" % (B, n, B),
-                       "pairs_per_verification_per_gpu": n, "verifications_per_step": B, "pairs_per_step_per_gpu": n * B,
-                       "parallelism": "shard%d+allgather%dB" % (world, 576 * B), "steps_in_flight": S, "check": check},
+            "scaling": "strong" if c3 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": workload, "name": args.config, "pairs_per_verification_per_gpu": n, "verifications_per_step": B,
+                       "pairs_per_step_per_gpu": n * B, "parallelism": par, "steps_in_flight": S, "check": check,
+                       "backend": env.backend if world > 1 else "none", "ranks_in_process_group": len(info)},
             "roofline": {"bound": "valu-int32-mac", "achieved": ach, "peak": PEAK_TMACS, "unit": "TMAC/s",
-                         "frac": ach / PEAK_TMACS, "traffic": pmc_traffic(kname, n * B),
-                         "traffic_unit": "bytes per launch, offline rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (profiles/r01_bench_pmc_summary.csv)",
+                         "frac": ach / PEAK_TMACS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch, offline rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (%s)" % traffic_src,
                          "algorithmic_bytes_per_launch": (HBM_BYTES_PER_PAIRING * n * B + 576 * ((n + 2) // 3) * B),
                          "kernel": kname,
                          "kernel_launches_timed": len(miller_ms), "kernel_ms_avg": miller_avg,
                          "pairings_per_launch": n * B, "mac_per_pairing": MAC_PER_PAIRING,
                          "reduce_kernels_ms_per_step": sum(reduce_ms) / max(1, len(miller_ms)),
+                         "degenerate_pair_kernel_ms_per_step": sum(slow_ms) / max(1, len(miller_ms)),
                          "final_exp_kernel_ms_avg": (sum(fexp_ms) / len(fexp_ms)) if fexp_ms else None,
                          "whole_step_TMACs": (MAC_PER_PAIRING * n + MAC_PER_FINAL_EXP) * B * world / (dt / args.steps) / 1e12,
                          "step_latency_ms_avg": sum(step_ms) / len(step_ms), "step_latency_ms_min": step_ms[0],
                          "hbm_GBps_algorithmic": HBM_BYTES_PER_PAIRING * n * B / (miller_avg * 1e-3) / 1e9,
                          "hbm_peak_GBps": PEAK_HBM_GBS},
-            "single_verification": {"pairs": n, "latency_ms": min(one_ms), "pairings_per_s": n / (min(one_ms) * 1e-3)},
+            "per_rank": [{"rank": i["rank"], "device": i["device"], "k_miller_ms_avg": i["k_miller_ms_avg"]} for i in info],
+            "single_call_latency": lat,
         }
         if not args.no_cpu_baseline and world == 1:
-            cb, cpu_out = cpu_baseline(mine[0][0], mine[0][1], n)
-            if cpu_out != per[0]:
+            cb = cpu_baseline(g1[:96 * min(n, 1025)], g2[:192 * min(n, 1025)], min(n, 1025), per[0] if n == 1025 else None)
+            if not cb["matches_gpu"]:
                 raise SystemExit("CPU oracle and GPU disagree -- bench invalid")
-            cb["matches_gpu"] = True
             line["cpu_baseline"] = cb
         print(json.dumps(line))
-    if dist:
+
+
+def device_timed(env, fn, reps):
+    torch = env.torch
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / reps
+
+
+def run_c4(env, args):
+    """C4: 10 000 groups x (67-point G2 multi-scalar combine + two-pair verify).  Groups shard over
+    ranks with no exchange (weak scaling: 10 000 groups per GPU)."""
+    torch = env.torch
+    from bls_py import _native, hostmath as H, util
+    from bls_py.keys import PublicKey
+    eng = _native.Engine(env.local_dev)
+    with open(os.path.join(ROOT, "tests", "golden", "threshold.json")) as f:
+        th = json.load(f)["67_of_100"]
+    groups, k = args.groups, 67
+    pts = b"".join(bytes.fromhex(s) for s in th["unit_sigs_affine"])
+    lam = [int(x, 16) for x in th["lambdas"]]
+    # every group gets its own shares: group g's points are the golden shares scaled by c_g (a G2
+    # group sum per share would cost more than the measurement; instead the SCALARS differ:
+    # lambda_j * c_g, so that the combine of group g must equal c_g * golden)
+    cg = [prf_scalar(b"blsgpu/c4", 1, env.rank * groups + g) for g in range(groups)]
+    sc = b"".join(((l * c) % N_ORDER).to_bytes(32, "big") for c in cg for l in lam)
+    tp, ts = env.up(pts * groups), env.up(sc)
+    tout = torch.zeros(groups * 192, dtype=torch.uint8, device=env.dev)
+    tinf = torch.zeros(groups, dtype=torch.uint8, device=env.dev)
+    lib, h = eng.lib, eng.h
+    reps = max(1, args.steps)
+    dt_c = device_timed(env, lambda: lib.blsgpu_g2_msm_dev(h, tp.data_ptr(), ts.data_ptr(), k, groups, tout.data_ptr(), tinf.data_ptr(), 0), reps)
+    got = bytes(tout.cpu().numpy())
+    gold_pt = bytes.fromhex(th["combined_affine"])
+    want, _ = eng.g2_msm(gold_pt * groups, cg, 1, groups)
+    ok_c = got == want and not bool(tinf.any())
+    # verify: e(-G1, sig_g) e(c_g pk, H(m)) = 1 per group
+    pk = PublicKey.from_bytes(bytes.fromhex(th["master_pk"])).value.to_affine()._aff()
+    hm = H.g2_affine_bytes(H.hash_to_g2_prehashed(util.hash256(bytes.fromhex(th["msg"])), util.hash512))
+    ng1 = H.g1_affine_bytes(H.jac_to_affine(H.F1, H.jac_mul(H.F1, H.aff_to_jac(H.F1, H.G1_GEN), N_ORDER - 1)))
+    pks, _ = eng.g1_msm(H.g1_affine_bytes(pk) * groups, cg, 1, groups)
+    pg1 = b"".join(ng1 + pks[96 * g:96 * (g + 1)] for g in range(groups))
+    pg2 = b"".join(got[192 * g:192 * (g + 1)] + hm for g in range(groups))
+    v1, v2 = env.up(pg1), env.up(pg2)
+    vout = torch.zeros(groups * 576, dtype=torch.uint8, device=env.dev)
+    dt_v = device_timed(env, lambda: eng.pairing_multi_batch_dev(v1.data_ptr(), v2.data_ptr(), 2, groups, vout.data_ptr(), 0), reps)
+    one = (1).to_bytes(48, "big") + bytes(48 * 11)
+    ok_v = bytes(vout.cpu().numpy()) == one * groups
+    dt = env.max_over_ranks(dt_c + dt_v)
+    oks = env.gather_objects(ok_c and ok_v)
+    if env.rank == 0:
+        if not all(oks):
+            raise SystemExit("result mismatch -- bench invalid")
+        # algorithmic work (SURVEY 8d): bucket method, 4-bit windows: 64 windows x (67 + 2 x 15) mixed G2
+        # additions of 36 Fq-mults; two Miller loops + one final exponentiation per verify
+        mac_combine = 64 * (k + 30) * 36 * MAC_PER_FQ_MUL
+        mac_verify = 2 * MAC_PER_PAIRING + MAC_PER_FINAL_EXP
+        print(json.dumps({
+            "metric": "threshold groups/sec (k=67 of n=100: combine + verify)", "value": groups * env.world / dt, "unit": "groups/s",
+            "n_gpus": env.world, "steps": reps, "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: %d groups per GPU, G2 multi-scalar combine of 67 shares + 2-pair verify; "
+                                   "bucket method, one (group, window) per lane, buckets in HBM" % groups, "name": "c4",
+                       "check": "combine == c_g x reference golden, every verify == 1"},
+            "combine_s": dt_c, "verify_s": dt_v,
+            "roofline": {"bound": "valu-int32-mac", "kernel": "k_msm_lane<2> (+ k_msm_prep, windows, horner)", "peak": PEAK_TMACS, "unit": "TMAC/s",
+                         "achieved": mac_combine * groups / dt_c / 1e12, "frac": mac_combine * groups / dt_c / 1e12 / PEAK_TMACS,
+                         "verify_achieved": mac_verify * groups / dt_v / 1e12, "traffic": None,
+                         "algorithmic_bytes": groups * k * (192 + 32)}}))
+
+
+def run_c5(env, args):
+    """C5: one G1 multi-scalar sum over 2^20 DIFFERENT points (aggregate_pub_keys at scale)."""
+    torch = env.torch
+    from bls_py import _native
+    eng = _native.Engine(env.local_dev)
+    with open(os.path.join(ROOT, "tests", "golden", "pairing.json")) as f:
+        gen1 = bytes.fromhex(json.load(f)["gen"]["g1"])
+    n = args.points
+    base = env.rank * n
+    a = [prf_scalar(b"blsgpu/a", 5, base + i) for i in range(n)]
+    t = [prf_scalar(b"blsgpu/t", 5, base + i) for i in range(n)]
+    pts = b""
+    for lo in range(0, n, 1 << 18):                     # the points a_i G1, in slices
+        m = min(1 << 18, n - lo)
+        p, _ = eng.g1_msm(gen1 * m, a[lo:lo + m], 1, m)
+        pts += p
+    assert len(set(pts[96 * i:96 * (i + 1)] for i in range(0, n, max(1, n // 4096)))) == len(range(0, n, max(1, n // 4096)))
+    tp, ts = env.up(pts), env.up(b"".join(x.to_bytes(32, "big") for x in t))
+    tout = torch.zeros(96, dtype=torch.uint8, device=env.dev)
+    tinf = torch.zeros(1, dtype=torch.uint8, device=env.dev)
+    lib, h = eng.lib, eng.h
+    reps = max(1, args.steps)
+    dt = device_timed(env, lambda: lib.blsgpu_g1_msm_dev(h, tp.data_ptr(), ts.data_ptr(), n, 1, tout.data_ptr(), tinf.data_ptr(), 0), reps)
+    got = bytes(tout.cpu().numpy())
+    s = sum(x * y for x, y in zip(a, t)) % N_ORDER       # sum t_i (a_i G) = (sum t_i a_i) G
+    want, _ = eng.g1_msm(gen1, [s], 1, 1)
+    ok = got == want
+    dtm = env.max_over_ranks(dt)
+    oks = env.gather_objects(ok)
+    if env.rank == 0:
+        if not all(oks):
+            raise SystemExit("result mismatch -- bench invalid")
+        # algorithmic work (SURVEY 8d): 64 windows x (n + 2 x 15) mixed G1 additions of 11 Fq-mults
+        mac = 64 * (n + 30) * 11 * MAC_PER_FQ_MUL
+        print(json.dumps({
+            "metric": "G1 multi-scalar-sum points/sec", "value": n * env.world / dtm, "unit": "points/s", "n_gpus": env.world,
+            "steps": reps, "warmup": 1, "ms_per_step": dtm * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: one G1 multi-scalar sum over %d different PRF points per GPU; bucket method with "
+                                   "4-bit windows, one (chunk, window) per lane, buckets in HBM (faster than the LDS-bucket kernels "
+                                   "from 65 536 points on: DESIGN.md 2d)" % n, "name": "c5",
+                       "check": "sum t_i (a_i G) == (sum t_i a_i) G"},
+            "roofline": {"bound": "valu-int32-mac", "kernel": "k_msm_lane<1> (+ k_msm_prep, fold, windows, horner)", "peak": PEAK_TMACS,
+                         "unit": "TMAC/s", "achieved": mac / dt / 1e12, "frac": mac / dt / 1e12 / PEAK_TMACS, "traffic": None,
+                         "algorithmic_bytes": n * (96 + 32), "hbm_GBps_algorithmic": n * 128 / dt / 1e9}}))
+
+
+def run_h2c(env, args):
+    torch = env.torch
+    from bls_py import _native, hostmath as H, util
+    eng = _native.Engine(env.local_dev)
+    n = args.messages
+    msgs = b"".join(hashlib.sha256(b"bench-h2c-%d-%d" % (env.rank, i)).digest() for i in range(n))
+    tin = env.up(msgs)
+    tout = torch.zeros(n * 192, dtype=torch.uint8, device=env.dev)
+    reps = max(1, args.steps)
+    dt = device_timed(env, lambda: eng.lib.blsgpu_hash_to_g2_dev(eng.h, tin.data_ptr(), n, tout.data_ptr(), 0), reps)
+    got = bytes(tout.cpu().numpy())
+    ok = all(got[192 * i:192 * (i + 1)] == H.g2_affine_bytes(H.hash_to_g2_prehashed(msgs[32 * i:32 * (i + 1)], util.hash512))
+             for i in (0, n // 2, n - 1)) and len(set(got[192 * i:192 * (i + 1)] for i in range(0, n, max(1, n // 512)))) > 1
+    dtm = env.max_over_ranks(dt)
+    oks = env.gather_objects(ok)
+    if env.rank == 0:
+        if not all(oks):
+            raise SystemExit("result mismatch -- bench invalid")
+        # algorithmic work per message: 2 encodings x 5 fixed powers of ~380 squarings + 64 projective G2 steps of cofactor clearing
+        mac = (2 * 5 * 380 * 2 + 2 * 64 * 36 + 400) * MAC_PER_FQ_MUL
+        print(json.dumps({
+            "metric": "hash-to-G2 messages/sec", "value": n * env.world / dtm, "unit": "messages/s", "n_gpus": env.world, "steps": reps,
+            "warmup": 1, "ms_per_step": dtm * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "hash_to_point_prehashed_Fq2 of %d message hashes per GPU (SHA-256 chain, two SW encodings, cofactor clearing)" % n,
+                       "name": "h2c", "check": "3 messages against the host integer code (itself pinned to the reference's vectors)"},
+            "roofline": {"bound": "valu-int32-mac", "kernel": "k_pow + k_h2c_stage + k_h2c_clear", "peak": PEAK_TMACS, "unit": "TMAC/s",
+                         "achieved": mac * n / dt / 1e12, "frac": mac * n / dt / 1e12 / PEAK_TMACS, "traffic": None}}))
+
+
+def dry_run(args):
+    """what a test without a GPU can check of the multi-rank path: self-launch, rendezvous, the exchange"""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    got = [torch.full((144,), rank, dtype=torch.int32)]
+    if world > 1:
+        dist.init_process_group("gloo")
+        got = [torch.zeros(144, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(got, torch.full((144,), rank, dtype=torch.int32))
         dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_in_process_group": dist.get_world_size() if world > 1 else 1,
+                          "partials_seen_from": [int(t[0]) for t in got]}))
+    if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5", "h2c"])
+    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="c2: pairs per GPU per verification")
+    ap.add_argument("--verifications", type=int, default=VERIFICATIONS_PER_STEP,
+                    help="c2: independent aggregate verifications per step (one launch sequence)")
+    ap.add_argument("--pairs-total", type=int, default=C3_PAIRS, help="c3: pairs of the one multi-pairing, over all GPUs")
+    ap.add_argument("--groups", type=int, default=10000, help="c4: threshold groups per GPU")
+    ap.add_argument("--points", type=int, default=1 << 20, help="c5: points per GPU")
+    ap.add_argument("--messages", type=int, default=16384, help="h2c: messages per GPU")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="steps in flight (the final exponentiations of one step overlap the Miller loops of the next)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: CPU-side collective, for rehearsing the multi-rank path on one GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch path only (no GPU): form the process group, all-gather one 576-byte partial per rank over gloo, report")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.dry_run:
+        return dry_run(args)
+    if args.config in ("c4", "c5", "h2c") and args.steps == 48:
+        args.steps = 3
+    env = Env(args)
+    if env.world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, env.world))
+    {"c2": run_pairing, "c3": run_pairing, "c4": run_c4, "c5": run_c5, "h2c": run_h2c}[args.config](env, args)
+    env.finish()
 
 
 if __name__ == "__main__":

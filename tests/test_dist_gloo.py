@@ -108,3 +108,20 @@ def test_two_ranks_match_reference(golden, oracle):
         assert p.exitcode == 0
     want = golden("pairing.json")["seeded"]["8"]["out"]
     assert res[0] == res[1] == want
+
+
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it must start its own ranks (a child
+    torch.distributed.run) -- the way the driver's scaling sweep calls it.  --dry-run stops before
+    any GPU work: rendezvous on 127.0.0.1, one 576-byte partial per rank all-gathered over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_in_process_group"] == 2 and line["partials_seen_from"] == [0, 1]
