@@ -528,6 +528,14 @@ def gen_scheme():
                         for h, pk in zip(sF.aggregation_info.message_hashes,
                                          sF.aggregation_info.public_keys)],
          "quotient": sig_rec(quo), "verify_quotient": BLS.verify(quo)}
+    # dividing by an aggregate (tests.py:191-198)
+    s7, s8 = sk2.sign(m3), sk2.sign(m4)
+    sR2 = BLS.aggregate_sigs([s7, s8])
+    sF2 = BLS.aggregate_sigs([sF, sR2])
+    quo2 = sF2.divide_by([sR2])
+    n["quotient2"] = sig_rec(quo2)
+    n["verify_quotient2"] = BLS.verify(quo2)
+    assert n["quotient2"].startswith("06af6930bd06838f2e4b00b62911fb29")          # the hex of tests.py:198
     out["nested"] = n
     # (de)serialisation round trips
     ser = []

@@ -238,3 +238,68 @@ def test_lane_bucket_method_degenerate(lane_engine, engine, golden):
     assert lane_engine.g1_msm(P * 3, [0, 0, 0], 3) == (bytes(96), [True])
     assert lane_engine.g1_msm(P + bytes(96), [7, 9], 2) == engine.g1_msm(P, [7], 1)
     assert lane_engine.g1_msm(P * 40, [5] * 40, 40) == engine.g1_msm(P, [200], 1)
+
+
+N_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+def _prf(tag, seed, i):
+    import hashlib
+    return int.from_bytes(hashlib.sha256(tag + seed.to_bytes(4, "big") + i.to_bytes(4, "big")).digest(), "big") % (N_ORDER - 1) + 1
+
+
+def test_c4_full_size_10000_groups(engine, golden):
+    """BASELINE configs[3] at full size with the DEFAULT kernel selection: 10 000 threshold groups of
+    k = 67 shares.  Group g's Lagrange weights are the reference's times c_g, so its combine must be
+    c_g x the reference's combined signature (threshold.json, reference-generated) and
+    e(-G1, sig_g) e(c_g pk, H(m)) must be one for every group."""
+    from bls_py import hostmath as H, util
+    from bls_py.keys import PublicKey
+    th = golden("threshold.json")["67_of_100"]
+    groups, k = 10000, 67
+    pts = b"".join(bytes.fromhex(s) for s in th["unit_sigs_affine"])
+    lam = [int(x, 16) for x in th["lambdas"]]
+    cg = [1] + [_prf(b"blsgpu/c4", 1, g) for g in range(1, groups)]
+    sc = b"".join(((l * c) % N_ORDER).to_bytes(32, "big") for c in cg for l in lam)
+    got, inf = engine.g2_msm(pts * groups, sc, k, groups)
+    assert not any(inf)
+    gold_pt = bytes.fromhex(th["combined_affine"])
+    assert got[:192] == gold_pt                                       # c_0 = 1: the reference's own combine
+    want, _ = engine.g2_msm(gold_pt * groups, cg, 1, groups)
+    assert got == want
+    pk = PublicKey.from_bytes(bytes.fromhex(th["master_pk"])).value.to_affine()._aff()
+    hm = H.g2_affine_bytes(H.hash_to_g2_prehashed(util.hash256(bytes.fromhex(th["msg"])), util.hash512))
+    ng1 = H.g1_affine_bytes(H.jac_to_affine(H.F1, H.jac_mul(H.F1, H.aff_to_jac(H.F1, H.G1_GEN), N_ORDER - 1)))
+    pks, _ = engine.g1_msm(H.g1_affine_bytes(pk) * groups, cg, 1, groups)
+    pg1 = b"".join(ng1 + pks[96 * g:96 * (g + 1)] for g in range(groups))
+    pg2 = b"".join(got[192 * g:192 * (g + 1)] + hm for g in range(groups))
+    one = (1).to_bytes(48, "big") + bytes(48 * 11)
+    assert engine.pairing_multi_batch(pg1, pg2, 2, groups) == one * groups
+    # one tampered share: that group, and only that group, stops verifying
+    bad = bytearray(pg2)
+    bad[192 * 2 * 777:192 * 2 * 777 + 192] = got[192 * 778:192 * 779]
+    res = engine.pairing_multi_batch(pg1, bytes(bad), 2, groups)
+    assert [g for g in range(groups) if res[576 * g:576 * (g + 1)] != one] == [777]
+
+
+def test_c5_full_size_distinct_points(engine, golden):
+    """BASELINE configs[4] at full size with the DEFAULT kernel selection: one G1 multi-scalar sum over
+    2^20 DIFFERENT points a_i G (PRF scalars), checked by  sum t_i (a_i G) = (sum t_i a_i) G;  and the
+    reference's 1024-key aggregate (msm.json) through the same default path."""
+    gen1 = bytes.fromhex(golden("pairing.json")["gen"]["g1"])
+    n = 1 << 20
+    a = [_prf(b"blsgpu/a", 5, i) for i in range(n)]
+    t = [_prf(b"blsgpu/t", 5, i) for i in range(n)]
+    pts = b""
+    for lo in range(0, n, 1 << 18):
+        p, _ = engine.g1_msm(gen1 * (1 << 18), a[lo:lo + (1 << 18)], 1, 1 << 18)
+        pts += p
+    sample = [pts[96 * i:96 * (i + 1)] for i in range(0, n, 257)]
+    assert len(set(sample)) == len(sample)
+    got, inf = engine.g1_msm(pts, t, n, 1)
+    want, _ = engine.g1_msm(gen1, [sum(x * y for x, y in zip(a, t)) % N_ORDER], 1, 1)
+    assert got == want and not inf[0]
+    # plain sum (scalars = NULL) of the same points
+    got, _ = engine.g1_msm(pts, None, n, 1)
+    want, _ = engine.g1_msm(gen1, [sum(a) % N_ORDER], 1, 1)
+    assert got == want

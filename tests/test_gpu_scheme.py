@@ -133,3 +133,43 @@ def test_verify_batch_on_gpu():
     got = BLS.verify_batch(batch)
     assert got == [True, True, True, True, False, True, True, True]
     assert got == [BLS.verify(s) for s in batch]
+
+
+def test_secure_aggregation_and_division_on_gpu(golden):
+    """SURVEY 8f rank 4 on the HIP provider: the reference's hex vectors for the colliding-message
+    aggregate (tests.py:147), the nested 6-signature aggregate (:172), divide_by (:177, :198) and its
+    error paths (:179-189) -- the secure path's G2 scalar multiples, the divisions' G2 sums and every
+    verify run on the GPU."""
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    s = golden("scheme.json")
+    v = s["vectors"]
+    sk1, sk2 = [PrivateKey.from_seed(bytes.fromhex(x)) for x in v["seeds"]]
+    m = bytes.fromhex(v["msg"])
+    agg = BLS.aggregate_sigs([sk1.sign(m), sk2.sign(m)])            # same message: secure path
+    assert agg.serialize().hex() == v["agg_sig"] and BLS.verify(agg)
+    assert BLS.aggregate_pub_keys([sk1.get_public_key(), sk2.get_public_key()], True).serialize().hex() == v["agg_pk_secure"]
+    sigs = [(sk1, sk2)[k].sign(bytes.fromhex(mm)) for k, mm in zip(v["agg2_signers"], v["agg2_msgs"])]
+    agg2 = BLS.aggregate_sigs(sigs)
+    assert agg2.serialize().hex() == v["agg2_sig"] and BLS.verify(agg2)
+    n = s["nested"]
+    m1, m2, m3, m4 = [bytes.fromhex(x) for x in n["msgs"]]
+    s1, s2, s3, s4, s5, s6 = sk1.sign(m1), sk2.sign(m2), sk2.sign(m1), sk1.sign(m3), sk1.sign(m1), sk1.sign(m4)
+    sL = BLS.aggregate_sigs([s1, s2])
+    sR = BLS.aggregate_sigs([s3, s4, s5])
+    sF = BLS.aggregate_sigs([sL, sR, s6])
+    assert [sL.serialize().hex(), sR.serialize().hex(), sF.serialize().hex()] == [n["sig_L"], n["sig_R"], n["sig_final"]]
+    assert BLS.verify(sL) and BLS.verify(sR) and BLS.verify(sF)
+    quo = sF.divide_by([s2, s5, s6])
+    assert quo.serialize().hex() == n["quotient"] and BLS.verify(quo) and BLS.verify(sF)
+    assert quo.divide_by([]) == quo
+    with pytest.raises(Exception):
+        quo.divide_by([s6])                                       # not a subset (tests.py:179-181)
+    sF.divide_by([s1])                                            # a unique message may be divided
+    with pytest.raises(Exception):
+        sF.divide_by([sL])                                        # s3, s5 share m1 with s1 (tests.py:183-189)
+    s7, s8 = sk2.sign(m3), sk2.sign(m4)
+    sR2 = BLS.aggregate_sigs([s7, s8])
+    sF2 = BLS.aggregate_sigs([sF, sR2])
+    quo2 = sF2.divide_by([sR2])
+    assert BLS.verify(quo2) and quo2.serialize().hex() == n["quotient2"]

@@ -182,6 +182,10 @@ def test_nested_aggregation_and_division(golden):
     sF.divide_by([s1])                    # fine
     with pytest.raises(Exception):
         sF.divide_by([sL])                # not unique
+    s7, s8 = sk2.sign(m3), sk2.sign(m4)         # dividing by an aggregate (tests.py:191-198)
+    sR2 = BLS.aggregate_sigs([s7, s8])
+    quo2 = BLS.aggregate_sigs([sF, sR2]).divide_by([sR2])
+    assert BLS.verify(quo2) and quo2.serialize().hex() == n["quotient2"]
 
 
 def test_verify4_inputs_match_reference(golden):
