@@ -1,8 +1,9 @@
-"""Copy the summaries of gpurun_out/r01 (written by tools/profile_round.sh on the GPU box)
-into profiles/ under round-1 names."""
-import collections, csv, json, os, shutil
+"""Copy the summaries of gpurun_out/<round> (written by tools/profile_round.sh on the GPU box)
+into profiles/ under round names.  ROUND=r02 python tools/collect_profiles.py"""
+import collections, csv, glob, json, os, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.path.join(ROOT, "gpurun_out", "r01")
+RN = os.environ.get("ROUND", "r02")
+R = os.path.join(ROOT, "gpurun_out", RN)
 P = os.path.join(ROOT, "profiles")
 
 
@@ -13,27 +14,53 @@ def json_line(path):
     raise SystemExit("no JSON line in " + path)
 
 
-shutil.copy(os.path.join(R, "kt", "kt_kernel_stats.csv"), os.path.join(P, "r01_bench_kernel_stats.csv"))
-for src, dst in (("bench_default.json", "r01_bench_line.json"), ("kt_bench.json", "r01_bench_line_under_rocprof.json"),
-                 ("bench_2rank_gloo_rehearsal.json", "r01_bench_line_2rank_gloo_rehearsal_on_one_gpu.json")):
-    with open(os.path.join(P, dst), "w") as f:
+def find(d, pat):
+    hits = glob.glob(os.path.join(R, d, "**", pat), recursive=True)
+    if not hits:
+        raise SystemExit("no %s under %s" % (pat, d))
+    return hits[0]
+
+
+shutil.copy(find("kt", "*kernel_stats.csv"), os.path.join(P, RN + "_bench_kernel_stats.csv"))
+for c in ("c4", "c5", "h2c"):
+    shutil.copy(find("kt_" + c, "*kernel_stats.csv"), os.path.join(P, "%s_%s_kernel_stats.csv" % (RN, c)))
+for src, dst in (("bench_default.json", "_bench_line.json"), ("kt_bench.json", "_bench_line_under_rocprof.json"),
+                 ("bench_2rank_gloo_rehearsal.json", "_bench_line_2rank_gloo_rehearsal_on_one_gpu.json"),
+                 ("bench_c3.json", "_bench_c3_line.json"), ("bench_c3_2rank_gloo.json", "_bench_c3_line_2rank_gloo_rehearsal_on_one_gpu.json")):
+    with open(os.path.join(P, RN + dst), "w") as f:
         f.write(json_line(os.path.join(R, src)))
-shutil.copy(os.path.join(R, "configs.jsonl"), os.path.join(P, "r01_configs_c3_c4_c5_h2c.jsonl"))
-rows_out = []
-for p, f in (("pmc_fetch", "f"), ("pmc_write", "w"), ("pmc_sq", "s")):
-    rows = list(csv.DictReader(open(os.path.join(R, p, f + "_counter_collection.csv"))))
-    agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    n = collections.defaultdict(set)
-    for r in rows:
-        k = r["Kernel_Name"].split("(")[0]
-        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        n[k].add(r["Dispatch_Id"])
-    for k, v in agg.items():
-        if "blsgpu" in k:
-            for c, x in v.items():
-                rows_out.append((k, c, len(n[k]), x / len(n[k])))
-with open(os.path.join(P, "r01_bench_pmc_summary.csv"), "w") as f:
-    f.write("kernel,counter,dispatches,average_per_dispatch\n")
-    for k, c, d, x in rows_out:
-        f.write("%s,%s,%d,%.6g\n" % (k, c, d, x))
-print(open(os.path.join(P, "r01_bench_pmc_summary.csv")).read())
+with open(os.path.join(P, RN + "_configs_c4_c5_h2c.jsonl"), "w") as f:
+    for c in ("c4", "c5", "h2c"):
+        f.write(json_line(os.path.join(R, "bench_%s.json" % c)))
+if os.path.exists(os.path.join(R, "sweep_n.jsonl")):
+    shutil.copy(os.path.join(R, "sweep_n.jsonl"), os.path.join(P, RN + "_scaling_curve_single_call.jsonl"))
+
+
+def pmc_rows(dirs):
+    rows_out = []
+    for p in dirs:
+        try:
+            path = find(p, "*counter_collection.csv")
+        except SystemExit:
+            continue
+        rows = list(csv.DictReader(open(path)))
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        n = collections.defaultdict(set)
+        for r in rows:
+            k = r["Kernel_Name"].split("(")[0]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            n[k].add(r["Dispatch_Id"])
+        for k, v in agg.items():
+            if "blsgpu" in k:
+                for c, x in v.items():
+                    rows_out.append((k, c, len(n[k]), x / len(n[k])))
+    return rows_out
+
+
+for name, dirs in ((RN + "_bench_pmc_summary.csv", ("pmc_fetch", "pmc_write", "pmc_sq")),
+                   (RN + "_configs_pmc_summary.csv", ("pmc_c4", "pmc_c5", "pmc_h2c"))):
+    with open(os.path.join(P, name), "w") as f:
+        f.write("kernel,counter,dispatches,average_per_dispatch\n")
+        for k, c, d, x in pmc_rows(dirs):
+            f.write("%s,%s,%d,%.6g\n" % (k, c, d, x))
+print(open(os.path.join(P, RN + "_bench_pmc_summary.csv")).read())

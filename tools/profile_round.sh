@@ -1,18 +1,28 @@
+# Runs on the GPU box (gpurun): the round's bench lines, rocprofv3 kernel stats and PMC passes.
+# ROUND=r02 bash tools/profile_round.sh ; then python tools/collect_profiles.py here copies the summaries into profiles/.
 set -e
+R=${ROUND:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r01
-timeout -k 10 300 python bench.py > gpurun_out/r01/bench_default.json 2> gpurun_out/r01/bench_default.err
+O=gpurun_out/$R
+mkdir -p $O
+timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench done"
-timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --backend gloo --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/r01/bench_2rank_gloo_rehearsal.json 2> gpurun_out/r01/bench_2rank.err
-echo "2-rank rehearsal done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/r01/kt -o kt --output-format csv -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline > gpurun_out/r01/kt_bench.json 2> gpurun_out/r01/kt.err
-echo "kernel trace done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/r01/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline > gpurun_out/r01/pmc_fetch.json 2> gpurun_out/r01/pmc_fetch.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/r01/pmc_write -o w --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline > gpurun_out/r01/pmc_write.json 2> gpurun_out/r01/pmc_write.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS -d gpurun_out/r01/pmc_sq -o s --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline > gpurun_out/r01/pmc_sq.json 2> gpurun_out/r01/pmc_sq.err
+timeout -k 10 200 python bench.py --gpus 2 --backend gloo --steps 8 --warmup 2 > $O/bench_2rank_gloo_rehearsal.json 2> $O/bench_2rank.err
+timeout -k 10 200 python bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err
+timeout -k 10 200 python bench.py --config c3 --gpus 2 --backend gloo --steps 8 --warmup 2 > $O/bench_c3_2rank_gloo.json 2> $O/bench_c3_2rank.err
+for c in c4 c5 h2c; do timeout -k 10 300 python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; done
+echo "config lines done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-latency > $O/kt_bench.json 2> $O/kt.err
+for c in c4 c5 h2c; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt_$c -o kt --output-format csv -- python3 bench.py --config $c --steps 2 > $O/kt_$c.json 2> $O/kt_$c.err
+done
+echo "kernel traces done"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency > $O/pmc_write.json 2> $O/pmc_write.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS -d $O/pmc_sq -o s --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency > $O/pmc_sq.json 2> $O/pmc_sq.err
+for c in c4 c5 h2c; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES FETCH_SIZE WRITE_SIZE -d $O/pmc_$c -o p --output-format csv -- python3 bench.py --config $c --steps 1 > $O/pmc_$c.json 2> $O/pmc_$c.err || echo "pmc $c failed"
+done
 echo "pmc done"
-timeout -k 10 300 python tools/bench_configs.py > gpurun_out/r01/configs.jsonl 2> gpurun_out/r01/configs.err
-echo "configs done"
-cat gpurun_out/r01/bench_default.json
-cat gpurun_out/r01/bench_2rank_gloo_rehearsal.json
-cat gpurun_out/r01/configs.jsonl
+timeout -k 10 200 python tools/sweep_n.py > $O/sweep_n.jsonl 2> $O/sweep_n.err || echo "sweep failed"
+cat $O/bench_default.json
