@@ -101,6 +101,16 @@ int blsgpu_miller_loop_batch_dev(blsgpu_ctx *ctx, const void *d_g1, const void *
 int blsgpu_line_eval_batch(blsgpu_ctx *ctx, const uint8_t *r, const uint8_t *q, const uint8_t *p, size_t n,
                            uint8_t *out);
 
+/* The Fq12 arithmetic of the reference's native module on n elements at once (576 bytes each; an Fq, Fq2 or
+ * Fq6 element is an Fq12 element whose other coefficients are zero):
+ *   op 0 fq12_add (fields_t.py:339-343), 1 fq12_sub (:346-350), 2 fq12_mul (:503-554 / fields_t_c.pyx:824-875),
+ *      3 fq12_neg (:321-325), 4 fq12_invert (:328-337; 0 -> 0 as fq_invert :47-55);  b is ignored for 3 and 4.
+ * blsgpu_fq12_pow_batch: fq12_pow(a_i, e) (:340-353 / fields_t_c.pyx:771-821) for ONE exponent e given as
+ * e_len big-endian bytes. */
+int blsgpu_fq12_op_batch(blsgpu_ctx *ctx, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
+int blsgpu_fq12_pow_batch(blsgpu_ctx *ctx, const uint8_t *a, const uint8_t *e_be, size_t e_len, size_t n,
+                          uint8_t *out);
+
 /* Sharded form (one rank per GPU).  Step 1: the product of the n Miller-loop
  * values of this shard (fq_miller_loop, fields_t.py:1091-1111, folded with
  * fq12_mul as in :1119-1120) as ONE partial of BLSGPU_PARTIAL_WORDS uint32.

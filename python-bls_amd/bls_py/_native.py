@@ -23,6 +23,7 @@ SYMBOLS = (
     "blsgpu_g1_decompress", "blsgpu_g2_decompress", "blsgpu_g1_decompress_dev", "blsgpu_g2_decompress_dev",
     "blsgpu_hash_to_g2", "blsgpu_hash_to_g2_dev",
     "blsgpu_miller_loop_batch", "blsgpu_miller_loop_batch_dev", "blsgpu_line_eval_batch", "blsgpu_ctx_trim",
+    "blsgpu_fq12_op_batch", "blsgpu_fq12_pow_batch",
 )
 
 _lib = None
@@ -67,6 +68,8 @@ def load_library(path=None):
         L.blsgpu_miller_loop_batch.argtypes = [vp, cp, cp, cp, sz, cp]
         L.blsgpu_miller_loop_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
         L.blsgpu_line_eval_batch.argtypes = [vp, cp, cp, cp, sz, cp]
+        L.blsgpu_fq12_op_batch.argtypes = [vp, ctypes.c_int, cp, cp, sz, cp]
+        L.blsgpu_fq12_pow_batch.argtypes = [vp, cp, cp, sz, sz, cp]
         L.blsgpu_miller_product_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
         L.blsgpu_final_exp_product_dev.argtypes = [vp, vp, sz, vp, vp]
         L.blsgpu_final_exp.argtypes = [vp, cp, cp]
@@ -181,6 +184,24 @@ class Engine:
         out = ctypes.create_string_buffer(max(1, len(xs)))
         self._check(self.lib.blsgpu_final_exp_batch(self.h, xs, len(xs) // 576, out), "blsgpu_final_exp_batch")
         return out.raw[:len(xs)]
+
+    FQ12_OPS = {"add": 0, "sub": 1, "mul": 2, "neg": 3, "inv": 4}
+
+    def fq12_op(self, op: str, a: bytes, b: bytes = None) -> bytes:
+        """fq12_add / sub / mul / neg / invert on n elements (n x 576 bytes each)."""
+        if len(a) % 576 or (b is not None and len(b) != len(a)):
+            raise ValueError("need n x 576 bytes")
+        out = ctypes.create_string_buffer(max(1, len(a)))
+        self._check(self.lib.blsgpu_fq12_op_batch(self.h, self.FQ12_OPS[op], a, b, len(a) // 576, out), "blsgpu_fq12_op_batch")
+        return out.raw[:len(a)]
+
+    def fq12_pow(self, a: bytes, e: int) -> bytes:
+        if len(a) % 576 or e < 0:
+            raise ValueError("need n x 576 bytes and a non-negative exponent")
+        eb = e.to_bytes(max(1, (e.bit_length() + 7) // 8), "big")
+        out = ctypes.create_string_buffer(max(1, len(a)))
+        self._check(self.lib.blsgpu_fq12_pow_batch(self.h, a, eb, len(eb), len(a) // 576, out), "blsgpu_fq12_pow_batch")
+        return out.raw[:len(a)]
 
     def pairing_multi_batch(self, g1: bytes, g2: bytes, gsz: int, groups: int, inf=None) -> bytes:
         n = gsz * groups

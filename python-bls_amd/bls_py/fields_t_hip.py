@@ -9,6 +9,7 @@ bls_py/fields_t.py:1256-1263 re-binds from the native module:
     fq12_final_exp(t)                               -> 12-tuple of ints   (fields_t.py:1124-1128)
     fq2_double_line_eval(rx, ry, px, py)            -> 12-tuple of ints   (fields_t.py:1035-1049)
     fq2_add_line_eval(rx, ry, qx, qy, px, py)       -> 12-tuple of ints   (fields_t.py:1052-1078)
+    fq12_mul(a, b), fq12_add(a, b), fq12_invert(a), fq12_pow(a, e)        (fields_t.py:321-554)
 
 Ps = tuple of (x, y, inf), Qs = tuple of ((x0, x1), (y0, y1), inf), ints in [0, q).  The flags
 are passed on as they are: like the reference, the engine never reads P's, and a flagged Q skips
@@ -62,3 +63,23 @@ def fq2_double_line_eval(rx_t, ry_t, px, py, device=0):
 def fq2_add_line_eval(rx_t, ry_t, qx_t, qy_t, px, py, device=0):
     return _unpack12(_native.engine(device).line_eval_batch(_fq2(rx_t) + _fq2(ry_t), _fq2(qx_t) + _fq2(qy_t),
                                                             _fq(px) + _fq(py), 1))
+
+
+def _fq12(t):
+    return b"".join(_fq(v) for v in t)
+
+
+def fq12_mul(a, b, device=0):
+    return _unpack12(_native.engine(device).fq12_op("mul", _fq12(a), _fq12(b)))
+
+
+def fq12_add(a, b, device=0):
+    return _unpack12(_native.engine(device).fq12_op("add", _fq12(a), _fq12(b)))
+
+
+def fq12_invert(a, device=0):
+    return _unpack12(_native.engine(device).fq12_op("inv", _fq12(a)))
+
+
+def fq12_pow(a, e, device=0):
+    return _unpack12(_native.engine(device).fq12_pow(_fq12(a), e))

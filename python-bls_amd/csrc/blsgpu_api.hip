@@ -741,6 +741,49 @@ BLSGPU_EXPORT int blsgpu_line_eval_batch(blsgpu_ctx* c, const uint8_t* r, const 
     return 0;
 }
 
+// Fq12 field operations on n elements (op: 0 add, 1 sub, 2 mul, 3 neg, 4 invert), or a^e for one exponent
+namespace {
+int fq12_op_host(blsgpu_ctx* c, uint32_t op, const uint8_t* a, const uint8_t* b, const uint8_t* ebits, size_t nbits, size_t n, uint8_t* out) {
+    if (!c || (n && (!a || !out)) || (n && op <= 2 && !b)) return fail(-EINVAL, "NULL argument");
+    if (n == 0) return 0;
+    if (n > 0x00FFFFF0ull || nbits > 0x10000) return fail(-EINVAL, "too large");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t need = n * BLSGPU_FQ12_BYTES * 3 + nbits + 64;
+    if (int rc_ = grow_buffer(c, &c->d_io, &c->io_cap, need)) return rc_;
+    StreamGuard sg(c, nullptr);
+    char* dout = (char*)c->d_io;
+    char* da = dout + n * BLSGPU_FQ12_BYTES;
+    char* db = da + n * BLSGPU_FQ12_BYTES;
+    char* de = db + n * BLSGPU_FQ12_BYTES;
+    HIP_TRY(hipMemcpyAsync(da, a, n * BLSGPU_FQ12_BYTES, hipMemcpyHostToDevice, 0));
+    if (op <= 2) HIP_TRY(hipMemcpyAsync(db, b, n * BLSGPU_FQ12_BYTES, hipMemcpyHostToDevice, 0));
+    if (nbits) HIP_TRY(hipMemcpyAsync(de, ebits, nbits, hipMemcpyHostToDevice, 0));
+    const unsigned grid = (unsigned)(n < 16384 ? n : 16384);
+    hipLaunchKernelGGL(blsgpu::k_fq12_op, dim3(grid), dim3(64), (size_t)blsgpu::SLOW_TEAM_BYTES, 0, c->tabs, op, (const uint32_t*)da,
+                       (const uint32_t*)db, (const uint8_t*)de, (uint32_t)nbits, (uint32_t)n, (uint32_t*)dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, n * BLSGPU_FQ12_BYTES, hipMemcpyDeviceToHost));
+    return 0;
+}
+}  // namespace
+BLSGPU_EXPORT int blsgpu_fq12_op_batch(blsgpu_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+    if (op < 0 || op > 4) return fail(-EINVAL, "bad op");
+    return fq12_op_host(c, (uint32_t)op, a, b, nullptr, 0, n, out);
+}
+BLSGPU_EXPORT int blsgpu_fq12_pow_batch(blsgpu_ctx* c, const uint8_t* a, const uint8_t* e_be, size_t e_len, size_t n, uint8_t* out) {
+    if (n && (!e_be && e_len)) return fail(-EINVAL, "NULL exponent");
+    // exponent bytes (big-endian) -> bits, most significant first, leading zeros dropped
+    std::vector<uint8_t> bits;
+    bool started = false;
+    for (size_t i = 0; i < e_len; i++)
+        for (int k = 7; k >= 0; k--) {
+            const uint8_t bit = (e_be[i] >> k) & 1;
+            started = started || bit;
+            if (started) bits.push_back(bit);
+        }
+    return fq12_op_host(c, 5u, a, nullptr, bits.data(), bits.size(), n, out);
+}
+
 // m independent final exponentiations: fq12_final_exp on each 576-byte element
 BLSGPU_EXPORT int blsgpu_final_exp_batch(blsgpu_ctx* c, const uint8_t* in, size_t m, uint8_t* out) {
     if (!c || (m && (!in || !out))) return fail(-EINVAL, "NULL argument");

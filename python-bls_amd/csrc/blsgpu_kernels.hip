@@ -652,6 +652,49 @@ __global__ void __launch_bounds__(64) k_miller_exact(VmTables T, const uint32_t*
     }
 }
 
+// Fq12 operations on byte inputs, one element (pair) per wavefront: op 0 add, 1 sub, 2 mul, 3 neg, 4 invert
+// (fq12_add / fq12_sub / fq12_mul / fq12_neg / fq12_invert, fields_t.py:321-352, 503-554, 328-337; 0^-1 = 0),
+// 5 = power by the exponent bits ebits[0 .. nbits) (most significant first; fq12_pow, fields_t.py:340-353).
+// Fq, Fq2 and Fq6 elements are Fq12 elements with the other coefficients zero.
+#define BLSGPU_SEG(NAME) T.segflat + BLSVM_SEGF_##NAME##_OFF, BLSVM_SEGF_##NAME##_LEN
+__global__ void __launch_bounds__(64) k_fq12_op(VmTables T, uint32_t op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                const uint8_t* __restrict__ ebits, uint32_t nbits, uint32_t n,
+                                                uint32_t* __restrict__ out_bytes) {
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    team_init_consts(T, team, lane);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        wave_fence();
+        for (uint32_t k = lane; k < 144; k += 64) team[R1_DW + (k / 12) * 12 + (11 - k % 12)] = bswap32(a[(size_t)i * 144 + k]);
+        wave_fence();
+        run_rounds<true>(T, BLSGPU_SEG(TO_MONT_0_1), 0, lane);                   // register 0 = a
+        if (op <= 2u) {
+            wave_fence();
+            for (uint32_t k = lane; k < 144; k += 64) team[R1_DW + (k / 12) * 12 + (11 - k % 12)] = bswap32(b[(size_t)i * 144 + k]);
+            wave_fence();
+            run_rounds<true>(T, BLSGPU_SEG(TO_MONT_1_1), 0, lane);               // register 1 = b
+            if (op == 0u) run_rounds<true>(T, BLSGPU_SEG(ADD_0_1), 0, lane);
+            else if (op == 1u) run_rounds<true>(T, BLSGPU_SEG(SUB_0_1), 0, lane);
+            else run_rounds<true>(T, BLSGPU_SEG(MUL_0_1), 0, lane);
+        } else if (op == 3u) {
+            run_rounds<true>(T, BLSGPU_SEG(NEG_0_0), 0, lane);
+        } else if (op == 4u) {
+            run_rounds(T, BLSGPU_SEG(INV12_2_0), 0, lane);
+            run_rounds<true>(T, BLSGPU_SEG(COPY_0_2), 0, lane);
+        } else {
+            run_rounds<true>(T, BLSGPU_SEG(COPY_1_0), 0, lane);                  // register 1 = base
+            run_rounds<true>(T, BLSGPU_SEG(SET_ONE_0), 0, lane);
+            for (uint32_t k = 0; k < nbits; ++k) {                               // the reference's loop squares and multiplies too
+                run_rounds<true>(T, BLSGPU_SEG(MUL_0_0), 0, lane);
+                if (ebits[k]) run_rounds<true>(T, BLSGPU_SEG(MUL_0_1), 0, lane);
+            }
+        }
+        wave_fence();
+        write_acc_bytes(T, team, lane, out_bytes + (size_t)i * 144);
+    }
+}
+#undef BLSGPU_SEG
+
 // fq2_double_line_eval(R, P) (fields_t.py:1035-1049; q == nullptr) / fq2_add_line_eval(R, Q, P)
 // (:1052-1078) for n triples: r, q n x 192 bytes, p n x 96 bytes -> n x 576 bytes.
 __global__ void __launch_bounds__(64) k_line_eval(VmTables T, const uint32_t* __restrict__ r, const uint32_t* __restrict__ q,

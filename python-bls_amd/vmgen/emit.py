@@ -173,6 +173,7 @@ def limbs32(v):
 
 
 DIRECT_SEGS = ["mul_0_1", "from_mont_1_0", "to_mont_0_1", "copy_1_0", "line_dbl", "line_add",     # called by name from the kernels
+               "to_mont_1_1", "set_one_0", "mul_0_0", "add_0_1", "sub_0_1", "neg_0_0", "inv12_2_0", "copy_0_2",
                "h1_a", "h1w_a", "h1_b", "h1_c", "d1_a", "d1_c", "d2_a", "d2_b", "d2_c"]
 POW_SEG = re.compile(r"^(h1_(sqr|mul)[23]|d1_(sqr|mul)|d2[pq]_(sqr|mul))$")
 MSM_NP = {1: 6, 2: 2}                                         # points per team in the MSM kernels

@@ -393,6 +393,21 @@ def seg_cyc_sqr(cfg, n, d):
     return b
 
 
+def seg_addsub(d, a, sign):
+    b = Builder("%s_%d_%d" % ("add" if sign > 0 else "sub", d, a))    # R[d] <- R[d] +- R[a]  (fq12_add / fq12_sub, fields_t.py:339-352)
+    x, y = [b.inp(reg(d) + i) for i in range(12)], [b.inp(reg(a) + i) for i in range(12)]
+    for i in range(12):
+        b.out(x[i] + y[i] if sign > 0 else x[i] - y[i], reg(d) + i)
+    return b
+
+
+def seg_neg(d, a):
+    b = Builder("neg_%d_%d" % (d, a))      # R[d] <- -R[a]
+    for i in range(12):
+        b.out(-b.inp(reg(a) + i), reg(d) + i)
+    return b
+
+
 def seg_copy(d, a):
     b = Builder("copy_%d_%d" % (d, a))    # R[d] <- R[a]
     out12(b, in12(b, reg(a)), reg(d))
@@ -455,6 +470,9 @@ SEG_FACTORY = {
     "cyc_sqr2": lambda cfg, *r: seg_cyc_sqr(cfg, 2, *r),
     "cyc_sqr1": lambda cfg, *r: seg_cyc_sqr(cfg, 1, *r),
     "copy": lambda cfg, *r: seg_copy(*r),
+    "add": lambda cfg, *r: seg_addsub(*r, 1),
+    "sub": lambda cfg, *r: seg_addsub(*r, -1),
+    "neg": lambda cfg, *r: seg_neg(*r),
     "conj": lambda cfg, *r: seg_conj(*r),
     "frob1": lambda cfg, *r: seg_frob(cfg, 1, *r),
     "frob2": lambda cfg, *r: seg_frob(cfg, 2, *r),
@@ -543,7 +561,8 @@ def build_all(cfg=None, verbose=False):
     for name in sorted(set(mscript[1:])):
         builders.append(seg_body(lazy, int(name[5]), int(name[6])))
     fscript = final_exp_script()
-    extra = ["from_mont_1_0", "to_mont_0_1", "to_mont_1_1", "set_one_0", "mul_0_1", "copy_0_1", "copy_1_0"]
+    extra = ["from_mont_1_0", "to_mont_0_1", "to_mont_1_1", "set_one_0", "mul_0_1", "copy_0_1", "copy_1_0",
+             "mul_0_0", "add_0_1", "sub_0_1", "neg_0_0", "inv12_2_0", "copy_0_2"]      # blsgpu_fq12_op_batch / blsgpu_fq12_pow
     for name in sorted(set(fscript + extra)):
         builders.append(seg_by_name(lazy if name.startswith("mul_") else cfg, name))
     segs = {}
