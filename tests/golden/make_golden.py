@@ -685,6 +685,9 @@ if __name__ == "__main__":
     if "seeded8192" in only:                # opt-in: ~10 minutes of pure Python
         gen_seeded_digest(8192)
         only = [a for a in only if a != "seeded8192"] or ["-"]
+    if "seeded65536" in only:               # opt-in: ~80 minutes of pure Python (BASELINE configs[2] at full size)
+        gen_seeded_digest(65536)
+        only = [a for a in only if a != "seeded65536"] or ["-"]
     for name, fn in gens.items():
         if not only or name in only:
             print("==", name)
