@@ -362,3 +362,35 @@ def test_batched_many_groups_sliced(engine, golden):
     out = engine.pairing_multi_batch(a * groups, b * groups, 24, groups)
     one = engine.pairing_multi(a, b, 24)
     assert out == one * groups
+
+
+def test_two_streams_on_one_context_and_growing_workspace(golden, seeded_pairs):
+    """One context used from two streams, with batch sizes that make the workspace grow while work is
+    enqueued: calls on different streams are ordered on the device (include/blsgpu.h "Threading and
+    streams"), replaced buffers stay alive until blsgpu_ctx_trim."""
+    import torch
+    from bls_py import _native
+    eng = _native.Engine(0)                                   # a fresh context: small initial workspace
+    g1, g2 = seeded_pairs
+    dev = torch.device("cuda:0")
+    t1 = torch.frombuffer(bytearray(g1 * 9), dtype=torch.uint8).to(dev)
+    t2 = torch.frombuffer(bytearray(g2 * 9), dtype=torch.uint8).to(dev)
+    s = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    sizes = [64, 1025, 300, 4100, 1025, 9225, 8, 1025]        # 4100 and 9225 pairs outgrow the 4096-pair default
+    outs = [torch.zeros(576, dtype=torch.uint8, device=dev) for _ in sizes]
+    for k, n in enumerate(sizes):
+        eng.pairing_multi_dev(t1.data_ptr(), t2.data_ptr(), n, outs[k].data_ptr(), s[k % 2].cuda_stream)
+    torch.cuda.synchronize()
+    want1025 = golden("pairing.json")["seeded"]["1025"]["out"]
+    ref = _native.engine(0)
+    for k, n in enumerate(sizes):
+        got = bytes(outs[k].cpu().numpy())
+        if n == 1025:
+            assert got.hex() == want1025
+        else:
+            assert got == ref.pairing_multi((g1 * 9)[:96 * n], (g2 * 9)[:192 * n], n), n
+    eng.trim()
+    eng.pairing_multi_dev(t1.data_ptr(), t2.data_ptr(), 1025, outs[0].data_ptr(), s[1].cuda_stream)
+    torch.cuda.synchronize()
+    assert bytes(outs[0].cpu().numpy()).hex() == want1025
+    eng.close()
