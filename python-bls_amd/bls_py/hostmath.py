@@ -76,11 +76,22 @@ def f2_pow(a, e):
     return r
 
 
+class RealSquareRoot(Exception):
+    """What the reference's y_for_x ends in for a G2 x whose u = x^3 + b' has zero imaginary part and a
+    square real part: Fq2.modsqrt returns an Fq there (fields.py:466-467) and the AffinePoint constructor
+    refuses mixed coordinate types with Exception('x,y should be field elements') (ec.py:24-30)."""
+
+
 def f2_sqrt(a):
-    """fields.py:463-482 (complex method)."""
+    """fields.py:463-482 (complex method).  Zero imaginary part: the reference's branch returns an
+    element of Fq, which no caller can use -- ValueError when a0 is no square of Fq (fields.py:199-205),
+    RealSquareRoot where the reference's caller y_for_x fails on the type of the root."""
     a0, a1 = a[0] % Q, a[1] % Q
     if a1 == 0:
-        return (fq_sqrt(a0), 0)
+        if a0 == 0:
+            return (0, 0)
+        fq_sqrt(a0)                                  # ValueError('No sqrt exists') for a non-residue
+        raise RealSquareRoot("x,y should be field elements")
     alpha = (a0 * a0 + a1 * a1) % Q
     if pow(alpha, (Q - 1) // 2, Q) == Q - 1:
         raise ValueError("No sqrt exists")
@@ -314,7 +325,7 @@ def sw_encode(F, t):
         try:
             y_for_x(F, x)
             return 1
-        except ValueError:
+        except (ValueError, RealSquareRoot):          # the reference: a bare `except` (ec.py:489-498)
             return -1
     a, b = ok(x1), ok(x2)
     x = (x1, x2, x3)[((a - 1) * b) % 3]

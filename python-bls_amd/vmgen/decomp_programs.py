@@ -13,10 +13,11 @@ validity flag comes out beside the point):
       delta = (a0 +- r)/2, x0 = sqrt(delta), x1 = a1 / (2 x0).  Both delta candidates are
       exponentiated side by side and the reference's pick (the first one unless its
       Legendre symbol is -1) is an arithmetic select.  The reference's separate branch
-      for a1 = 0 (y = (sqrt(a0), 0), invalid when a0 is not a square) falls out of the
-      same formulas: then r = a0 chi(a0), so delta+ = a0 exactly when a0 is a square,
-      x1 = 0, and validity is chi(delta+) = 1:
-          valid = ind(chi(alpha)) * (nz(a1) + (1 - nz(a1)) ind(chi(delta+))).
+      for a1 = 0 returns an element of Fq (fields.py:466-467), which y_for_x cannot use:
+      it ends in ValueError (a0 no square of Fq, or u = 0) or in the AffinePoint constructor's
+      Exception('x,y should be field elements') -- Signature.from_bytes rejects EVERY encoding
+      whose u has zero imaginary part (tests/golden/g2_real_u.json, reference-generated):
+          valid = ind(chi(alpha)) * nz(a1).
       Choice of the root (signature.py:31-35): the other root -y is taken iff
       (big and (-y).c1 > q/2) or (not big and (-y).c1 < q/2), i.e. with g = [y.c1 > q/2]
       and z = [y.c1 = 0] = 1 - nz(a1):  flip = big xor (g + z).
@@ -162,7 +163,7 @@ def build_d2(NE, cfg=None, verbose=False):
         c = (one - ((chi[0] * chi[0] - chi[0]) * inv2)).mat()
         x0 = (sq[1] + c * (sq[0] - sq[1])).mat()
         x1 = (a1 * (x0 * 2).inv()).mat()
-        valid = (va * (nz + (one - nz) * _ind(chi[0], inv2))).mat()
+        valid = (va * nz).mat()
         t = (x1.sgn() + one - nz).mat()                           # g + z
         flip = (big + t - (big * t) * 2).mat()
         y0 = (x0 - (flip * x0) * 2).mat()

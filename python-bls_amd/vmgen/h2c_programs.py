@@ -13,13 +13,19 @@ sign flip) is restated branch-free:
     delta = (a0 +/- alpha)/2 -- both candidates are exponentiated side by side
     and the one the reference would pick is selected by its Legendre symbol;
   * sign: SGN rounds evaluate "imaginary part > (q-1)/2" (ec.py:94-100).
+A candidate x whose u = x^3 + b' has ZERO imaginary part is skipped by the reference although u is a
+square of Fq2: Fq2.modsqrt returns an Fq there (fields.py:466-467), y_for_x fails on it and sw_encode's bare
+`except` counts the candidate as invalid (ec.py:489-498).  Restated: the norm handed to the symbol test is
+n' = nz(a1) N(u) and the selector is the exact indicator of chi(n') = 1, so a1 = 0 (which includes u = 0)
+gives 0.  (If the LAST candidate x3 is of that kind, or x1 is and u2, u3 are non-squares, the reference's
+sw_encode raises -- ec.py:503; there is nothing to reproduce then, and hashed inputs never get there.)
+Reference-generated vectors: tests/golden/g2_real_u.json.
 The reference's early exit for t = 0 (ec.py:450-452) is kept as a flag
 nz(t) = t (1/t) in {0, 1} (the VM's inversion maps 0 to 0): t = 0 gives the point
 at infinity, Z = 0 in the projective triple handed to kernel H2, whose additions
 are complete.  Its other exit, w = t^2 + b' + 1 = 0 (ec.py:466-473), cannot
 happen over Fq2: -(5 + 4i) is not a square there (tests/test_vm_h2c.py).  Not covered: an encoding whose
-chosen x has x^3 + b' with zero imaginary part or zero norm (the reference takes
-another square-root branch there; needs t built from a known curve point).
+LAST candidate has x^3 + b' with zero imaginary part (the reference raises there).
 
 Kernel H1 (h1_*):  NE encodings per team -> affine points S_e.
 Kernel H2 (h2_*):  NM messages per team: P = S_0 + S_1, cofactor clearing, affine bytes.
@@ -160,6 +166,7 @@ def build_h1(NE, cfg=None, verbose=False, wide=False):
             u = cfg.mul2(cfg.sqr2(x), x)
             u = tw.f2_mat((u[0] + one * 4, u[1] + one * 4))
             n = (u[0] * u[0] + u[1] * u[1]).mat()
+            n = (n * (u[1] * u[1].inv()).mat()).mat()              # n' = nz(a1) N(u)
             k = 3 * e + i
             b.out(x[0], L.X + 2 * k), b.out(x[1], L.X + 2 * k + 1)
             b.out(u[0], L.U + 2 * k), b.out(u[1], L.U + 2 * k + 1)
@@ -185,8 +192,8 @@ def build_h1(NE, cfg=None, verbose=False, wide=False):
             k = 3 * e + i
             z, n = b.inp(L.ACC + k), b.inp(L.N + k)
             r = (z * n).mat()
-            chi = r * z
-            c.append(((one + chi) * inv2).mat())
+            chi = (r * z).mat()
+            c.append(((chi * chi + chi) * inv2).mat())             # 1 iff chi = 1 (0 for chi = -1 and for n' = 0)
             rr.append(r)
         xs = [_c2(b, L.X + 2 * (3 * e + i)) for i in range(3)]
         us = [_c2(b, L.U + 2 * (3 * e + i)) for i in range(3)]

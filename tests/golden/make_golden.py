@@ -400,6 +400,74 @@ def gen_lines():
     dump("lines.json", out)
 
 
+def gen_real_u():
+    """G2 x coordinates whose u = x^3 + 4(1+i) has ZERO imaginary part.  Fq2.modsqrt (fields.py:463-467)
+    then returns an Fq, not an Fq2: y_for_x raises -- Exception('x,y should be field elements') from the
+    AffinePoint constructor when u is a square of Fq, ValueError('No sqrt exists') when it is not -- so
+    Signature.from_bytes rejects such an encoding and sw_encode's bare `except` (ec.py:489-498) skips such a
+    candidate.  Recorded: encodings with the reference's verdict, and values t whose FIRST candidate x1 is
+    of this kind, with the reference's sw_encode and full hash-to-G2 tail."""
+    import random
+    from bls_py.ec import y_for_x, psi
+    rng = random.Random(11)
+    ect = default_ec_twist
+
+    def craft(want_qr):
+        while True:
+            b = rng.randrange(1, Q)
+            rhs = (b * b * b - 4) * pow(3 * b, Q - 2, Q) % Q          # a^2 with 3 a^2 b - b^3 + 4 = 0
+            if pow(rhs, (Q - 1) // 2, Q) != 1:
+                continue
+            x = Fq2(Q, pow(rhs, (Q + 1) // 4, Q), b)
+            u = x * x * x + ect.b
+            assert int(u[1]) == 0
+            if (pow(int(u[0]), (Q - 1) // 2, Q) == 1) == want_qr:
+                return x
+    out = {"decompress": [], "sw_encode": []}
+    for want in (True, False, True, False):
+        x = craft(want)
+        for sign in (0, 0x80):
+            enc = bytearray(x.serialize())
+            enc[0] |= sign
+            try:
+                Signature.from_bytes(bytes(enc))
+                verdict = "accepted"
+            except Exception as e:                                   # noqa: BLE001
+                verdict = type(e).__name__
+            assert verdict in ("Exception", "ValueError")
+            out["decompress"].append({"encoding": bytes(enc).hex(), "u_is_square_in_fq": want, "reference": verdict})
+    s3, c1 = Fq2(Q, ect.sqrt_n3, 0), Fq2(Q, ect.sqrt_n3m1o2, 0)
+    B = ect.b + Fq2(Q, 1, 0)
+    while len(out["sw_encode"]) < 4:
+        x1 = craft(len(out["sw_encode"]) % 2 == 0)
+        z = -B * (x1 - c1) * ~(x1 - c1 + s3)                          # t^2 such that the first candidate is x1
+        try:
+            t = z.modsqrt()
+        except ValueError:
+            continue
+        if type(t) is not Fq2 or t * t != z:
+            continue
+        t1 = Fq2(Q, rng.randrange(Q), rng.randrange(Q))
+        try:
+            P0 = sw_encode(t, ect, Fq2)
+        except ValueError:
+            # x1 is the only candidate with a square u (u2, u3 are both non-squares then): the
+            # reference itself fails on this t (ec.py:503 raises) -- nothing to compare
+            continue
+        assert P0.x != x1                                            # the reference skipped x1
+        Pt = P0 + sw_encode(t1, ect, Fq2)
+        xx = -ect.x                                                  # the tail of hash_to_point_prehashed_Fq2 (ec.py:541-550)
+        psi2P = psi(psi(2 * Pt, ect), ect)
+        a0 = xx * Pt
+        a1 = xx * a0
+        a2 = (a1 + a0) - Pt
+        a3 = psi((xx + 1) * Pt, ect)
+        R = (a2 - a3 + psi2P)
+        out["sw_encode"].append({"t": tup_hex(t.ZT) + tup_hex(t1.ZT), "skipped_x1": tup_hex(x1.ZT),
+                                 "sw_encode_t0": g2_bytes(P0).hex(), "point": g2_bytes(R.to_affine() if hasattr(R, "to_affine") else R).hex()})
+    dump("g2_real_u.json", out)
+
+
 def gen_seeded_digest(n=8192):
     """SHA-256 of the reference's multi-pairing of the first n PRF-seeded pairs (SURVEY 8c F-PAIR),
     with digests of the inputs so that a test can rebuild them from the PRF alone."""
@@ -681,7 +749,7 @@ if __name__ == "__main__":
     gens = {"fields": gen_fields, "pairing": lambda: gen_pairing(big),
             "verify4": gen_verify4, "scheme": gen_scheme,
             "hash": gen_hash_to_curve, "threshold": lambda: gen_threshold(big),
-            "msm": lambda: gen_msm(big), "points": gen_points, "degenerate": gen_degenerate, "lines": gen_lines}
+            "msm": lambda: gen_msm(big), "points": gen_points, "degenerate": gen_degenerate, "lines": gen_lines, "real_u": gen_real_u}
     if "seeded8192" in only:                # opt-in: ~10 minutes of pure Python
         gen_seeded_digest(8192)
         only = [a for a in only if a != "seeded8192"] or ["-"]

@@ -15,7 +15,7 @@ Q = H.Q
 def host(deg, enc):
     try:
         A = (H.g1_decompress if deg == 1 else H.g2_decompress)(enc)
-    except ValueError:
+    except (ValueError, H.RealSquareRoot):
         return None
     return H.g1_affine_bytes(A) if deg == 1 else H.g2_affine_bytes(A)
 
@@ -60,14 +60,18 @@ def test_random_and_rejected_encodings(engine):
     assert engine.g1_decompress(b"") == (b"", [])
 
 
-def test_g2_real_u_branch(engine):
-    """x^3 + 4(1+i) real: the reference's `a1 == 0` branch of Fq2.modsqrt, both outcomes."""
+def test_g2_real_u_branch(engine, golden):
+    """x^3 + 4(1+i) real: the reference's `a1 == 0` branch of Fq2.modsqrt returns an Fq and
+    Signature.from_bytes raises for every such encoding (tests/golden/g2_real_u.json, reference-generated)."""
     from test_vm_decompress import fq2_cube_roots_with_real_u, encode
     xs = fq2_cube_roots_with_real_u(6)
     encs = [encode(2, x, big) for x in xs for big in (False, True)]
-    got = [host(2, e) is not None for e in encs]
-    assert any(got) and not all(got)
+    assert not any(host(2, e) is not None for e in encs)
     compare(engine, 2, encs)
+    recs = golden("g2_real_u.json")["decompress"]
+    assert all(r["reference"] in ("Exception", "ValueError") for r in recs)
+    _, ok = engine.g2_decompress(b"".join(bytes.fromhex(r["encoding"]) for r in recs))
+    assert not any(ok)
 
 
 def test_round_trip_at_size(engine, seeded_pairs):

@@ -101,3 +101,11 @@ def test_one_message_per_lane_clearing(golden):
         got = e.hash_to_g2(msgs)
         assert got == _native.engine(0).hash_to_g2(msgs)                # the VM form (default engine, small batch)
         assert got[:192] == H.g2_affine_bytes(H.hash_to_g2_prehashed(msgs[:32], hash512))
+
+
+def test_candidate_with_real_u_is_skipped(engine, golden):
+    """tests/golden/g2_real_u.json (reference-generated): t whose first Shallue-van de Woestijne candidate has
+    a u with zero imaginary part -- the reference skips it; blsgpu_map_to_g2 must return the reference's point."""
+    recs = golden("g2_real_u.json")["sw_encode"]
+    out = engine.map_to_g2(b"".join(bytes.fromhex(r["t"]) for r in recs))
+    assert out.hex() == "".join(r["point"] for r in recs)

@@ -1,7 +1,8 @@
 """Decompression VM programs (vmgen.decomp_programs) in the Python interpreter against
 the host integer implementation (bls_py.hostmath.g1_/g2_decompress, pinned to the
-reference by the serialisation vectors of tests/golden/scheme.json), including the
-inputs the reference rejects and its a1 = 0 square-root branch.  CPU only."""
+reference by the serialisation vectors of tests/golden/scheme.json and by the reference-generated
+verdicts of tests/golden/g2_real_u.json), including the inputs the reference rejects -- among them every
+G2 x whose u = x^3 + b' has zero imaginary part (Fq2.modsqrt's a1 = 0 branch, fields.py:466-467).  CPU only."""
 import random
 
 import pytest
@@ -45,7 +46,7 @@ def check(progs, deg, xs, bigs):
     for x, big, o in zip(xs, bigs, got):
         try:
             want = (H.g1_decompress if deg == 1 else H.g2_decompress)(encode(deg, x, big))
-        except ValueError:
+        except (ValueError, H.RealSquareRoot):
             assert o[-1] == 0
             continue
         accepted += 1
@@ -112,5 +113,25 @@ def test_g2_random_special_and_edges(progs):
     for i in range(0, 8, NE):
         ok += check(progs, 2, special[i:i + NE], [False, True, False, True])
         ok += check(progs, 2, special[i:i + NE], [True, False, True, False])
-    assert 0 < ok < 16                     # both outcomes of the a1 = 0 branch occur (a0 square or not)
+    assert ok == 0                         # u with zero imaginary part: the reference rejects them all (g2_real_u.json)
     check(progs, 2, [(0, 0), (1, 0), (0, 1), (Q - 1, 0)], [False, True, True, False])
+
+
+def test_g2_encodings_whose_u_is_real(progs, golden):
+    """Reference-generated verdicts (Signature.from_bytes raises for all of them): the host mirror raises the
+    matching exception and the GPU program's validity flag is 0."""
+    recs = golden("g2_real_u.json")["decompress"]
+    consts, d1, d2 = progs
+    for i in range(0, len(recs), NE):
+        chunk = recs[i:i + NE]
+        xs, bigs = [], []
+        for r in chunk:
+            enc = bytes.fromhex(r["encoding"])
+            bigs.append(bool(enc[0] & 0x80))
+            xs.append((int.from_bytes(bytes([enc[0] & 0x1f]) + enc[1:48], "big"), int.from_bytes(enc[48:], "big")))
+            with pytest.raises(H.RealSquareRoot if r["reference"] == "Exception" else ValueError):
+                H.g2_decompress(enc)
+        while len(xs) < NE:
+            xs.append(xs[0]), bigs.append(bigs[0])
+        got = run(consts, d2, 2, xs, bigs)
+        assert all(o[-1] == 0 for o in got)

@@ -110,3 +110,27 @@ def test_infinity_summand(progs):
     want = aff(H.jac_add(F2, H.jac_add(F2, a2, H.jac_neg(F2, a3)), psi2))
     assert got[0] == want
     assert got[1] is None                            # infinity + infinity -> (0, 0) at the ABI
+
+
+def test_candidate_with_real_u_is_skipped(progs, golden):
+    """Reference-generated (tests/golden/g2_real_u.json): values t whose first candidate x1 has
+    u = x1^3 + b' with zero imaginary part.  The reference's sw_encode skips x1 (Fq2.modsqrt's a1 = 0 branch
+    makes y_for_x fail) and takes x2 or x3; so do the host mirror and the GPU program, through to the hash."""
+    recs = golden("g2_real_u.json")["sw_encode"]
+    assert len(recs) == 4
+
+    def fq2s(h, k):
+        b = bytes.fromhex(h)
+        v = [int.from_bytes(b[48 * i:48 * (i + 1)], "big") for i in range(2 * k)]
+        return [(v[2 * i], v[2 * i + 1]) for i in range(k)]
+    for lo in (0, 2):
+        ts = [t for r in recs[lo:lo + 2] for t in fq2s(r["t"], 2)]
+        enc = encode(progs, ts)
+        for j, r in enumerate(recs[lo:lo + 2]):
+            want = fq2s(r["sw_encode_t0"], 2)
+            assert affine_of(enc[2 * j]) == (want[0], want[1]) == H.sw_encode(H.F2, ts[2 * j])
+            assert affine_of(enc[2 * j])[0] != fq2s(r["skipped_x1"], 1)[0]
+        got = clear(progs, [(enc[0], enc[1]), (enc[2], enc[3])])
+        for j, r in enumerate(recs[lo:lo + 2]):
+            want = fq2s(r["point"], 2)
+            assert got[j] == (want[0], want[1])
