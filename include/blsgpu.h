@@ -170,7 +170,9 @@ int blsgpu_g2_msm_dev(blsgpu_ctx *ctx, const void *d_pts, const void *d_scalars,
  * reduced mod q) onwards: sw_encode twice (ec.py:449-507), their sum, cofactor
  * clearing with psi.  t: n x 192 bytes (t0.c0, t0.c1, t1.c0, t1.c1 big-endian
  * canonical); out: n x 192 bytes affine G2, (0,0) for infinity.  t = 0 encodes
- * to infinity as in ec.py:450-452. */
+ * to infinity as in ec.py:450-452; a candidate x whose x^3 + b' has zero imaginary part is skipped
+ * as the reference's bare `except` skips it (ec.py:489-498).  Where the reference's sw_encode itself
+ * raises (its LAST candidate is of that kind -- never for hashed input) the output is unspecified. */
 int blsgpu_map_to_g2(blsgpu_ctx *ctx, const uint8_t *t, size_t n, uint8_t *out);
 int blsgpu_map_to_g2_dev(blsgpu_ctx *ctx, const void *d_t, size_t n, void *d_out, void *stream);
 
@@ -186,8 +188,10 @@ int blsgpu_hash_to_g2_dev(blsgpu_ctx *ctx, const void *d_msg_hashes, size_t n, v
  * three bits (`& 0x1f`), y_for_x (ec.py:255-269; square roots fields.py:199-205 and
  * 463-482), and the reference's choice between y and -y by bit 0x80 (G2: on the
  * imaginary part only, signature.py:31-35).  in: n x 48 (G1) / n x 96 (G2) bytes;
- * out: n x 96 / n x 192 bytes affine; ok[i] = 1 iff the reference accepts encoding i
- * (it raises ValueError otherwise; out bytes of such an entry are unspecified). */
+ * out: n x 96 / n x 192 bytes affine; ok[i] = 1 iff the reference accepts encoding i (it raises
+ * otherwise -- ValueError, or for a G2 x whose x^3 + 4(1+i) has zero imaginary part the AffinePoint
+ * constructor's Exception, because Fq2.modsqrt returns an Fq there, fields.py:466-467; out bytes of
+ * such an entry are unspecified). */
 int blsgpu_g1_decompress(blsgpu_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, uint8_t *ok);
 int blsgpu_g2_decompress(blsgpu_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, uint8_t *ok);
 int blsgpu_g1_decompress_dev(blsgpu_ctx *ctx, const void *d_in, size_t n, void *d_out, void *d_ok, void *stream);
