@@ -210,6 +210,17 @@ BLS_HD void fat_reduce(uint32_t* __restrict__ out, const uint64_t* __restrict__ 
     double e = hf * (1.0 / 436277738.0) - 0.001;        // q >> 352 = 0x1a0111ea
     uint32_t k = (e > 0.0) ? (uint32_t)e : 0u;
     // (V + k (2^384 - q)) mod 2^384 = V - k q
+#if defined(__HIP_DEVICE_COMPILE__)
+    // twelve independent multiply-adds, then ONE add-with-carry per limb (out_j = lo_j + hi_(j-1) + carry)
+    // instead of a 64-bit add of the running carry per limb (mad + move + 64-bit add)
+    uint64_t t[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) t[j] = acc[j] + (uint64_t)k * qc[j];
+    out[0] = (uint32_t)t[0];
+    uint32_t cy = 0;
+#pragma unroll
+    for (int j = 1; j < 12; j++) out[j] = addc((uint32_t)t[j], (uint32_t)(t[j - 1] >> 32), cy);
+#else
     uint64_t c = 0;
 #pragma unroll
     for (int j = 0; j < 12; j++) {
@@ -217,6 +228,7 @@ BLS_HD void fat_reduce(uint32_t* __restrict__ out, const uint64_t* __restrict__ 
         out[j] = (uint32_t)t;
         c = t >> 32;
     }
+#endif
 }
 
 // ---- sign of a field element (the VM's SGN rounds) ----------------------------
