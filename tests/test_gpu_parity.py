@@ -172,11 +172,13 @@ def test_pairing_module_wrappers(golden):
         PR.ate_pairing_multi([P], [Qp, Qp])
 
 
-def test_seeded_8192_digest_vs_reference(engine, golden):
-    """SURVEY 8c F-PAIR: the reference's multi-pairing of the first 8192 PRF-seeded pairs (fixture made by
-    make_golden.py seeded8192).  The inputs are rebuilt here from the PRF scalars with the engine's own
-    group sums and checked against the fixture's input digests first."""
-    v = golden("pairing_seeded_8192.json")
+@pytest.mark.parametrize("size", [8192, 65536])
+def test_seeded_digest_vs_reference(engine, golden, size):
+    """SURVEY 8c F-PAIR: the reference's multi-pairing of the first 8192 / 65 536 PRF-seeded pairs (BASELINE
+    configs[2] at full size; fixtures made by make_golden.py seeded8192 / seeded65536 -- 10 and 80 minutes of
+    pure Python).  The inputs are rebuilt here from the PRF scalars with the engine's own group sums and
+    checked against the fixture's input digests first."""
+    v = golden("pairing_seeded_%d.json" % size)
     n = v["n"]
     nord = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 
