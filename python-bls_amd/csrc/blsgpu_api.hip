@@ -51,6 +51,7 @@ struct blsgpu_ctx {
     uint32_t* d_degen = nullptr;       // [0] count, [1 ..] block indices of degenerate pairs (k_miller_slow's work list)
     size_t degen_cap = 0;
     size_t mp_threshold = 4096;        // pairs from which k_miller_mp is used
+    size_t mp3_threshold = 9216;       // ... with three pairs per wavefront; between the two thresholds: two
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
     size_t h2c_reg_threshold = (size_t)-1;  // messages from which cofactor clearing runs one message per lane (off: the VM form wins at every size)
@@ -126,7 +127,8 @@ static int grow_elems(blsgpu_ctx* c, T** p, size_t* cap_elems, size_t elems) {
     return 0;
 }
 static int ensure_workspace(blsgpu_ctx* c, size_t max_pairs) {
-    size_t need = (max_pairs + 2) / 3 + (max_pairs + MILLER_WAVES - 1) / MILLER_WAVES + 1;
+    // one partial per Miller block: at most a team of two pairs (k_miller_mp<2>), plus the levels of the reduce chain
+    size_t need = (max_pairs + 1) / 2 + (max_pairs + MILLER_WAVES - 1) / MILLER_WAVES + 1;
     if (need > c->part_cap) {
         size_t cap0 = c->part_cap * 144, cap1 = c->part_cap * 144;     // in u32
         int rc = grow_elems(c, &c->d_part[0], &cap0, need * 144);
@@ -356,6 +358,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     blsgpu_ctx* c = new blsgpu_ctx();
     c->device = device;
     c->mp_threshold = default_mp_threshold();
+    if (const char* e = getenv("BLSGPU_MP3_THRESHOLD")) c->mp3_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -364,7 +367,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     size_t o_m = 0;
     size_t o_mp = o_m + al(sizeof(BLSVM_MILLER_FLAT));
-    size_t o_h2 = o_mp + al(sizeof(BLSVM_MP_FLAT));
+    size_t o_mp2 = o_mp + al(sizeof(BLSVM_MP_FLAT));
+    size_t o_h2 = o_mp2 + al(sizeof(BLSVM_MP2_FLAT));
     size_t o_f = o_h2 + al(sizeof(BLSVM_H2_FLAT));
     size_t o_sl = o_f + al(sizeof(BLSVM_FEXP_FLAT));
     size_t o_s = o_sl + al(sizeof(BLSVM_SLOW_FLAT));
@@ -378,6 +382,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     char* base = (char*)c->d_tables;
     struct { size_t off; const void* src; size_t len; } parts[] = {
         {o_m, BLSVM_MILLER_FLAT, sizeof(BLSVM_MILLER_FLAT)}, {o_mp, BLSVM_MP_FLAT, sizeof(BLSVM_MP_FLAT)},
+        {o_mp2, BLSVM_MP2_FLAT, sizeof(BLSVM_MP2_FLAT)},
         {o_h2, BLSVM_H2_FLAT, sizeof(BLSVM_H2_FLAT)},
         {o_f, BLSVM_FEXP_FLAT, sizeof(BLSVM_FEXP_FLAT)},
         {o_sl, BLSVM_SLOW_FLAT, sizeof(BLSVM_SLOW_FLAT)},
@@ -392,6 +397,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     }
     c->tabs.mflat = (const uint2*)(base + o_m);
     c->tabs.mpflat = (const uint2*)(base + o_mp);
+    c->tabs.mp2flat = (const uint2*)(base + o_mp2);
     c->tabs.h2flat = (const uint2*)(base + o_h2);
     c->tabs.fflat = (const uint2*)(base + o_f);
     c->tabs.sflat = (const uint2*)(base + o_sl);
@@ -426,7 +432,9 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, BLSVM_D2_SLOTS * 48);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, BLSVM_D2_SLOTS * 48);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_decompress<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BLSVM_D2_SLOTS * 48);
-    (void)hipFuncSetAttribute((const void*)blsgpu::k_miller_mp, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_miller_mp<BLSVM_MP_G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              blsgpu::MP_TEAM_BYTES);
+    (void)hipFuncSetAttribute((const void*)blsgpu::k_miller_mp<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               blsgpu::MP_TEAM_BYTES);
     (void)hipFuncSetAttribute((const void*)blsgpu::k_final_groups, hipFuncAttributeMaxDynamicSharedMemorySize,
                               REDUCE_WAVES * blsgpu::TEAM_BYTES);
@@ -503,6 +511,11 @@ BLSGPU_EXPORT int blsgpu_ctx_set_mp_threshold(blsgpu_ctx* c, size_t pairs) {
     c->mp_threshold = pairs;
     return 0;
 }
+BLSGPU_EXPORT int blsgpu_ctx_set_mp3_threshold(blsgpu_ctx* c, size_t pairs) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    c->mp3_threshold = pairs;
+    return 0;
+}
 
 BLSGPU_EXPORT int blsgpu_ctx_reserve(blsgpu_ctx* c, size_t max_pairs) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
@@ -560,17 +573,22 @@ constexpr unsigned SLOW_GRID = 1024;
 static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups, bool one_per_block,
                          uint32_t* d_partials, hipStream_t st, size_t* bpg_out) {
     const bool mp = !one_per_block && use_mp(c, gsz * groups);
-    const size_t per_block = one_per_block ? 1 : (mp ? (size_t)BLSVM_MP_G : (size_t)MILLER_WAVES);
+    const bool mp2 = mp && gsz * groups < c->mp3_threshold;       // a few thousand pairs: teams of two fill the chip
+    const size_t per_block = one_per_block ? 1 : (mp ? (mp2 ? (size_t)2 : (size_t)BLSVM_MP_G) : (size_t)MILLER_WAVES);
     size_t bpg = (gsz + per_block - 1) / per_block;
     *bpg_out = bpg;
     if (bpg * groups > 0x7FFFFFFFull) return fail(-EINVAL, "batch too large");
     if (bpg * groups + 2 > c->degen_cap) return fail(-ENOMEM, "work list too small");
     blsgpu::DegenList dg{c->d_degen, c->d_degen + 1, (const uint8_t*)d_inf};
     HIP_TRY(hipMemsetAsync(c->d_degen, 0, sizeof(uint32_t), st));
-    if (mp) {
+    if (mp2) {
         KernelTimer kt(c, st, 0);
-        hipLaunchKernelGGL(blsgpu::k_miller_mp, dim3((unsigned)(bpg * groups)), dim3(64), (size_t)blsgpu::MP_TEAM_BYTES, st, c->tabs,
+        hipLaunchKernelGGL(blsgpu::k_miller_mp<2>, dim3((unsigned)(bpg * groups)), dim3(64), (size_t)blsgpu::MP_TEAM_BYTES, st, c->tabs,
                            (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, d_partials, dg);
+    } else if (mp) {
+        KernelTimer kt(c, st, 0);
+        hipLaunchKernelGGL(blsgpu::k_miller_mp<BLSVM_MP_G>, dim3((unsigned)(bpg * groups)), dim3(64), (size_t)blsgpu::MP_TEAM_BYTES, st,
+                           c->tabs, (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, d_partials, dg);
     } else {
         size_t lds = per_block * blsgpu::TEAM_BYTES;
         KernelTimer kt(c, st, 0);
@@ -603,7 +621,7 @@ static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, co
         return 0;
     }
     size_t need_pairs = (gsz + 3) * groups;            // every group rounds its team count up
-    if ((need_pairs + 2) / 3 + (need_pairs + MILLER_WAVES - 1) / MILLER_WAVES + 1 > c->part_cap) {
+    if ((need_pairs + 1) / 2 + (need_pairs + MILLER_WAVES - 1) / MILLER_WAVES + 1 > c->part_cap) {
         int rc = ensure_workspace(c, need_pairs);
         if (rc) return rc;
     }

@@ -31,6 +31,7 @@ namespace blsgpu {
 struct VmTables {
     const uint2* mflat;       // Miller loop: flat round sequence {data_off, meta}
     const uint2* mpflat;      // Miller loop, BLSVM_MP_G pairs per team
+    const uint2* mp2flat;     // Miller loop, two pairs per team
     const uint2* h2flat;      // hash to G2: sum + cofactor clearing
     const uint2* fflat;       // final exponentiation
     const uint2* sflat;       // reference-faithful Miller loop (vmgen/slow_programs.py)
@@ -510,6 +511,19 @@ __global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, c
 // of its pairs, so the observable behaviour is that of k_miller.
 constexpr int MP_TEAM_DW = BLSVM_MP_TEAM_SLOTS * 12;
 constexpr int MP_TEAM_BYTES = MP_TEAM_DW * 4;
+// The multi-pair programs exist for G = BLSVM_MP_G (3: fewest instructions per pairing) and for G = 2: a
+// call of a few thousand pairs cannot fill the chip with teams of three (8192 pairs = 2731 teams for
+// 4096 places) and a team of two finishes in 3/4 of the time.
+template <int G> struct MpCfg;
+template <> struct MpCfg<BLSVM_MP_G> {
+    static constexpr uint32_t F = BLSVM_MP_F, CORE = BLSVM_MP_CORE, Q = BLSVM_MP_Q, INIT_LEN = BLSVM_MP_INIT_LEN, FLAT_LEN = BLSVM_MP_FLAT_LEN;
+    static __device__ __forceinline__ const uint2* flat(const VmTables& T) { return T.mpflat; }
+};
+template <> struct MpCfg<2> {
+    static constexpr uint32_t F = BLSVM_MP2_F, CORE = BLSVM_MP2_CORE, Q = BLSVM_MP2_Q, INIT_LEN = BLSVM_MP2_INIT_LEN, FLAT_LEN = BLSVM_MP2_FLAT_LEN;
+    static __device__ __forceinline__ const uint2* flat(const VmTables& T) { return T.mp2flat; }
+};
+static_assert(BLSVM_MP2_TEAM_SLOTS <= BLSVM_MP_TEAM_SLOTS, "one scratchpad size for both multi-pair programs");
 
 // raw big-endian pair -> limb slots: P (2 values) from slot `p_slot`, Q (4 values) from `q_slot`
 __device__ __forceinline__ void load_pair_raw(uint32_t* team, uint32_t p_slot, uint32_t q_slot, const uint32_t* __restrict__ g1,
@@ -522,40 +536,42 @@ __device__ __forceinline__ void load_pair_raw(uint32_t* team, uint32_t p_slot, u
     }
 }
 
+template <int G>
 __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
                                                      uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials, DegenList dg) {
+    using C = MpCfg<G>;
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t grp = blockIdx.x / bpg;                       // groups as in k_miller
-    const uint32_t in_grp = (blockIdx.x - grp * bpg) * BLSVM_MP_G;
+    const uint32_t in_grp = (blockIdx.x - grp * bpg) * G;
     const size_t first = (size_t)grp * gsz + in_grp;
-    const uint32_t cnt = min((uint32_t)BLSVM_MP_G, gsz - in_grp);
+    const uint32_t cnt = min((uint32_t)G, gsz - in_grp);
     team_init_consts(T, team, lane);
     wave_fence();
     bool ok = true;
-    uint32_t f_dw = (uint32_t)(BLSVM_MP_F * 12);
-    if (cnt == (uint32_t)BLSVM_MP_G) {
+    uint32_t f_dw = C::F * 12u;
+    if (cnt == (uint32_t)G) {
         // the multi-pair programs have their own scratchpad layout (vmgen/programs.MPLayout)
         for (uint32_t g = 0; g < cnt; ++g) {
-            load_pair_raw(team, BLSVM_MP_CORE + 14u * g, BLSVM_MP_Q + 4u * g, g1, g2, first + g, lane);
+            load_pair_raw(team, C::CORE + 14u * g, C::Q + 4u * g, g1, g2, first + g, lane);
             ok = ok && !q_flagged(dg, first + g);
         }
         wave_fence();
         uint32_t stash[3] = {0u, 0u, 0u};                        // Q of the team's pairs between the chord steps
-        const OnCurveCheck chk{0u, BLSVM_MP_F + 1, 2 * BLSVM_MP_G, lane};                // every Q on the twist
-        if (ok) ok = run_rounds<true>(T, T.mpflat, BLSVM_MP_FLAT_LEN, 0, lane, stash, BLSVM_MP_INIT_LEN, chk);
+        const OnCurveCheck chk{0u, C::F + 1, 2 * G, lane};       // every Q on the twist
+        if (ok) ok = run_rounds<true>(T, C::flat(T), C::FLAT_LEN, 0, lane, stash, C::INIT_LEN, chk);
         if (ok) {
             wave_fence();
             // final Z of pair g in slots CORE + 14 g + 6, + 7: zero iff both are
             bool nz = false;
-            if (lane < 2u * BLSVM_MP_G) {
+            if (lane < 2u * G) {
                 uint32_t X[12];
-                lds_load12(X, (BLSVM_MP_CORE + 14u * (lane >> 1) + 6u + (lane & 1u)) * 3u);
+                lds_load12(X, (C::CORE + 14u * (lane >> 1) + 6u + (lane & 1u)) * 3u);
                 bls::fq_canon(X);
                 nz = !bls::fq_is_zero(X);
             }
             const uint64_t m = __ballot(nz);
-            for (uint32_t g = 0; g < (uint32_t)BLSVM_MP_G; ++g) ok = ok && ((m >> (2u * g)) & 3ull) != 0;
+            for (uint32_t g = 0; g < (uint32_t)G; ++g) ok = ok && ((m >> (2u * g)) & 3ull) != 0;
         }
     } else {
         // ragged last team of a group: its pairs one by one through the single-pair program

@@ -98,7 +98,7 @@ def pack(segs, order):
             if kind in ("save", "restore"):
                 # light programs only: the 12-slot window at slot K <-> the stash registers; no
                 # lane records (the look-ahead fetch reads the start of the data, harmlessly)
-                assert name.startswith("mp_") and rnd["K"] < 256
+                assert name.startswith(("mp_", "mp2_")) and rnd["K"] < 256
                 lst.append((0, (2 if kind == "save" else 3) | (rnd["K"] << 8)))
                 continue
             if kind in ("mul", "inv", "sgn"):
@@ -186,6 +186,8 @@ def build_tables(verbose=False):
     segs, mscript, fscript = P.build_all(verbose=verbose)
     mpsegs, mpscript, mplay = P.build_multi(verbose=verbose)
     segs.update(mpsegs)
+    mp2segs, mp2script, mp2lay = P.build_multi(G=2, verbose=verbose, prefix="mp2")
+    segs.update(mp2segs)
     msm = {}
     for deg, NP in MSM_NP.items():
         msegs, lay = MP.build(deg, NP, verbose=verbose)
@@ -211,7 +213,7 @@ def build_tables(verbose=False):
     return dict(segs=segs, mscript=mscript, fscript=fscript, mpsegs=mpsegs, mpscript=mpscript, mplay=mplay, msm=msm,
                 h1=(h1segs, h1lay, h1script), h1w=(h1segs, h1lay, h1wscript), h2=(h2segs, h2lay, h2script),
                 d1=(d1segs, d1lay, d1script), d2=(d2segs, d2lay, d2script), order=order,
-                slow=(slowsegs, slowscript),
+                slow=(slowsegs, slowscript), mp2=(mp2segs, mp2script, mp2lay),
                 seg_rounds=seg_rounds, data=data)
 
 
@@ -221,7 +223,7 @@ def generate(path=None, verbose=False):
     (h1segs, h1lay, h1script), (h2segs, h2lay, h2script) = tb["h1"], tb["h2"]
     order, seg_rounds, data = tb["order"], tb["seg_rounds"], tb["data"]
     team_slots = P.TEMP0 + max(s.ntemp for n, s in segs.items()
-                               if not n.startswith(("g", "mp_", "h", "d1", "d2", "slow_", "line_")))
+                               if not n.startswith(("g", "mp_", "mp2_", "h", "d1", "d2", "slow_", "line_")))
     mplay = tb["mplay"]
     # (the kernel's fallback for special pairs runs the single-pair program in the same scratchpad)
     mp_team_slots = max(team_slots, P.mp_team_slots(mpsegs))
@@ -249,6 +251,11 @@ def generate(path=None, verbose=False):
     w("/* multi-pair scratchpad (programs.MPLayout): accumulator, pair g's PX PY at CORE + 14 g, its Q at Q + 4 g */\n")
     w("#define BLSVM_MP_F %d\n#define BLSVM_MP_CORE %d\n#define BLSVM_MP_Q %d\n" % (mplay.F, mplay.CORE, mplay.Q))
     flat("BLSVM_MP_FLAT", [r for n in mpscript for r in seg_rounds[n]])
+    mp2segs, mp2script, mp2lay = tb["mp2"]
+    w("/* the same with TWO pairs per team (calls of a few thousand pairs) */\n")
+    w("#define BLSVM_MP2_TEAM_SLOTS %d\n#define BLSVM_MP2_F %d\n#define BLSVM_MP2_CORE %d\n#define BLSVM_MP2_Q %d\n#define BLSVM_MP2_INIT_LEN %d\n"
+      % (max(team_slots, P.mp_team_slots(mp2segs)), mp2lay.F, mp2lay.CORE, mp2lay.Q, len(seg_rounds[mp2script[0]])))
+    flat("BLSVM_MP2_FLAT", [r for n in mp2script for r in seg_rounds[n]])
     w("/* rounds of the first segment: the kernels look at the on-curve residual (accumulator coefficients 1 .. 2 G) after it */\n")
     w("#define BLSVM_MILLER_INIT_LEN %d\n#define BLSVM_MP_INIT_LEN %d\n" % (len(seg_rounds[mscript[0]]), len(seg_rounds[mpscript[0]])))
     slowsegs, slowscript = tb["slow"]

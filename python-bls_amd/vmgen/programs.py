@@ -571,29 +571,32 @@ def build_all(cfg=None, verbose=False):
     return segs, mscript, fscript
 
 
-def build_multi(cfg=None, G=MP_G, verbose=False):
+def build_multi(cfg=None, G=MP_G, verbose=False, prefix="mp"):
     """Miller-loop programs for G pairs per team sharing one accumulator:
-    returns (segments by name, script, layout)."""
+    returns (segments by name, script, layout).  prefix names the segments (mp_*: three pairs, the
+    throughput program; mp2_*: two pairs, for calls of a few thousand pairs, where 4096 teams of two
+    fill the chip and a team finishes in 3/4 of the time)."""
     cfg = cfg or tw.Cfg()
     lazy = lazy_cfg(cfg)
     lay = MPLayout(G)
     bits = [(NX >> p) & 1 for p in range(62, -1, -1)]
     # step k multiplies the chord line in iff bit k is set (fields_t.py:1104); the chord step
     # itself runs inside that body, so the T chain is a tangent step ahead only
-    script = ["mp_init"] + [("mp_body_c0" if bit else ("mp_body_02" if k + 1 == len(bits) else "mp_body_00"))
-                            for k, bit in enumerate(bits)]
+    pb = prefix + "_body"
+    script = [prefix + "_init"] + [(pb + "_c0" if bit else (pb + "_02" if k + 1 == len(bits) else pb + "_00"))
+                                   for k, bit in enumerate(bits)]
     assert bits[-1] == 0 and not any(a and b_ for a, b_ in zip(bits, bits[1:]))
-    plan = [(seg_init(lazy, False, G, "mp_init", lay), lay.TEMP_HI, False),
-            (seg_body_chord(lazy, 0, G, lay), lay.TEMP_HI, False),
-            (seg_body(lazy, 0, 0, G, "mp_body", lay), lay.TEMP_LO, False),
-            (seg_body(lazy, 0, 2, G, "mp_body", lay), lay.TEMP_LO, False)]
+    plan = [(seg_init(lazy, False, G, prefix + "_init", lay), lay.TEMP_HI, False),
+            (seg_body_chord(lazy, 0, G, lay, pb), lay.TEMP_HI, False),
+            (seg_body(lazy, 0, 0, G, pb, lay), lay.TEMP_LO, False),
+            (seg_body(lazy, 0, 2, G, pb, lay), lay.TEMP_LO, False)]
     segs = {}
     for b, tb, on_demand in plan:
         segs[b.name] = schedule(b, temp_base=tb, verbose=verbose, lazy_lin=on_demand)
         segs[b.name].temp_base = tb
     # the Q window travels in registers between the segments that use it (MPLayout)
-    segs["mp_init"].rounds.append({"kind": "save", "K": lay.Q, "lanes": []})
-    segs["mp_body_c0"].rounds.insert(0, {"kind": "restore", "K": lay.Q, "lanes": []})
+    segs[prefix + "_init"].rounds.append({"kind": "save", "K": lay.Q, "lanes": []})
+    segs[pb + "_c0"].rounds.insert(0, {"kind": "restore", "K": lay.Q, "lanes": []})
     return segs, script, lay
 
 

@@ -57,20 +57,46 @@ DEGEN = ["ord13", "ord13_neg", "ord13_p_zero", "ord13_px_zero", "ord13_in_team",
          "flag_on_off_curve", "pflag_only", "all_kinds"]
 
 
-@pytest.mark.parametrize("mp", [1 << 30, 0])
+KERNELS = {"k_miller": (1 << 30, 9216), "k_miller_mp<3>": (0, 0), "k_miller_mp<2>": (0, 1 << 30)}
+
+
+class kernel_choice:
+    """force one of the three Miller kernels whatever the batch size (thresholds of include/blsgpu.h)"""
+
+    def __init__(self, engine, which):
+        self.engine, self.thr = engine, KERNELS[which]
+
+    def __enter__(self):
+        self.engine.set_mp_threshold(self.thr[0])
+        self.engine.set_mp3_threshold(self.thr[1])
+
+    def __exit__(self, *a):
+        self.engine.set_mp_threshold(4096)
+        self.engine.set_mp3_threshold(9216)
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
 @pytest.mark.parametrize("name", DEGEN)
-def test_degenerate_pairs(engine, golden, name, mp):
+def test_degenerate_pairs(engine, golden, name, kernel):
     """Inputs on which the reference's special cases decide (low-order, off-curve, zero, flagged:
     tests/golden/pairing_degenerate.json, reference-generated).  The fast kernels must notice and
-    k_miller_slow must reproduce the reference's bytes -- through k_miller (mp = huge threshold:
-    one pair per wavefront) and through k_miller_mp (threshold 0: three pairs per wavefront)."""
+    k_miller_slow must reproduce the reference's bytes -- through k_miller (one pair per wavefront) and
+    through k_miller_mp with three and with two pairs per wavefront."""
     v = golden("pairing_degenerate.json")["cases"][name]
     n = len(v["g1"])
-    try:
-        engine.set_mp_threshold(mp)
+    with kernel_choice(engine, kernel):
         assert engine.pairing_multi(cat(v["g1"]), cat(v["g2"]), n, flags(v)).hex() == v["out"]
-    finally:
-        engine.set_mp_threshold(4096)
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 64, 65, 1025])
+def test_every_kernel_on_ordinary_batches(engine, golden, seeded_pairs, oracle, kernel, n):
+    """the three Miller kernels give the same bytes on ordinary batches of every raggedness"""
+    g1, g2 = seeded_pairs
+    a, b = g1[:96 * n], g2[:192 * n]
+    want = bytes.fromhex(golden("pairing.json")["seeded"]["1025"]["out"]) if n == 1025 else oracle.pairing_multi(a, b, n, threads=8)
+    with kernel_choice(engine, kernel):
+        assert engine.pairing_multi(a, b, n) == want
 
 
 def test_degenerate_pairs_inside_large_batches(engine, golden, seeded_pairs, oracle):
@@ -87,12 +113,9 @@ def test_degenerate_pairs_inside_large_batches(engine, golden, seeded_pairs, ora
             a += bytes.fromhex(c["g1"][0]); b += bytes.fromhex(c["g2"][0]); inf += bytes(int(x) for x in c["inf"][0])
     n = len(a) // 96
     want = oracle.pairing_multi(bytes(a), bytes(b), n, threads=8, inf=bytes(inf))
-    for mp in (1 << 30, 0):
-        try:
-            engine.set_mp_threshold(mp)
-            assert engine.pairing_multi(bytes(a), bytes(b), n, bytes(inf)) == want, mp
-        finally:
-            engine.set_mp_threshold(4096)
+    for kernel in KERNELS:
+        with kernel_choice(engine, kernel):
+            assert engine.pairing_multi(bytes(a), bytes(b), n, bytes(inf)) == want, kernel
     # batch entry: groups of 3 (one k_miller wavefront per pair) and of 27 (per-group product tree)
     for gsz in (3, 27):
         groups = n // gsz
@@ -305,22 +328,21 @@ def test_batched_independent_pairings(engine, golden, seeded_pairs, oracle):
     assert engine.final_exp_batch(ins) == b"".join(bytes.fromhex(r["out"]) for r in recs) * 4
 
 
-@pytest.mark.parametrize("gsz,groups,mp", [(25, 5, 0), (25, 5, 1 << 30), (205, 5, 0), (1025, 3, 0), (64, 16, 1 << 30)])
-def test_batched_large_groups(engine, seeded_pairs, gsz, groups, mp):
+@pytest.mark.parametrize("gsz,groups,kernel", [(25, 5, "k_miller_mp<3>"), (25, 5, "k_miller_mp<2>"), (25, 5, "k_miller"),
+                                               (205, 5, "k_miller_mp<3>"), (205, 5, "k_miller_mp<2>"), (1025, 3, "k_miller_mp<3>"),
+                                               (1025, 3, "k_miller_mp<2>"), (64, 16, "k_miller")])
+def test_batched_large_groups(engine, seeded_pairs, gsz, groups, kernel):
     """Groups long enough for the per-group product tree (grouped k_miller / k_miller_mp +
     k_reduce over blockIdx.y): every group must equal its own blsgpu_pairing_multi.
-    gsz not a multiple of 3 or 4 exercises the ragged last team of every group."""
+    gsz not a multiple of 2, 3 or 4 exercises the ragged last team of every group."""
     g1, g2 = seeded_pairs
     n = gsz * groups
     reps = (n + 1024) // 1025
     a, b = (g1 * reps)[:96 * n], (g2 * reps)[:192 * n]
-    try:
-        engine.set_mp_threshold(mp)
+    with kernel_choice(engine, kernel):
         out = engine.pairing_multi_batch(a, b, gsz, groups)
         singles = [engine.pairing_multi(a[96 * gsz * g:96 * gsz * (g + 1)], b[192 * gsz * g:192 * gsz * (g + 1)], gsz)
                    for g in range(groups)]
-    finally:
-        engine.set_mp_threshold(4096)
     assert [out[576 * g:576 * (g + 1)] for g in range(groups)] == singles
     assert len(set(singles)) == groups or gsz * groups > 1025
 

@@ -223,8 +223,9 @@ def test_scratchpad_budgets():
         return (160 * 1024) // (-(-slots * 48 // 512) * 512)
     mp = P.mp_team_slots(tb["mpsegs"])
     single = P.TEMP0 + max(s.ntemp for n, s in tb["segs"].items()
-                           if not n.startswith(("g", "mp_", "h", "d1", "d2")))
+                           if not n.startswith(("g", "mp_", "mp2_", "h", "d1", "d2", "slow_", "line_")))
     assert teams(max(mp, single)) >= 16, (mp, single)
+    assert P.mp_team_slots(tb["mp2"][0]) <= max(mp, single)            # the two-pair program shares the scratchpad size
     h2segs, h2lay, _ = tb["h2"]
     assert teams(HP.h2_team_slots(h2segs, h2lay)) >= 12
     # the Q window of the multi-pair layout is what three stash registers per lane hold
@@ -266,3 +267,43 @@ def test_field_op_segments(built, golden):
         load(want, 0, ops[i]), load(want, 1, ops[i])
         want.run(segs["mul_0_1"])
         assert read(m, 0) == read(want, 0)
+
+
+def test_two_pair_program_packed(golden):
+    """the two-pairs-per-team Miller program (k_miller_mp<2>), packed tables decoded like the kernel:
+    accumulator == product of the two single-pair Miller values after the final exponentiation"""
+    from vmgen import tablesim
+    tb = emit.build_tables()
+    sr, data = tb["seg_rounds"], tb["data"]
+    consts = P.const_table()
+    mp2segs, mp2script, lay = tb["mp2"]
+    fexp = [r for n in tb["fscript"] for r in sr[n]] + sr["from_mont_1_0"]
+
+    def finish(f12):
+        m = tablesim.TableMachine(consts, 400, data, P.C_K1)
+        for i in range(12):
+            m.team[P.F + i] = f12[i]
+        m.run(fexp)
+        return b"".join(m.team[P.reg(1) + i].to_bytes(48, "big") for i in range(12))
+    v = golden("pairing.json")["small4"]
+    m = tablesim.TableMachine(consts[:P.C_GAM], P.mp_team_slots(mp2segs), data, P.C_K1)
+    singles = []
+    for k in range(2):
+        a, b = bytes.fromhex(v["g1"][k + 1]), bytes.fromhex(v["g2"][k + 1])
+        pv = [int.from_bytes(a[i * 48:(i + 1) * 48], "big") for i in range(2)] + \
+             [int.from_bytes(b[i * 48:(i + 1) * 48], "big") for i in range(4)]
+        ps = lay.pair(k)
+        m.team[ps.PX], m.team[ps.PY] = pv[0], pv[1]
+        for i in range(4):
+            m.team[ps.QX0 + i] = pv[2 + i]
+        s = tablesim.TableMachine(consts, 400, data, P.C_K1)
+        for i, x in enumerate(pv):
+            s.team[P.PX + i] = x
+        s.run([r for n in tb["mscript"] for r in sr[n]])
+        singles.append([s.team[P.F + i] for i in range(12)])
+    m.run([r for n in mp2script for r in sr[n]], light=True)
+    t = tablesim.TableMachine(consts, 400, data, P.C_K1)
+    for i in range(12):
+        t.team[P.reg(0) + i], t.team[P.reg(1) + i] = singles[0][i], singles[1][i]
+    t.run(sr["mul_0_1"])
+    assert finish([m.team[lay.F + i] for i in range(12)]) == finish([t.team[P.reg(0) + i] for i in range(12)])

@@ -19,14 +19,15 @@ def main():
     g1 = open(os.path.join(gold, "pairs_seed1_g1.bin"), "rb").read()
     g2 = open(os.path.join(gold, "pairs_seed1_g2.bin"), "rb").read()
     out = torch.zeros(576, dtype=torch.uint8, device=dev)
-    for n in (1025, 2048, 4096, 8192, 12288, 16384, 24576, 32768, 49152, 65536):
+    for n in (1025, 2048, 3072, 4096, 5120, 6144, 7168, 8192, 9216, 10240, 12288, 16384, 24576, 32768, 65536):
         reps = (n + 1024) // 1025
         t1 = torch.frombuffer(bytearray((g1 * reps)[:96 * n]), dtype=torch.uint8).to(dev)
         t2 = torch.frombuffer(bytearray((g2 * reps)[:192 * n]), dtype=torch.uint8).to(dev)
         eng.reserve(n)
         row = {"pairs": n}
-        for name, thr in (("k_miller", 1 << 40), ("k_miller_mp", 0)):
+        for name, thr, thr3 in (("k_miller", 1 << 40, 0), ("k_miller_mp2", 0, 1 << 40), ("k_miller_mp3", 0, 0)):
             eng.set_mp_threshold(thr)
+            eng.set_mp3_threshold(thr3)
             for _ in range(2):
                 eng.pairing_multi_dev(t1.data_ptr(), t2.data_ptr(), n, out.data_ptr(), 0)
             torch.cuda.synchronize()
