@@ -73,9 +73,10 @@ int blsgpu_ctx_trim(blsgpu_ctx *ctx);
  * latency-oriented one (one pair per wavefront).  Default 4096; 0 = always the
  * throughput kernel.  Results are identical either way. */
 int blsgpu_ctx_set_mp_threshold(blsgpu_ctx *ctx, size_t pairs);
-/* The throughput kernel runs three pairs per wavefront from `pairs` pairs per call on (default 9216) and two
- * pairs per wavefront below (a call of a few thousand pairs fills the chip with teams of two and each
- * finishes sooner).  0 = always three.  Results are identical either way. */
+/* The throughput kernel runs three pairs per wavefront from `pairs` pairs per call on and two pairs per
+ * wavefront below (a call of a few thousand pairs fills the chip with teams of two and each finishes sooner).
+ * 0 = always three; (size_t)-1 = the measured schedule (default: two up to ~8.7 k pairs and in the pockets
+ * where teams of two quantise better, three elsewhere).  Results are identical either way. */
 int blsgpu_ctx_set_mp3_threshold(blsgpu_ctx *ctx, size_t pairs);
 
 /* fq_ate_pairing_multi(Ps, Qs) -- fields_t.py:1114-1121 / fields_t_c.pyx:2333-2391.

@@ -51,7 +51,7 @@ struct blsgpu_ctx {
     uint32_t* d_degen = nullptr;       // [0] count, [1 ..] block indices of degenerate pairs (k_miller_slow's work list)
     size_t degen_cap = 0;
     size_t mp_threshold = 4096;        // pairs from which k_miller_mp is used
-    size_t mp3_threshold = 9216;       // ... with three pairs per wavefront; between the two thresholds: two
+    size_t mp3_threshold = (size_t)-1; // ... with three pairs per wavefront from here on, two below; -1: the measured schedule
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
     size_t h2c_reg_threshold = (size_t)-1;  // messages from which cofactor clearing runs one message per lane (off: the VM form wins at every size)
@@ -103,6 +103,15 @@ static size_t default_mp_threshold() {
     return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4096;
 }
 static bool use_mp(const blsgpu_ctx* c, size_t n) { return n >= c->mp_threshold; }
+// Two or three pairs per wavefront?  Three costs fewest instructions per pairing (large batches), two fills the
+// chip sooner: 4096 teams are one "round" of the chip, so teams of two win while the batch is a little under a
+// multiple of 8192 pairs and teams of three where it is a little under a multiple of 12288 -- measured crossovers
+// (tools/mp_threshold_sweep.py, profiles/r02_schedule_experiments.txt); from ~20 000 pairs on blocks flow
+// continuously and three wins by 8 %.
+static bool use_mp2(const blsgpu_ctx* c, size_t n) {
+    if (c->mp3_threshold != (size_t)-1) return n < c->mp3_threshold;
+    return n <= 8704 || (n > 9728 && n <= 11264) || (n > 14336 && n <= 18432);
+}
 // grow-only (see blsgpu_ctx::retired): *p gets at least `bytes`; contents are scratch, not copied
 static int grow_buffer(blsgpu_ctx* c, void** p, size_t* cap_bytes, size_t bytes) {
     if (bytes <= *cap_bytes) return 0;
@@ -573,7 +582,7 @@ constexpr unsigned SLOW_GRID = 1024;
 static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups, bool one_per_block,
                          uint32_t* d_partials, hipStream_t st, size_t* bpg_out) {
     const bool mp = !one_per_block && use_mp(c, gsz * groups);
-    const bool mp2 = mp && gsz * groups < c->mp3_threshold;       // a few thousand pairs: teams of two fill the chip
+    const bool mp2 = mp && use_mp2(c, gsz * groups);              // a few thousand pairs: teams of two fill the chip
     const size_t per_block = one_per_block ? 1 : (mp ? (mp2 ? (size_t)2 : (size_t)BLSVM_MP_G) : (size_t)MILLER_WAVES);
     size_t bpg = (gsz + per_block - 1) / per_block;
     *bpg_out = bpg;

@@ -88,7 +88,7 @@ def main():
             gsz, groups = rng.choice([(1, 40), (2, 33), (5, 17), (23, 9), (24, 9), (25, 8), (67, 5), (130, 3)])
             a, b, f = pick(gsz * groups, t % 2 == 0)
             eng.set_mp_threshold(rng.choice([0, 4096, 1 << 40]))
-            eng.set_mp3_threshold(rng.choice([0, 9216, 1 << 40]))
+            eng.set_mp3_threshold(rng.choice([0, 2 ** 64 - 1, 1 << 40]))
             got = eng.pairing_multi_batch(a, b, gsz, groups, f)
             want = b"".join(O.pairing_multi(a[96 * gsz * g:96 * gsz * (g + 1)], b[192 * gsz * g:192 * gsz * (g + 1)], gsz, threads=16,
                                             inf=f[2 * gsz * g:2 * gsz * (g + 1)])
