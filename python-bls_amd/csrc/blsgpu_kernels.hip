@@ -770,8 +770,9 @@ __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __re
     if (wave == 0) {
         wave_fence();
         if (do_final) {
-            run_rounds(T, T.fflat, BLSVM_FEXP_FLAT_LEN, base16, lane);
-            run_rounds(T, T.segflat + BLSVM_SEGF_FROM_MONT_1_0_OFF, BLSVM_SEGF_FROM_MONT_1_0_LEN, base16, lane);
+            run_rounds(T, T.fflat, BLSVM_FEXP_HEAD_LEN, base16, lane);                     // the segment with the inversion
+            run_rounds<true>(T, T.fflat + BLSVM_FEXP_HEAD_LEN, BLSVM_FEXP_FLAT_LEN - BLSVM_FEXP_HEAD_LEN, base16, lane);
+            run_rounds<true>(T, T.segflat + BLSVM_SEGF_FROM_MONT_1_0_OFF, BLSVM_SEGF_FROM_MONT_1_0_LEN, base16, lane);
             if (lane < 12) {                         // relaxed (< 2q) -> canonical residues
                 uint32_t X[12];
                 lds_load12(X, base16 + (BLSVM_SLOT_REG0 + 12 + lane) * 3);
@@ -816,8 +817,9 @@ __global__ void __launch_bounds__(512) k_final_groups(VmTables T, const uint32_t
         if (i) run_rounds<true>(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, base16, lane);
     }
     wave_fence();
-    run_rounds(T, T.fflat, BLSVM_FEXP_FLAT_LEN, base16, lane);
-    run_rounds(T, T.segflat + BLSVM_SEGF_FROM_MONT_1_0_OFF, BLSVM_SEGF_FROM_MONT_1_0_LEN, base16, lane);
+    run_rounds(T, T.fflat, BLSVM_FEXP_HEAD_LEN, base16, lane);                             // the segment with the inversion
+    run_rounds<true>(T, T.fflat + BLSVM_FEXP_HEAD_LEN, BLSVM_FEXP_FLAT_LEN - BLSVM_FEXP_HEAD_LEN, base16, lane);
+    run_rounds<true>(T, T.segflat + BLSVM_SEGF_FROM_MONT_1_0_OFF, BLSVM_SEGF_FROM_MONT_1_0_LEN, base16, lane);
     if (lane < 12) {
         uint32_t X[12];
         lds_load12(X, base16 + (BLSVM_SLOT_REG0 + 12 + lane) * 3);

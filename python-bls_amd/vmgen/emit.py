@@ -285,6 +285,10 @@ def generate(path=None, verbose=False):
     w("#define BLSVM_H2_FINAL_LEN %d   /* rounds of the last segment (the only one with an inversion) */\n" % len(seg_rounds["h2_affine"]))
     flat("BLSVM_MILLER_FLAT", mflat)
     flat("BLSVM_FEXP_FLAT", fflat)
+    # the one inversion of the final exponentiation sits in its first segment: the kernels walk that segment with
+    # the full interpreter and everything after it with the light one (products and combinations only)
+    assert fscript[0] == "inv12_2_0" and all(r["kind"] in ("mul", "lin") for n in fscript[1:] for r in segs[n].rounds)
+    w("#define BLSVM_FEXP_HEAD_LEN %d\n" % len(seg_rounds[fscript[0]]))
     for deg, (msegs, lay) in msm.items():
         for nm in ("NP", "IN", "R", "A", "S", "PR0", "PR1", "OUT"):
             w("#define BLSVM_MSM%d_%s %d\n" % (deg, nm, getattr(lay, nm)))
