@@ -87,7 +87,7 @@ def pmc_traffic(kernel, pairings_per_launch):
         with open(path) as f:
             for row in f:
                 c = row.strip().split(",")
-                if len(c) == 4 and c[0].endswith(kernel) and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                if len(c) == 4 and c[0].split("::")[-1].split("<")[0] == kernel and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
                     kb[c[1]] = float(c[3])
         if len(kb) == 2:
             return int((kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), "profiles/" + name
