@@ -185,6 +185,21 @@ __global__ void __launch_bounds__(64, 2) k_h2c_stage(VmTables T, const uint32_t*
         run_rounds(T, T.segflat + BLSVM_SEGF_H1_C_OFF, BLSVM_SEGF_H1_C_LEN, 0, lane);
     }
     wave_fence();
+    if (STAGE == 0) {
+        // A candidate whose u = x^3 + b' has zero imaginary part has no y in the reference (Fq2.modsqrt's a1 == 0
+        // branch, fields.py:466-467; sw_encode's except, ec.py:489-498): n' = 0 keeps h1_b from choosing it
+        // (vmgen.h2c_programs.real_u_step; tests/golden/g2_real_u.json).
+        bool real_u = false;
+        if (lane < 3 * BLSVM_H1_NE) {
+            uint32_t A1[12];
+            lds_load12(A1, (BLSVM_H1_U + 2 * lane + 1) * 3);
+            bls::fq_canon(A1);
+            real_u = bls::fq_is_zero(A1);
+        }
+        if (real_u)
+            for (uint32_t w = 0; w < 12; ++w) team[(BLSVM_H1_N + lane) * 12 + w] = 0u;
+        wave_fence();
+    }
     img_store(team, my, BLSVM_H1_STATE0, H1_IMG, lane);
 }
 

@@ -266,6 +266,7 @@ def generate(path=None, verbose=False):
     w("#define BLSVM_H1_NE %d\n#define BLSVM_H1_SLOTS %d\n" % (H1_NE, h1lay.TEMP0 + max(s.ntemp for s in h1segs.values())))
     w("#define BLSVM_H2_NM %d\n#define BLSVM_H2_SLOTS %d\n" % (H2_NM, HP.h2_team_slots(h2segs, h2lay)))
     w("#define BLSVM_H1_T %d\n#define BLSVM_H1_TH %d\n#define BLSVM_H1_S %d\n#define BLSVM_H2_S %d\n#define BLSVM_H2_OUT %d\n" % (h1lay.T, h1lay.TH, h1lay.S, h2lay.S, h2lay.OUT))
+    w("#define BLSVM_H1_U %d\n#define BLSVM_H1_N %d\n" % (h1lay.U, h1lay.N))
     w("#define BLSVM_H1_ACC %d\n#define BLSVM_H1_BASE %d\n#define BLSVM_H1_STATE0 %d\n#define BLSVM_H1_STATE1 %d\n" % (h1lay.ACC, h1lay.BASE, h1lay.T, h1lay.TEMP0))
     w("#define BLSVM_NCONST_H2C %d\n#define BLSVM_HC_PSIX %d\n#define BLSVM_HC_PSIY %d\n" % (HP.HC_END, HP.HC_PSIX, HP.HC_PSIY))
     w("/* scratchpad slot of an extra constant -> its entry in the constant table */\n")

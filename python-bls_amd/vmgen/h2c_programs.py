@@ -16,8 +16,9 @@ sign flip) is restated branch-free:
 A candidate x whose u = x^3 + b' has ZERO imaginary part is skipped by the reference although u is a
 square of Fq2: Fq2.modsqrt returns an Fq there (fields.py:466-467), y_for_x fails on it and sw_encode's bare
 `except` counts the candidate as invalid (ec.py:489-498).  Restated: the norm handed to the symbol test is
-n' = nz(a1) N(u) and the selector is the exact indicator of chi(n') = 1, so a1 = 0 (which includes u = 0)
-gives 0.  (If the LAST candidate x3 is of that kind, or x1 is and u2, u3 are non-squares, the reference's
+n' = N(u), set to 0 when a1 = 0 -- a zero test the stage-0 kernel does itself between h1_a and the
+exponentiation (real_u_step below is its statement for the interpreters) -- and the selector is the exact
+indicator of chi(n') = 1, so a1 = 0 (which includes u = 0) gives 0.  (If the LAST candidate x3 is of that kind, or x1 is and u2, u3 are non-squares, the reference's
 sw_encode raises -- ec.py:503; there is nothing to reproduce then, and hashed inputs never get there.)
 Reference-generated vectors: tests/golden/g2_real_u.json.
 The reference's early exit for t = 0 (ec.py:450-452) is kept as a flag
@@ -165,8 +166,7 @@ def build_h1(NE, cfg=None, verbose=False, wide=False):
         for i, x in enumerate((x1, x2, x3)):
             u = cfg.mul2(cfg.sqr2(x), x)
             u = tw.f2_mat((u[0] + one * 4, u[1] + one * 4))
-            n = (u[0] * u[0] + u[1] * u[1]).mat()
-            n = (n * (u[1] * u[1].inv()).mat()).mat()              # n' = nz(a1) N(u)
+            n = (u[0] * u[0] + u[1] * u[1]).mat()                  # N(u); real_u_step() zeroes it when a1 = 0
             k = 3 * e + i
             b.out(x[0], L.X + 2 * k), b.out(x[1], L.X + 2 * k + 1)
             b.out(u[0], L.U + 2 * k), b.out(u[1], L.U + 2 * k + 1)
@@ -245,6 +245,17 @@ def build_h1(NE, cfg=None, verbose=False, wide=False):
         return sc
     script = [b0name] + exp_script("3") + ["h1_b"] + exp_script("2") + ["h1_c"]
     return segs, L, script
+
+
+def real_u_step(team, L, NE):
+    """The step the stage-0 kernel performs itself after h1_a / h1w_a (k_h2c_stage<0>, blsgpu_h2c.hip):
+    a candidate whose u = x^3 + b' has zero imaginary part gets n' = 0, so that h1_b never picks it.
+    Fq2.modsqrt returns an Fq for such u and y_for_x raises (fields.py:466-467, ec.py:93-104); sw_encode's
+    bare except moves on to the next candidate (ec.py:489-500).  Vectors: tests/golden/g2_real_u.json."""
+    from .sim import Q
+    for k in range(3 * NE):
+        if team[L.U + 2 * k + 1] % Q == 0:
+            team[L.N + k] = 0
 
 
 def _pt(b, base, m):

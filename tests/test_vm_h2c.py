@@ -29,6 +29,8 @@ def encode(progs, ts):
         m.team[L.T + 2 * e], m.team[L.T + 2 * e + 1] = t
     for name in script:
         m.run(segs[name])
+        if name in ("h1_a", "h1w_a"):
+            HP.real_u_step(m.team, L, NE)            # the zero test the stage-0 kernel does natively
     return [[m.team[L.S + 5 * e + k] for k in range(5)] for e in range(NE)]
 
 
