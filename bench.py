@@ -28,6 +28,7 @@ linearity identities evaluated by the engine itself otherwise) and aborts on a m
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import hashlib
 import json
 import os
@@ -60,13 +61,31 @@ def prf_scalar(tag, seed, i):
     return int.from_bytes(h.digest(), "big") % (N_ORDER - 1) + 1
 
 
-def self_launch(args):
-    """--gpus N without a launcher: run this script under torch.distributed.run as a child (this
-    process has not touched a GPU) and hand its exit code on."""
+def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """file descriptor 1 -> 2 for the duration (native libraries write there directly)"""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        os.dup2(keep, 1)
+        os.close(keep)
+
+
+def self_launch(args):
+    """--gpus N without a launcher: run this script under torch.distributed.run as a child (this
+    process has not touched a GPU) and hand its exit code on."""
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -161,14 +180,22 @@ class Env:
         self.dev = torch.device("cuda", self.local_dev)
         self.dist = None
         self.backend = args.backend
-        if self.world > 1:
+        if self.world > 1 or args.force_process_group:
             import torch.distributed as dist
             self.dist = dist
-            if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)
-            else:
-                dist.init_process_group("gloo")
-            assert dist.get_world_size() == self.world
+            if "MASTER_ADDR" not in os.environ:                # a forced one-rank group started without a launcher
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1")
+            # librccl (a version banner) and gloo (its connection report) print on stdout when the group forms:
+            # send that to stderr, stdout carries the one JSON line only
+            with stdout_to_stderr():
+                if args.backend == "nccl":
+                    dist.init_process_group("nccl", device_id=self.dev)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                else:
+                    dist.init_process_group("gloo")
+                    dist.barrier()
+            assert dist.get_world_size() == max(1, self.world)
 
     def up(self, b):
         return self.torch.frombuffer(bytearray(b), dtype=self.torch.uint8).to(self.dev)
@@ -318,7 +345,7 @@ def run_pairing(env, args):
         ev = torch.cuda.Event()
         ev.record(stream)
         miller_done[0] = ev
-        if world == 1:
+        if env.dist is None:
             engs[k].final_exp_product_batch_dev(parts[k].data_ptr(), 1, B, outs[k].data_ptr(), st)
         else:
             env.all_gather_partials(stream, parts[k], gath[k], B * 144)     # B x 576 bytes per rank
@@ -388,7 +415,7 @@ def run_pairing(env, args):
             "scaling": "strong" if c3 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "pairs_per_verification_per_gpu": n, "verifications_per_step": B,
                        "pairs_per_step_per_gpu": n * B, "parallelism": par, "steps_in_flight": S, "check": check,
-                       "backend": env.backend if world > 1 else "none", "ranks_in_process_group": len(info)},
+                       "backend": env.backend if env.dist else "none", "ranks_in_process_group": len(info)},
             "roofline": {"bound": "valu-int32-mac", "achieved": ach, "peak": PEAK_TMACS, "unit": "TMAC/s",
                          "frac": ach / PEAK_TMACS, "traffic": traffic,
                          "traffic_unit": "bytes per launch, offline rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (%s)" % traffic_src,
@@ -575,10 +602,11 @@ def dry_run(args):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     got = [torch.full((144,), rank, dtype=torch.int32)]
     if world > 1:
-        dist.init_process_group("gloo")
         got = [torch.zeros(144, dtype=torch.int32) for _ in range(world)]
-        dist.all_gather(got, torch.full((144,), rank, dtype=torch.int32))
-        dist.barrier()
+        with stdout_to_stderr():
+            dist.init_process_group("gloo")
+            dist.all_gather(got, torch.full((144,), rank, dtype=torch.int32))
+            dist.barrier()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_in_process_group": dist.get_world_size() if world > 1 else 1,
                           "partials_seen_from": [int(t[0]) for t in got]}))
@@ -603,6 +631,8 @@ def main():
                     help="steps in flight (the final exponentiations of one step overlap the Miller loops of the next)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU-side collective, for rehearsing the multi-rank path on one GPU")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="form the process group and run the all-gather even with one rank (RCCL rehearsal on a one-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--dry-run", action="store_true",

@@ -26,6 +26,7 @@ for c in ("c4", "c5", "h2c"):
     shutil.copy(find("kt_" + c, "*kernel_stats.csv"), os.path.join(P, "%s_%s_kernel_stats.csv" % (RN, c)))
 for src, dst in (("bench_default.json", "_bench_line.json"), ("kt_bench.json", "_bench_line_under_rocprof.json"),
                  ("bench_2rank_gloo_rehearsal.json", "_bench_line_2rank_gloo_rehearsal_on_one_gpu.json"),
+                 ("bench_rccl_1rank_rehearsal.json", "_bench_line_rccl_1rank_rehearsal.json"),
                  ("bench_c3.json", "_bench_c3_line.json"), ("bench_c3_2rank_gloo.json", "_bench_c3_line_2rank_gloo_rehearsal_on_one_gpu.json")):
     with open(os.path.join(P, RN + dst), "w") as f:
         f.write(json_line(os.path.join(R, src)))

@@ -8,6 +8,7 @@ mkdir -p $O
 timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench done"
 timeout -k 10 200 python bench.py --gpus 2 --backend gloo --steps 8 --warmup 2 > $O/bench_2rank_gloo_rehearsal.json 2> $O/bench_2rank.err
+timeout -k 10 200 python bench.py --force-process-group --no-cpu-baseline --no-latency > $O/bench_rccl_1rank_rehearsal.json 2> $O/bench_rccl_1rank.err
 timeout -k 10 200 python bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err
 timeout -k 10 200 python bench.py --config c3 --gpus 2 --backend gloo --steps 8 --warmup 2 > $O/bench_c3_2rank_gloo.json 2> $O/bench_c3_2rank.err
 for c in c4 c5 h2c; do timeout -k 10 300 python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; done
