@@ -55,6 +55,7 @@ struct blsgpu_ctx {
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
     size_t h2c_reg_threshold = (size_t)-1;  // messages from which cofactor clearing runs one message per lane (off: the VM form wins at every size)
+    size_t msm_sort_threshold = 262144; // points from which one G1 sum with scalars uses sorted buckets (k_srt_*)
     size_t msm_lane_threshold = 65536; // points from which the bucket sums run one (group, chunk, window) per lane
     uint32_t* d_buckets = nullptr;     // their buckets (HBM)
     size_t bucket_cap = 0;
@@ -227,6 +228,79 @@ int decompress_host(blsgpu_ctx* c, const uint8_t* in, size_t n, uint8_t* out, ui
 namespace {
 constexpr int MSM_WAVES = 4;
 
+// One large G1 sum with scalars by sorted buckets (blsgpu_msm.hip, k_srt_*).  Returns 1 without having written a
+// result when the digits are too unevenly spread for equal list pieces to pay (a run of very many pieces is
+// finished by ONE wavefront of k_srt_fix_long); the caller then takes the fixed-window path.
+static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* d_out_inf, hipStream_t st) {
+    using C = blsgpu::MsmCfg<1>;
+    uint32_t lg = 0;
+    while ((n >> (lg + 1)) != 0) lg++;
+    uint32_t cb = lg > 7 ? lg - 7 : 8;                       // about 128 list entries per bucket
+    if (cb < 8) cb = 8;
+    if (cb > blsgpu::SRT_MAXBITS) cb = blsgpu::SRT_MAXBITS;
+    if (const char* e = getenv("BLSGPU_MSM_SORT_BITS")) cb = (uint32_t)strtoul(e, nullptr, 10);
+    if (cb < 5 || cb > blsgpu::SRT_MAXBITS) return fail(-EINVAL, "BLSGPU_MSM_SORT_BITS out of range");
+    const uint32_t nwin = (256 + cb - 1) / cb;
+    const size_t nkeys = (size_t)nwin << cb;
+    if ((size_t)nwin * n > 0xFFFFFFF0ull) return 1;
+    const size_t nch = ((size_t)1 << (cb - 1)) / blsgpu::SRT_BITADDS, nsum = (size_t)nwin * cb;
+    const size_t lanes = blsgpu::SRT_LANES;
+    // workspace: prep | cnt | start (+1) | cursor | maxcnt, total | idx | bsum | headpart | headkey | bit sums (two buffers) | winsums
+    size_t off = 0;
+    auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
+    const size_t o_prep = take(n * 36), o_cnt = take(nkeys), o_start = take(nkeys + 1), o_cur = take(nkeys), o_max = take(2),
+                 o_idx = take((size_t)nwin * n), o_bsum = take(nkeys * 36), o_hp = take(lanes * 36), o_hk = take(lanes),
+                 o_b0 = take(nsum * nch * 36), o_b1 = take(nsum * ((nch + 7) / 8) * 36), o_win = take((size_t)nwin * 36), o_live = take((n + 3) / 4),
+                 o_wtot = take(2 * (size_t)nwin), o_long = take(nkeys + 4);
+    if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, off)) return rc_;
+    uint32_t* W = c->d_buckets;
+    const uint32_t* sc = (const uint32_t*)d_scalars;
+    HIP_TRY(hipMemsetAsync(W + o_cnt, 0, nkeys * 4, st));
+    HIP_TRY(hipMemsetAsync(W + o_long, 0, 16, st));          // counter of the long runs (the key list follows it)
+    size_t pblocks = (n + (size_t)MSM_WAVES * C::NP - 1) / ((size_t)MSM_WAVES * C::NP);
+    hipLaunchKernelGGL(blsgpu::k_msm_prep<1>, dim3((unsigned)pblocks), dim3(MSM_WAVES * 64), (size_t)MSM_WAVES * blsgpu::TEAM_BYTES, st,
+                       c->tabs, (const uint32_t*)d_pts, (uint32_t)n, W + o_prep);
+    HIP_TRY(hipGetLastError());
+    uint8_t* live = (uint8_t*)(W + o_live);
+    const dim3 sgrid((unsigned)((n + blsgpu::SRT_SLICE - 1) / blsgpu::SRT_SLICE), nwin);
+    hipLaunchKernelGGL(blsgpu::k_srt_live, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W + o_prep, (uint32_t)n, live);
+    hipLaunchKernelGGL(blsgpu::k_srt_count, sgrid, dim3(1024), 0, st, sc, live, (uint32_t)n, cb, W + o_cnt);
+    hipLaunchKernelGGL(blsgpu::k_srt_scan_window, dim3(nwin), dim3(1024), 0, st, W + o_cnt, cb, W + o_start, W + o_wtot, W + o_wtot + nwin);
+    hipLaunchKernelGGL(blsgpu::k_srt_scan_add, dim3(nwin), dim3(1024), 0, st, nwin, cb, W + o_wtot, W + o_wtot + nwin, W + o_start, W + o_cur,
+                       W + o_max);
+    HIP_TRY(hipGetLastError());
+    uint32_t h[2] = {0, 0};                                  // longest run, (unused)
+    HIP_TRY(hipMemcpyAsync(h, W + o_max, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h + 1, W + o_start + nkeys, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if ((uint64_t)h[0] * lanes > 2048ull * (uint64_t)h[1] + 2048ull * lanes) return 1;  // a run of more than ~2048 pieces
+    hipLaunchKernelGGL(blsgpu::k_srt_scatter, sgrid, dim3(1024), 0, st, sc, live, (uint32_t)n, cb, W + o_cur, W + o_idx);
+    hipLaunchKernelGGL(blsgpu::k_srt_accum, dim3((unsigned)(lanes / 64)), dim3(64), 0, st, W + o_prep, W + o_idx, W + o_start, (uint32_t)nkeys,
+                       (uint32_t)lanes, W + o_bsum, W + o_hp, W + o_hk);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(blsgpu::k_srt_fix, dim3((unsigned)((nkeys + 63) / 64)), dim3(64), 0, st, W + o_start, (uint32_t)nkeys, (uint32_t)lanes,
+                       W + o_hp, W + o_hk, W + o_bsum, W + o_long, W + o_long + 4);
+    hipLaunchKernelGGL(blsgpu::k_srt_fix_long, dim3(1024), dim3(64), 0, st, W + o_start, (uint32_t)nkeys, (uint32_t)lanes, W + o_hp, W + o_bsum,
+                       W + o_long, W + o_long + 4);
+    const size_t btotal = nsum * nch;
+    hipLaunchKernelGGL(blsgpu::k_srt_bits, dim3((unsigned)((btotal + 63) / 64)), dim3(64), 0, st, W + o_bsum, nwin, cb, (uint32_t)btotal, W + o_b0);
+    HIP_TRY(hipGetLastError());
+    uint32_t *src = W + o_b0, *dst = W + o_b1;
+    for (size_t cur = nch; cur > 1;) {                        // runs of 8 partial sums per lane until one is left per (window, bit)
+        const size_t nfold = (cur + 7) / 8, ftotal = nsum * nfold;
+        hipLaunchKernelGGL(blsgpu::k_msm_lane_fold<1>, dim3((unsigned)((ftotal + 63) / 64)), dim3(64), 0, st, src, (uint32_t)cur, 8u,
+                           (uint32_t)nfold, (uint32_t)ftotal, dst);
+        HIP_TRY(hipGetLastError());
+        uint32_t* t = src; src = dst; dst = t;
+        cur = nfold;
+    }
+    hipLaunchKernelGGL(blsgpu::k_srt_windows, dim3(nwin), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, src, cb, W + o_win);
+    hipLaunchKernelGGL(blsgpu::k_msm_pip_horner<1>, dim3(1), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, W + o_win, nwin, cb,
+                       (uint32_t*)d_out, (uint8_t*)d_out_inf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int DEG>
 int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, size_t groups, void* d_out,
             void* d_out_inf, hipStream_t st) {
@@ -239,6 +313,10 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
         return 0;
     }
     if (k > 0x7FFFFFFFull || groups > 0x7FFFFFFFull || k * groups > 0xFFFFFFF0ull) return fail(-EINVAL, "msm too large");
+    if (DEG == 1 && groups == 1 && d_scalars && k >= c->msm_sort_threshold) {
+        const int rc_ = msm_sorted_g1(c, d_pts, d_scalars, k, d_out, d_out_inf, st);
+        if (rc_ != 1) return rc_;
+    }
     if ((groups == 1 && k >= c->pip_threshold) || (groups > 1 && groups <= 65535 && k >= c->pip_group_threshold)) {
         // bucket method: one large sum is cut into about 256 chunks; a batch of sums uses one chunk per group
         using P = blsgpu::PipCfg<DEG>;
@@ -293,7 +371,7 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(blsgpu::k_msm_pip_horner<DEG>, dim3((unsigned)groups), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, d_win,
-                           (uint32_t*)d_out, (uint8_t*)d_out_inf);
+                           (uint32_t)blsgpu::PIP_W, (uint32_t)blsgpu::PIP_C, (uint32_t*)d_out, (uint8_t*)d_out_inf);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -371,6 +449,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_LANE_THRESHOLD")) c->msm_lane_threshold = (size_t)strtoull(e, nullptr, 10);
     // pack all tables into one device allocation (16-byte aligned pieces)
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };

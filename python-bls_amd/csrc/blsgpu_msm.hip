@@ -353,22 +353,22 @@ __global__ void __launch_bounds__(64) k_msm_pip_windows(VmTables T, const uint32
     for (uint32_t d = lane; d < PJ_DW; d += 64) winsums[(size_t)win * PJ_DW + d] = team[C::PR0 * 12 + d];
 }
 
-// result = sum_w 2^(PIP_C w) W_w  (Horner from the top window), affine canonical bytes
+// result = sum_w 2^(cbits w) W_w over nwin windows (Horner from the top window), affine canonical bytes
 template <int DEG>
-__global__ void __launch_bounds__(64) k_msm_pip_horner(VmTables T, const uint32_t* __restrict__ winsums, uint32_t* __restrict__ out,
-                                                       uint8_t* __restrict__ out_inf) {
+__global__ void __launch_bounds__(64) k_msm_pip_horner(VmTables T, const uint32_t* __restrict__ winsums, uint32_t nwin, uint32_t cbits,
+                                                       uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf) {
     using C = MsmCfg<DEG>;
     constexpr uint32_t PJ_DW = 36 * DEG, PT_DW = 24 * DEG;
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     team_init_consts(T, team, lane);
     wave_fence();
-    winsums += (size_t)blockIdx.x * PIP_W * PJ_DW;              // blockIdx.x = group
+    winsums += (size_t)blockIdx.x * nwin * PJ_DW;               // blockIdx.x = group
     out += (size_t)blockIdx.x * PT_DW;
-    for (uint32_t d = lane; d < PJ_DW; d += 64) team[C::PR0 * 12 + d] = winsums[(size_t)(PIP_W - 1) * PJ_DW + d];
+    for (uint32_t d = lane; d < PJ_DW; d += 64) team[C::PR0 * 12 + d] = winsums[(size_t)(nwin - 1u) * PJ_DW + d];
     wave_fence();
-    for (int w = PIP_W - 2; w >= 0; w--) {
-        for (int s = 0; s < PIP_C; s++) run_rounds<true>(T, T.segflat + C::DBL_OFF, C::DBL_LEN, 0, lane);
+    for (int w = (int)nwin - 2; w >= 0; w--) {
+        for (uint32_t s = 0; s < cbits; s++) run_rounds<true>(T, T.segflat + C::DBL_OFF, C::DBL_LEN, 0, lane);
         for (uint32_t d = lane; d < PJ_DW; d += 64) team[C::PR1 * 12 + d] = winsums[(size_t)w * PJ_DW + d];
         wave_fence();
         run_rounds<true>(T, T.segflat + C::PADD_OFF, C::PADD_LEN, 0, lane);
@@ -480,6 +480,253 @@ __global__ void __launch_bounds__(64) k_msm_lane_fold(const uint32_t* __restrict
     reg::ptT<E> acc = lane_inf<E>();
     for (uint32_t i = lo; i < hi; i++) acc = reg::padd(acc, lane_ld_pt<E>(partials + ((size_t)w * chunks + i) * PJ_DW, false));
     lane_st_pt(acc, out + ((size_t)w * nfold + f) * PJ_DW);
+}
+
+// ---------------------------------------------------------------------------
+// Sorted buckets: ONE large G1 sum with scalars (BLS.aggregate_pub_keys(secure) at scale, bls.py:203-223 --
+// BASELINE config 5).  Windows of `cb` bits (13 for 2^20 points: 20 windows instead of 64); key = window * 2^cb +
+// digit.  A counting sort (k_srt_live, k_srt_count, k_srt_scan_*, k_srt_scatter) lists the point indices by key; the list is cut
+// into EQUAL pieces, one per lane (k_srt_accum): a lane keeps its running bucket sum in registers and adds affine
+// points to it (complete mixed addition, two wavefronts per SIMD), writing a sum out whenever the key changes.  A
+// bucket whose run begins in the lane is written by that lane alone; the piece of a run that continues from the lane
+// before goes to the lane's "head" slot and k_srt_fix / k_srt_fix_long add the heads to their buckets.  sum_d d B_d is taken bit by
+// bit -- S_b = sum of the buckets whose digit has bit b (k_srt_bits + k_msm_lane_fold: plain sums, no dependent
+// chain over 8191 buckets), W_w = sum_b 2^b S_b (k_srt_windows) -- then Horner over the windows.
+// Same value as the reference's double-and-add summed over the points (fields_t.py:705-740); parity is on the
+// affine result.  Points at infinity ((0,0)) and zero digits are left out of the list.
+constexpr uint32_t SRT_LANES = 2048u * 64u;                   // two wavefronts per SIMD
+
+// digit of window w straight from the big-endian scalar (one or two of its eight words)
+__device__ __forceinline__ uint32_t srt_digit_at(const uint32_t* __restrict__ sc, uint32_t w, uint32_t cb) {
+    const uint32_t o = w * cb, j = o >> 5, sft = o & 31u;
+    uint32_t v = bswap32(sc[7u - j]) >> sft;
+    if (sft + cb > 32u && j < 7u) v |= bswap32(sc[6u - j]) << (32u - sft);
+    return v & ((1u << cb) - 1u);
+}
+
+// live[i] = 0 for the (0,0) encoding of infinity (Z = 0 after k_msm_prep): such points are left out of the list
+__global__ void __launch_bounds__(256) k_srt_live(const uint32_t* __restrict__ prep, uint32_t n, uint8_t* __restrict__ live) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t z = 0;
+    for (int j = 0; j < 12; j++) z |= prep[(size_t)i * 36 + 24 + j];
+    live[i] = z ? 1 : 0;
+}
+
+// Counting sort by key, histograms in LDS.  Workgroup (slice, window) owns SRT_SLICE consecutive points and the
+// 2^cb digits of one window: k_srt_count adds its histogram to cnt[]; k_srt_scatter rebuilds the histogram, reserves a
+// range of every non-empty bucket's run with ONE global atomic per bucket, and hands the positions out from LDS.
+constexpr uint32_t SRT_SLICE = 65536;
+constexpr uint32_t SRT_MAXBITS = 13;                          // 2^13 u32 of LDS per workgroup
+
+__device__ __forceinline__ void srt_histogram(uint32_t* hist, const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ live,
+                                              uint32_t lo, uint32_t hi, uint32_t w, uint32_t cb) {
+    for (uint32_t k = threadIdx.x; k < (1u << cb); k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t d = live[i] ? srt_digit_at(scalars + (size_t)i * 8, w, cb) : 0u;
+        if (d) atomicAdd(&hist[d], 1u);
+    }
+    __syncthreads();
+}
+__global__ void __launch_bounds__(1024) k_srt_count(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ live, uint32_t n,
+                                                    uint32_t cb, uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t hist[1u << SRT_MAXBITS];
+    const uint32_t w = blockIdx.y, lo = blockIdx.x * SRT_SLICE, hi = min(n, lo + SRT_SLICE);
+    srt_histogram(hist, scalars, live, lo, hi, w, cb);
+    for (uint32_t k = threadIdx.x; k < (1u << cb); k += blockDim.x)
+        if (hist[k]) atomicAdd(&cnt[(w << cb) + k], hist[k]);
+}
+
+// start[key] = exclusive prefix sum of cnt (start[nkeys] = number of list entries), cursor = start.
+// k_srt_scan_window: workgroup w scans the 2^cb counts of its window (positions inside the window) and notes the window's
+// total and longest run; k_srt_scan_add: adds the totals of the windows before.
+__global__ void __launch_bounds__(1024) k_srt_scan_window(const uint32_t* __restrict__ cnt, uint32_t cb, uint32_t* __restrict__ start,
+                                                          uint32_t* __restrict__ wtot, uint32_t* __restrict__ wmax) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t mx[1024];
+    const uint32_t t = threadIdx.x, nb = 1u << cb, per = (nb + 1023u) / 1024u;
+    const uint32_t lo = min(nb, t * per), hi = min(nb, lo + per);
+    const uint32_t* c = cnt + ((size_t)blockIdx.x << cb);
+    uint32_t s = 0, m = 0;
+    for (uint32_t k = lo; k < hi; k++) { s += c[k]; m = max(m, c[k]); }
+    part[t] = s;
+    mx[t] = m;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {           // Hillis-Steele inclusive scan
+        const uint32_t v = (t >= off) ? part[t - off] : 0u;
+        const uint32_t w = (t >= off) ? mx[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        mx[t] = max(mx[t], w);
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (uint32_t k = lo; k < hi; k++) {
+        start[((size_t)blockIdx.x << cb) + k] = run;
+        run += c[k];
+    }
+    if (t == 1023) { wtot[blockIdx.x] = part[t]; wmax[blockIdx.x] = mx[t]; }
+}
+__global__ void __launch_bounds__(1024) k_srt_scan_add(uint32_t nwin, uint32_t cb, const uint32_t* __restrict__ wtot,
+                                                       const uint32_t* __restrict__ wmax, uint32_t* __restrict__ start,
+                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ maxcnt) {
+    uint32_t base = 0, all = 0, m = 0;
+    for (uint32_t w = 0; w < nwin; w++) {
+        if (w < blockIdx.x) base += wtot[w];
+        all += wtot[w];
+        m = max(m, wmax[w]);
+    }
+    for (uint32_t k = threadIdx.x; k < (1u << cb); k += blockDim.x) {
+        const size_t key = ((size_t)blockIdx.x << cb) + k;
+        const uint32_t v = start[key] + base;
+        start[key] = v;
+        cursor[key] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { start[(size_t)nwin << cb] = all; maxcnt[0] = m; }
+}
+
+__global__ void __launch_bounds__(1024) k_srt_scatter(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ live, uint32_t n,
+                                                      uint32_t cb, uint32_t* __restrict__ cursor, uint32_t* __restrict__ idx) {
+    __shared__ uint32_t hist[1u << SRT_MAXBITS];
+    const uint32_t w = blockIdx.y, lo = blockIdx.x * SRT_SLICE, hi = min(n, lo + SRT_SLICE);
+    srt_histogram(hist, scalars, live, lo, hi, w, cb);
+    for (uint32_t k = threadIdx.x; k < (1u << cb); k += blockDim.x)
+        if (hist[k]) hist[k] = atomicAdd(&cursor[(w << cb) + k], hist[k]);        // first list position of this slice's entries
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t d = live[i] ? srt_digit_at(scalars + (size_t)i * 8, w, cb) : 0u;
+        if (d) idx[atomicAdd(&hist[d], 1u)] = i;
+    }
+}
+
+// lane l sums list entries [l per, (l + 1) per): see the header of this section.  headkey[l] = key of the piece
+// that continues a run begun before the lane (or ~0), headpart[l] its sum.
+__global__ void __launch_bounds__(64, 2) k_srt_accum(const uint32_t* __restrict__ prep, const uint32_t* __restrict__ idx,
+                                                     const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
+                                                     uint32_t* __restrict__ bsum, uint32_t* __restrict__ headpart,
+                                                     uint32_t* __restrict__ headkey) {
+    const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= nlanes) return;
+    const uint32_t total = start[nkeys], per = (total + nlanes - 1u) / nlanes;
+    const uint32_t p0 = min(total, L * per), p1 = min(total, p0 + per);
+    uint32_t hk = 0xFFFFFFFFu;
+    if (p0 < p1) {
+        uint32_t lo = 0, hi = nkeys;                          // last key with start[key] <= p0 (the one that owns p0)
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (start[mid] <= p0) lo = mid; else hi = mid;
+        }
+        uint32_t key = lo, nxt = start[key + 1];
+        bool head = start[key] < p0;
+        reg::ptT<reg::fe> acc = lane_inf<reg::fe>();
+#pragma unroll 1
+        for (uint32_t p = p0; p < p1; p++) {
+            if (p == nxt) {                                   // the run of `key` ends here
+                if (head) { lane_st_pt(acc, headpart + (size_t)L * 36); hk = key; }
+                else lane_st_pt(acc, bsum + (size_t)key * 36);
+                head = false;
+                acc = lane_inf<reg::fe>();
+                do { key++; nxt = start[key + 1]; } while (nxt <= p);
+            }
+            const uint32_t* pt = prep + (size_t)idx[p] * 36;
+            reg::fe x2, y2;
+            lane_ld(x2, pt, true);
+            lane_ld(y2, pt + 12, true);
+            reg::pmadd(acc, x2, y2);
+        }
+        if (head) { lane_st_pt(acc, headpart + (size_t)L * 36); hk = key; }
+        else lane_st_pt(acc, bsum + (size_t)key * 36);
+    }
+    headkey[L] = hk;
+}
+
+// one lane per key: empty buckets become infinity, the pieces of later lanes are added to the bucket.  A run of more
+// than SRT_LONG pieces (the top window of 255-bit scalars has 2^8 digits for 2^20 points) goes to k_srt_fix_long.
+constexpr uint32_t SRT_LONG = 3;
+__global__ void __launch_bounds__(64) k_srt_fix(const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
+                                                const uint32_t* __restrict__ headpart, const uint32_t* __restrict__ headkey,
+                                                uint32_t* __restrict__ bsum, uint32_t* __restrict__ nlong, uint32_t* __restrict__ longkeys) {
+    const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= nkeys) return;
+    const uint32_t total = start[nkeys], per = (total + nlanes - 1u) / nlanes;
+    const uint32_t s = start[key], e = start[key + 1];
+    if (s == e) { lane_st_pt(lane_inf<reg::fe>(), bsum + (size_t)key * 36); return; }
+    const uint32_t l0 = s / per, l1 = (e - 1u) / per;
+    if (l0 == l1) return;
+    if (l1 - l0 > SRT_LONG) { longkeys[atomicAdd(nlong, 1u)] = key; return; }
+    reg::ptT<reg::fe> acc = lane_ld_pt<reg::fe>(bsum + (size_t)key * 36, false);
+#pragma unroll 1
+    for (uint32_t l = l0 + 1; l <= l1; l++)
+        if (headkey[l] == key) acc = reg::padd(acc, lane_ld_pt<reg::fe>(headpart + (size_t)l * 36, false));
+    lane_st_pt(acc, bsum + (size_t)key * 36);
+}
+
+// one wavefront per long run: lane j sums the pieces l0 + 1 + j, + 64, ..; butterfly over the lanes; lane 0 adds the bucket
+__global__ void __launch_bounds__(64) k_srt_fix_long(const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
+                                                     const uint32_t* __restrict__ headpart, uint32_t* __restrict__ bsum,
+                                                     const uint32_t* __restrict__ nlong, const uint32_t* __restrict__ longkeys) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = start[nkeys], per = (total + nlanes - 1u) / nlanes, cnt = *nlong;
+    for (uint32_t k = blockIdx.x; k < cnt; k += gridDim.x) {
+        const uint32_t key = longkeys[k];
+        const uint32_t l0 = start[key] / per, l1 = (start[key + 1] - 1u) / per;
+        reg::ptT<reg::fe> acc = lane_inf<reg::fe>();
+#pragma unroll 1
+        for (uint32_t l = l0 + 1u + lane; l <= l1; l += 64u) acc = reg::padd(acc, lane_ld_pt<reg::fe>(headpart + (size_t)l * 36, false));
+#pragma unroll 1
+        for (int off = 32; off > 0; off >>= 1) {
+            reg::ptT<reg::fe> o;
+            uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+            const uint32_t* aw = reinterpret_cast<const uint32_t*>(&acc);
+#pragma unroll
+            for (int q = 0; q < 36; q++) ow[q] = (uint32_t)__shfl_xor((int)aw[q], off);
+            acc = reg::padd(acc, o);
+        }
+        if (lane == 0) {
+            acc = reg::padd(acc, lane_ld_pt<reg::fe>(bsum + (size_t)key * 36, false));
+            lane_st_pt(acc, bsum + (size_t)key * 36);
+        }
+    }
+}
+
+// lane (window w, bit b, item j): the SRT_BITADDS buckets of window w whose digits are the numbers m = SRT_BITADDS j ..
+// + SRT_BITADDS - 1 with a 1 inserted at bit b (the m-th digit that has bit b) -> out[(w * cb + b) * nitem + j]; every lane
+// the same number of additions, 2^(cb-1) / SRT_BITADDS items per (window, bit)
+constexpr uint32_t SRT_BITADDS = 8;
+__global__ void __launch_bounds__(64) k_srt_bits(const uint32_t* __restrict__ bsum, uint32_t nwin, uint32_t cb, uint32_t total,
+                                                 uint32_t* __restrict__ out) {
+    const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= total) return;
+    const uint32_t nitem = (1u << (cb - 1u)) / SRT_BITADDS;
+    const uint32_t j = L % nitem, b = (L / nitem) % cb, w = L / (nitem * cb);
+    reg::ptT<reg::fe> acc = lane_inf<reg::fe>();
+#pragma unroll 1
+    for (uint32_t m = j * SRT_BITADDS; m < (j + 1u) * SRT_BITADDS; m++) {
+        const uint32_t d = ((m >> b) << (b + 1u)) | (1u << b) | (m & ((1u << b) - 1u));
+        acc = reg::padd(acc, lane_ld_pt<reg::fe>(bsum + ((size_t)(w << cb) + d) * 36, false));
+    }
+    lane_st_pt(acc, out + (size_t)L * 36);
+}
+
+// W_w = sum_b 2^b S_(w,b): one team per window, Horner over the bits
+__global__ void __launch_bounds__(64) k_srt_windows(VmTables T, const uint32_t* __restrict__ bitsums, uint32_t cb, uint32_t* __restrict__ winsums) {
+    using C = MsmCfg<1>;
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    team_init_consts(T, team, lane);
+    wave_fence();
+    const uint32_t* src = bitsums + (size_t)blockIdx.x * cb * 36;
+    for (uint32_t d = lane; d < 36; d += 64) team[C::PR0 * 12 + d] = src[(size_t)(cb - 1u) * 36 + d];
+    wave_fence();
+    for (int b = (int)cb - 2; b >= 0; b--) {
+        run_rounds<true>(T, T.segflat + C::DBL_OFF, C::DBL_LEN, 0, lane);
+        for (uint32_t d = lane; d < 36; d += 64) team[C::PR1 * 12 + d] = src[(size_t)b * 36 + d];
+        wave_fence();
+        run_rounds<true>(T, T.segflat + C::PADD_OFF, C::PADD_LEN, 0, lane);
+    }
+    wave_fence();
+    for (uint32_t d = lane; d < 36; d += 64) winsums[(size_t)blockIdx.x * 36 + d] = team[C::PR0 * 12 + d];
 }
 
 }  // namespace blsgpu

@@ -240,6 +240,42 @@ def test_lane_bucket_method_degenerate(lane_engine, engine, golden):
     assert lane_engine.g1_msm(P * 40, [5] * 40, 40) == engine.g1_msm(P, [200], 1)
 
 
+@pytest.fixture(scope="module")
+def sorted_engine():
+    """An engine whose single G1 sums with scalars use the sorted buckets (k_srt_*) from 1 point on."""
+    return _engine_with(("BLSGPU_MSM_SORT_THRESHOLD",))
+
+
+@pytest.mark.parametrize("k", [1, 2, 65, 700, 3000])
+def test_sorted_buckets_vs_oracle(sorted_engine, oracle, seeded_pairs, k):
+    """k_srt_count/scan/scatter/accum/fix/bits/windows (8-bit windows at these sizes) against the oracle:
+    random, short, zero and extreme scalars, a point at infinity and repeated points in the list."""
+    g1, _ = seeded_pairs
+    rnd = random.Random(k * 13 + 1)
+    pts = bytearray((g1 * 3)[96 * 3:96 * (3 + k)])
+    sc = [rnd.choice([rnd.randrange(N), rnd.randrange(N), rnd.randrange(1 << 40), 0, N - 1, 1, (1 << 256) - 1]) for _ in range(k)]
+    if k >= 65:
+        pts[96 * 7:96 * 8] = bytes(96)                          # infinity in the list
+        pts[96 * 9:96 * 10] = pts[96 * 8:96 * 9]                # the same point twice ...
+        sc[9] = sc[8] = rnd.randrange(N)                        # ... in the same buckets (doubling inside the addition)
+    got, inf = sorted_engine.g1_msm(bytes(pts), sc, k, 1)
+    want, _ = oracle.g1_msm(bytes(pts), sc, k)
+    assert got == want and inf[0] == (want == bytes(96))
+
+
+def test_sorted_buckets_degenerate(sorted_engine, engine, golden):
+    p = golden("points.json")
+    P = bytes.fromhex(p["g1"][3]["p"])
+    negP = P[:48] + ((Q - int.from_bytes(P[48:], "big")) % Q).to_bytes(48, "big")
+    assert sorted_engine.g1_msm(P + negP, [5, 5], 2) == (bytes(96), [True])
+    assert sorted_engine.g1_msm(P * 3, [0, 0, 0], 3) == (bytes(96), [True])
+    assert sorted_engine.g1_msm(P + bytes(96), [7, 9], 2) == engine.g1_msm(P, [7], 1)
+    # every point in the same buckets: the list is one run per window -> the uneven-digits guard hands the sum to
+    # the fixed-window kernels; same result
+    assert sorted_engine.g1_msm(P * 400, [5] * 400, 400) == engine.g1_msm(P, [2000], 1)
+    assert sorted_engine.g1_msm(P * 40, [N - 1] * 40, 40) == engine.g1_msm(P, [(N - 1) * 40 % N], 1)
+
+
 N_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 
 
