@@ -548,18 +548,22 @@ def run_c5(env, args):
     if env.rank == 0:
         if not all(oks):
             raise SystemExit("result mismatch -- bench invalid")
-        # algorithmic work: 64 windows x (n + 2 x 15) mixed G1 additions of 11 Fq-mults
-        mac = 64 * (n + 30) * 11 * MAC_PER_FQ_MUL
+        # algorithmic work, SURVEY 8(d): Pippenger with 16-bit windows = 16 windows x (n + 2^16) mixed G1 additions of 11
+        # Fq-mults (1.9e8 Fq-mults for 2^20 points).  Executed: 20 windows of 13 bits -- 20 n list additions of 11 Fq-mults
+        # plus 20 x 13 x 4096 + 20 x 8191 full additions (12) for the buckets' bit sums and continuation pieces.
+        mac = 16 * (n + 65536) * 11 * MAC_PER_FQ_MUL
+        executed = (20 * n * 11 + (20 * 13 * 4096 + 20 * 8191) * 12) * MAC_PER_FQ_MUL
         print(json.dumps({
             "metric": "G1 multi-scalar-sum points/sec", "value": n * env.world / dtm, "unit": "points/s", "n_gpus": env.world,
             "steps": reps, "warmup": 1, "ms_per_step": dtm * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4]: one G1 multi-scalar sum over %d different PRF points per GPU; bucket method with "
-                                   "4-bit windows, one (chunk, window) per lane, buckets in HBM (faster than the LDS-bucket kernels "
-                                   "from 65 536 points on: DESIGN.md 2d)" % n, "name": "c5",
+            "config": {"workload": "BASELINE configs[4]: one G1 multi-scalar sum over %d different PRF points per GPU; sorted buckets: "
+                                   "13-bit windows, counting sort of the (window, digit) keys, equal pieces of the sorted list per lane "
+                                   "(complete mixed additions in registers), bit sums of the buckets, Horner (DESIGN.md 2d)" % n, "name": "c5",
                        "check": "sum t_i (a_i G) == (sum t_i a_i) G"},
-            "roofline": {"bound": "valu-int32-mac", "kernel": "k_msm_lane<1> (+ k_msm_prep, fold, windows, horner)", "peak": PEAK_TMACS,
-                         "unit": "TMAC/s", "achieved": mac / dt / 1e12, "frac": mac / dt / 1e12 / PEAK_TMACS, "traffic": None,
+            "roofline": {"bound": "valu-int32-mac", "kernel": "k_srt_accum (+ k_msm_prep, k_srt_count/scan/scatter/fix/bits, fold, windows, horner)",
+                         "peak": PEAK_TMACS, "unit": "TMAC/s", "achieved": mac / dt / 1e12, "frac": mac / dt / 1e12 / PEAK_TMACS, "traffic": None,
+                         "executed_TMACs": executed / dt / 1e12 if n == 1 << 20 else None,
                          "algorithmic_bytes": n * (96 + 32), "hbm_GBps_algorithmic": n * 128 / dt / 1e9}}))
 
 

@@ -602,7 +602,10 @@ __global__ void __launch_bounds__(1024) k_srt_scatter(const uint32_t* __restrict
 
 // lane l sums list entries [l per, (l + 1) per): see the header of this section.  headkey[l] = key of the piece
 // that continues a run begun before the lane (or ~0), headpart[l] its sum.
-__global__ void __launch_bounds__(64, 2) k_srt_accum(const uint32_t* __restrict__ prep, const uint32_t* __restrict__ idx,
+#ifndef BLSGPU_SRT_WAVES
+#define BLSGPU_SRT_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, BLSGPU_SRT_WAVES) k_srt_accum(const uint32_t* __restrict__ prep, const uint32_t* __restrict__ idx,
                                                      const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
                                                      uint32_t* __restrict__ bsum, uint32_t* __restrict__ headpart,
                                                      uint32_t* __restrict__ headkey) {
@@ -629,7 +632,11 @@ __global__ void __launch_bounds__(64, 2) k_srt_accum(const uint32_t* __restrict_
                 acc = lane_inf<reg::fe>();
                 do { key++; nxt = start[key + 1]; } while (nxt <= p);
             }
+#ifdef BLSGPU_EXP_NOGATHER
+            const uint32_t* pt = prep + (size_t)(p & 1023u) * 36;
+#else
             const uint32_t* pt = prep + (size_t)idx[p] * 36;
+#endif
             reg::fe x2, y2;
             lane_ld(x2, pt, true);
             lane_ld(y2, pt + 12, true);

@@ -21,8 +21,31 @@ __device__ __attribute__((noinline)) fe fe_mul(fe x, fe y) {
     bls::fq_mul(r.v, x.v, y.v);
     return r;
 }
-__device__ __forceinline__ fe fe_add(fe x, const fe& y) { bls::fq_add_mod(x.v, y.v); return x; }
-__device__ __forceinline__ fe fe_sub(fe x, const fe& y) { bls::fq_sub_mod(x.v, y.v); return x; }
+// modular addition / subtraction of canonical values as three carry chains of 12 (sum, trial subtraction, select)
+__device__ __forceinline__ fe fe_add(const fe& x, const fe& y) {
+    const uint32_t q[12] = BLS_Q_LIMBS;
+    uint32_t t[12], d[12], c = 0, br = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) t[j] = bls::addc(x.v[j], y.v[j], c);
+#pragma unroll
+    for (int j = 0; j < 12; j++) d[j] = bls::subc(t[j], q[j], br);
+    const bool ge = (c != 0) || (br == 0);
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 12; j++) r.v[j] = ge ? d[j] : t[j];
+    return r;
+}
+__device__ __forceinline__ fe fe_sub(const fe& x, const fe& y) {
+    const uint32_t q[12] = BLS_Q_LIMBS;
+    uint32_t d[12], br = 0, c = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) d[j] = bls::subc(x.v[j], y.v[j], br);
+    const uint32_t mask = 0u - br;
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 12; j++) r.v[j] = bls::addc(d[j], q[j] & mask, c);
+    return r;
+}
 __device__ __forceinline__ fe fe_zero() { fe r; for (int j = 0; j < 12; j++) r.v[j] = 0; return r; }
 __device__ __forceinline__ fe fe_neg(const fe& x) { return fe_sub(fe_zero(), x); }
 __device__ __forceinline__ fe2 f2_add(const fe2& x, const fe2& y) { return {fe_add(x.a, y.a), fe_add(x.b, y.b)}; }
