@@ -448,19 +448,48 @@ __global__ void __launch_bounds__(64) k_msm_lane(const uint32_t* __restrict__ pr
         const reg::ptT<E> inf = lane_inf<E>();
         for (int j = 0; j < PIP_NB - 1; j++) lane_st_pt(inf, B + j * PJ_DW);
     }
+    // Signed digits: the nibbles of s + 0x88..8 minus 8 are digits in [-8, 7] with the same value (no carry out of
+    // 256 bits while s < 2^256 - 0x88..8, which covers every scalar below the group order), so 8 buckets take
+    // +-P and the running sums below cover 8 buckets instead of 15.  A larger scalar keeps its plain nibbles
+    // (buckets 1 .. 15); the lanes of a wavefront see the same scalars, so `wide` is uniform.
+    bool wide = false;
     for (uint32_t i = lo; i < hi; i++) {
-        uint32_t dig;
-        if (scalars) dig = (bswap32(scalars[(size_t)i * 8 + (7 - win / 8)]) >> (4 * (win % 8))) & 15u;
-        else dig = (win == 0) ? 1u : 0u;
-        if (dig) {
-            uint32_t* b = B + (dig - 1) * PJ_DW;
-            const reg::ptT<E> r = reg::padd(lane_ld_pt<E>(b, false), lane_ld_pt<E>(prep + (size_t)i * PJ_DW, true));
+        const uint32_t* pt = prep + (size_t)i * PJ_DW;
+        uint32_t z = 0;
+        for (uint32_t j = 0; j < 12u * DEG; j++) z |= pt[24u * DEG + j];
+        if (z == 0) continue;                                                   // the point at infinity
+        uint32_t word;                                                          // the 32 bits that hold this window's nibble
+        bool big = false;
+        if (scalars) {
+            const uint32_t* sc = scalars + (size_t)i * 8;
+            big = bswap32(sc[0]) > 0x77777776u;
+            if (!big) {
+                uint32_t c = 0;
+                word = 0;
+                for (uint32_t j = 0; j <= win / 8; j++) word = bls::addc(bswap32(sc[7u - j]), 0x88888888u, c);
+            } else {
+                word = bswap32(sc[7 - win / 8]);
+            }
+        } else {
+            word = (win < 8) ? 0x88888889u : 0x88888888u;
+        }
+        const int nib = (int)((word >> (4 * (win % 8))) & 15u);
+        const int d = big ? nib : nib - 8;
+        wide = wide || big;
+        if (d != 0) {
+            uint32_t* b = B + ((d < 0 ? -d : d) - 1) * PJ_DW;
+            E x2, y2;
+            lane_ld(x2, pt, true);
+            lane_ld(y2, pt + 12 * DEG, true);
+            if (d < 0) y2 = reg::eneg(y2);
+            reg::ptT<E> r = lane_ld_pt<E>(b, false);
+            reg::pmadd(r, x2, y2);
             lane_st_pt(r, b);
         }
     }
     reg::ptT<E> acc = lane_inf<E>(), tot = lane_inf<E>();                       // sum_j j B_j by running sums
 #pragma unroll 1
-    for (int j = PIP_NB - 2; j >= 0; j--) {
+    for (int j = wide ? PIP_NB - 2 : PIP_NB / 2 - 1; j >= 0; j--) {
         acc = reg::padd(acc, lane_ld_pt<E>(B + j * PJ_DW, false));
         tot = reg::padd(tot, acc);
     }

@@ -110,19 +110,20 @@ __device__ ptT<E> pdbl(const ptT<E>& P) {
 }
 // complete mixed addition, RCB algorithm 8 (a = 0): P += (x2 : y2 : 1); (x2, y2) is an affine point, P any
 // point including (0 : 1 : 0).  11 products; the operands die early, so a G1 addition fits 256 registers.
-__device__ __forceinline__ void pmadd(ptT<fe>& P, const fe& x2, const fe& y2) {
-    fe t0 = fe_mul(P.X, x2), t1 = fe_mul(P.Y, y2);
-    fe t3 = fe_sub(fe_sub(fe_mul(fe_add(x2, y2), fe_add(P.X, P.Y)), t0), t1);
-    fe t4 = fe_add(fe_mul(y2, P.Z), P.Y);
-    fe y3 = fe_add(fe_mul(x2, P.Z), P.X);
+template <class E>
+__device__ __forceinline__ void pmadd(ptT<E>& P, const E& x2, const E& y2) {
+    E t0 = emul(P.X, x2), t1 = emul(P.Y, y2);
+    E t3 = esub(esub(emul(eadd(x2, y2), eadd(P.X, P.Y)), t0), t1);
+    E t4 = eadd(emul(y2, P.Z), P.Y);
+    E y3 = eadd(emul(x2, P.Z), P.X);
     t0 = ex3(t0);
-    const fe t2 = eb3(P.Z);
-    const fe z3 = fe_add(t1, t2);
-    t1 = fe_sub(t1, t2);
+    const E t2 = eb3(P.Z);
+    const E z3 = eadd(t1, t2);
+    t1 = esub(t1, t2);
     y3 = eb3(y3);
-    P.X = fe_sub(fe_mul(t3, t1), fe_mul(t4, y3));
-    P.Y = fe_add(fe_mul(y3, t0), fe_mul(t1, z3));
-    P.Z = fe_add(fe_mul(z3, t4), fe_mul(t0, t3));
+    P.X = esub(emul(t3, t1), emul(t4, y3));
+    P.Y = eadd(emul(y3, t0), emul(t1, z3));
+    P.Z = eadd(emul(z3, t4), emul(t0, t3));
 }
 template <class E> __device__ __forceinline__ ptT<E> pneg(const ptT<E>& P) { return {P.X, eneg(P.Y), P.Z}; }
 typedef ptT<fe2> pt;                                         // a point of the twist

@@ -230,6 +230,23 @@ def test_lane_bucket_method_vs_oracle(lane_engine, oracle, seeded_pairs, k, grou
             assert out2[192 * g:192 * (g + 1)] == oracle.g2_msm(pts2[192 * k * g:192 * k * (g + 1)], sc[k * g:k * (g + 1)], k)[0]
 
 
+def test_lane_bucket_method_scalars_beyond_the_signed_digit_range(lane_engine, oracle, seeded_pairs):
+    """k_msm_lane recodes scalars below 2^256 - 0x88..8 into signed nibbles (8 buckets); larger ones keep plain
+    nibbles (15 buckets), also mixed inside one chunk: the boundary values and 2^256 - 1 against the oracle."""
+    g1, g2 = seeded_pairs
+    edge = [(1 << 256) - 1, 0x77777777 << 224, (0x77777777 << 224) - 1, int("7" * 64, 16), int("7" * 64, 16) + 1, 1 << 255,
+            N - 1, 5, 0, int("8" * 64, 16), int("f" * 63 + "8", 16)]
+    for k, groups in ((len(edge), 1), (3, 3)):
+        n = k * groups
+        pts1, pts2 = g1[96 * 2:96 * (2 + n)], g2[192 * 2:192 * (2 + n)]
+        sc = (edge * 2)[:n]
+        out1, _ = lane_engine.g1_msm(pts1, sc, k, groups)
+        out2, _ = lane_engine.g2_msm(pts2, sc, k, groups)
+        for g in range(groups):
+            assert out1[96 * g:96 * (g + 1)] == oracle.g1_msm(pts1[96 * k * g:96 * k * (g + 1)], sc[k * g:k * (g + 1)], k)[0]
+            assert out2[192 * g:192 * (g + 1)] == oracle.g2_msm(pts2[192 * k * g:192 * k * (g + 1)], sc[k * g:k * (g + 1)], k)[0]
+
+
 def test_lane_bucket_method_degenerate(lane_engine, engine, golden):
     p = golden("points.json")
     P = bytes.fromhex(p["g1"][3]["p"])
