@@ -395,7 +395,8 @@ __global__ void __launch_bounds__(64) k_msm_pip_horner(VmTables T, const uint32_
 // ---------------------------------------------------------------------------
 // Bucket method with ONE (group, chunk, window) PER LANE (blsgpu_reg.hip): the lanes of a
 // wavefront are the 64 windows of the same chunk of points, so they read the same point
-// (one broadcast load) and add it to the bucket their own digit selects.  The 15 buckets
+// (one broadcast load) and add it to the bucket their own digit selects (signed nibbles:
+// buckets 1 .. 8 take +-P; 15 buckets for a scalar too large to recode).  The buckets
 // of a lane live in HBM (144 B G1 / 288 B G2 each, read and written once per addition:
 // ~0.3 KB of traffic against ~9 k / 25 k instructions).  Used when a batch offers enough
 // lanes to fill the chip (blsgpu_api.hip); the LDS-bucket kernels above serve the rest.
