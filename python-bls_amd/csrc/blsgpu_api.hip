@@ -55,7 +55,7 @@ struct blsgpu_ctx {
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
     size_t h2c_reg_threshold = (size_t)-1;  // messages from which cofactor clearing runs one message per lane (off: the VM form wins at every size)
-    size_t msm_sort_threshold = 262144; // points from which one G1 sum with scalars uses sorted buckets (k_srt_*)
+    size_t msm_sort_threshold = 16384;  // points from which one G1 sum with scalars uses sorted buckets (k_srt_*)
     size_t msm_lane_threshold = 65536; // points from which the bucket sums run one (group, chunk, window) per lane
     uint32_t* d_buckets = nullptr;     // their buckets (HBM)
     size_t bucket_cap = 0;
@@ -233,11 +233,11 @@ constexpr int MSM_WAVES = 4;
 // finished by ONE wavefront of k_srt_fix_long); the caller then takes the fixed-window path.
 static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* d_out_inf, hipStream_t st) {
     using C = blsgpu::MsmCfg<1>;
-    uint32_t lg = 0;
-    while ((n >> (lg + 1)) != 0) lg++;
-    uint32_t cb = lg > 7 ? lg - 7 : 8;                       // about 128 list entries per bucket
-    if (cb < 8) cb = 8;
-    if (cb > blsgpu::SRT_MAXBITS) cb = blsgpu::SRT_MAXBITS;
+    // Window bits: with 131 072 equal pieces a run covers 131072 / (2^cb windows) pieces whatever n is -- 0.8 for
+    // 13 bits, 1.5 for 12, 5 for 10 -- and a run of more than three pieces costs a whole wavefront in
+    // k_srt_fix_long, so only 12 and 13 bits (or very few keys: <= 7 bits) are cheap.  Measured (tools/c5_probe.py,
+    // profiles/r02_schedule_experiments.txt): 12 bits up to 2^18 points, 13 from there.
+    uint32_t cb = n >= 262144 ? 13 : 12;
     if (const char* e = getenv("BLSGPU_MSM_SORT_BITS")) cb = (uint32_t)strtoul(e, nullptr, 10);
     if (cb < 5 || cb > blsgpu::SRT_MAXBITS) return fail(-EINVAL, "BLSGPU_MSM_SORT_BITS out of range");
     const uint32_t nwin = (256 + cb - 1) / cb;
