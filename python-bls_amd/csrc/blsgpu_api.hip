@@ -54,7 +54,7 @@ struct blsgpu_ctx {
     size_t mp3_threshold = (size_t)-1; // ... with three pairs per wavefront from here on, two below; -1: the measured schedule
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
-    size_t h2c_reg_threshold = (size_t)-1;  // messages from which cofactor clearing runs one message per lane (off: the VM form wins at every size)
+    size_t h2c_reg_threshold = 65536;  // messages from which cofactor clearing runs one message per lane in registers (measured: DESIGN.md 2c)
     size_t msm_sort_threshold = 16384;  // points from which one G1 sum with scalars uses sorted buckets (k_srt_*)
     size_t msm_lane_threshold = 65536; // points from which the bucket sums run one (group, chunk, window) per lane
     uint32_t* d_buckets = nullptr;     // their buckets (HBM)
@@ -1032,7 +1032,7 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
     hipLaunchKernelGGL((blsgpu::k_h2c_stage<2, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,
                        (uint32_t)(2 * n), img);
     HIP_TRY(hipGetLastError());
-    if (n < c->h2c_reg_threshold) {        // the VM form (BLSVM_H2_NM messages per wavefront); default at every size
+    if (n < c->h2c_reg_threshold) {        // the VM form (BLSVM_H2_NM messages per wavefront)
         unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);
         hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)d_out);

@@ -76,8 +76,8 @@ def test_large_batch_properties(engine):
 
 
 def test_one_message_per_lane_clearing(golden):
-    """The register form of the cofactor clearing (an alternative selected with BLSGPU_H2C_REG_THRESHOLD), forced for a small
-    batch: reference vectors, infinity summands, ragged counts, and equality with the VM form."""
+    """The register form of the cofactor clearing (the default from 65 536 messages on; BLSGPU_H2C_REG_THRESHOLD), forced for a
+    small batch: reference vectors, infinity summands, ragged counts, and equality with the VM form."""
     import os
     from bls_py import _native
     old = os.environ.get("BLSGPU_H2C_REG_THRESHOLD")
