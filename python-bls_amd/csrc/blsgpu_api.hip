@@ -658,10 +658,12 @@ static int reduce_chain(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_t gr
 // Then k_miller_slow: it rewrites the partials of the blocks that met a degenerate pair with the
 // reference-faithful program (normally none: every wavefront leaves at once).
 constexpr unsigned SLOW_GRID = 1024;
+// team: 0 = choose by batch size; 2 / 3 = k_miller_mp with that many pairs per wavefront (groups of two or three pairs: one team
+// per group, the group's product comes out of the Miller kernel)
 static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups, bool one_per_block,
-                         uint32_t* d_partials, hipStream_t st, size_t* bpg_out) {
-    const bool mp = !one_per_block && use_mp(c, gsz * groups);
-    const bool mp2 = mp && use_mp2(c, gsz * groups);              // a few thousand pairs: teams of two fill the chip
+                         uint32_t* d_partials, hipStream_t st, size_t* bpg_out, int team = 0) {
+    const bool mp = team ? true : (!one_per_block && use_mp(c, gsz * groups));
+    const bool mp2 = team ? team == 2 : (mp && use_mp2(c, gsz * groups));   // a few thousand pairs: teams of two fill the chip
     const size_t per_block = one_per_block ? 1 : (mp ? (mp2 ? (size_t)2 : (size_t)BLSVM_MP_G) : (size_t)MILLER_WAVES);
     size_t bpg = (gsz + per_block - 1) / per_block;
     *bpg_out = bpg;
@@ -935,9 +937,13 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1
     if (gsz >= BATCH_TREE_MIN_GROUP) return grouped_pairing(c, d_g1, d_g2, d_inf, gsz, groups, nullptr, d_out, st);
     int rc = ensure_workspace(c, (n + 1) * MILLER_WAVES);      // one partial per PAIR here
     if (rc) return rc;
+    // groups of two or three pairs in a batch large enough for the team kernels: the group IS the team (one
+    // accumulator, its squarings shared), one partial per group; otherwise one partial per pair
+    const bool team_groups = (gsz == 2 || gsz == (size_t)BLSVM_MP_G) && use_mp(c, n) && groups <= 0x7FFFFFFFull;
     if (n) {
         size_t bpg = 0;
-        rc = launch_miller(c, d_g1, d_g2, d_inf, n, 1, true, c->d_part[0], st, &bpg);
+        rc = team_groups ? launch_miller(c, d_g1, d_g2, d_inf, gsz, groups, false, c->d_part[0], st, &bpg, (int)gsz)
+                         : launch_miller(c, d_g1, d_g2, d_inf, n, 1, true, c->d_part[0], st, &bpg);
         if (rc) return rc;
     }
     size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
@@ -945,7 +951,7 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1
     {
         KernelTimer kt(c, st, 2);
         hipLaunchKernelGGL(blsgpu::k_final_groups, dim3(blocks), dim3(REDUCE_WAVES * 64), lds, st, c->tabs, c->d_part[0],
-                           (uint32_t)gsz, (uint32_t)groups, (uint32_t*)d_out);
+                           (uint32_t)(team_groups ? 1 : gsz), (uint32_t)groups, (uint32_t*)d_out);
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -116,8 +116,9 @@ def test_degenerate_pairs_inside_large_batches(engine, golden, seeded_pairs, ora
     for kernel in KERNELS:
         with kernel_choice(engine, kernel):
             assert engine.pairing_multi(bytes(a), bytes(b), n, bytes(inf)) == want, kernel
-    # batch entry: groups of 3 (one k_miller wavefront per pair) and of 27 (per-group product tree)
-    for gsz in (3, 27):
+    # batch entry: groups of 3 (one k_miller wavefront per pair) and of 27 (per-group product tree); then groups of 2
+    # and 3 as the teams of k_miller_mp<2|3> (what a batch of >= 4096 pairs selects: the threshold is lowered here)
+    def check_groups(gsz):
         groups = n // gsz
         m = gsz * groups
         out = engine.pairing_multi_batch(bytes(a[:96 * m]), bytes(b[:192 * m]), gsz, groups, bytes(inf[:2 * m]))
@@ -126,6 +127,15 @@ def test_degenerate_pairs_inside_large_batches(engine, golden, seeded_pairs, ora
             want = oracle.pairing_multi(bytes(a[96 * sl.start:96 * sl.stop]), bytes(b[192 * sl.start:192 * sl.stop]), gsz,
                                         inf=bytes(inf[2 * sl.start:2 * sl.stop]))
             assert out[576 * g:576 * (g + 1)] == want, (gsz, g)
+
+    for gsz in (3, 27):
+        check_groups(gsz)
+    engine.set_mp_threshold(0)
+    try:
+        for gsz in (2, 3):
+            check_groups(gsz)
+    finally:
+        engine.set_mp_threshold(4096)
 
 
 def test_miller_loop_batch_is_the_reference_value(engine, golden, seeded_pairs, oracle):
