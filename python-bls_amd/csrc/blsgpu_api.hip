@@ -56,6 +56,7 @@ struct blsgpu_ctx {
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
     size_t h2c_reg_threshold = 65536;  // messages from which cofactor clearing runs one message per lane in registers (measured: DESIGN.md 2c)
     size_t msm_sort_threshold = 16384;  // points from which one G1 sum with scalars uses sorted buckets (k_srt_*)
+    size_t horner_np_threshold = 1024; // G2 sums per call from which the window Horner runs several sums per team
     size_t msm_lane_threshold = 65536; // points from which the bucket sums run one (group, chunk, window) per lane
     uint32_t* d_buckets = nullptr;     // their buckets (HBM)
     size_t bucket_cap = 0;
@@ -370,6 +371,13 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
                                c->tabs, c->d_msm_part, (uint32_t)chunks, d_win);
             HIP_TRY(hipGetLastError());
         }
+        if (DEG == 2 && groups >= c->horner_np_threshold) {  // a batch of G2 sums: BLSVM_HMSM2_NP sums per team
+            hipLaunchKernelGGL(blsgpu::k_msm_horner_np, dim3((unsigned)((groups + BLSVM_HMSM2_NP - 1) / BLSVM_HMSM2_NP)), dim3(64),
+                               (size_t)BLSVM_HMSM2_SLOTS * 48, st, c->tabs, d_win, (uint32_t)blsgpu::PIP_W, (uint32_t)blsgpu::PIP_C,
+                               (uint32_t)groups, (uint32_t*)d_out, (uint8_t*)d_out_inf);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         hipLaunchKernelGGL(blsgpu::k_msm_pip_horner<DEG>, dim3((unsigned)groups), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, d_win,
                            (uint32_t)blsgpu::PIP_W, (uint32_t)blsgpu::PIP_C, (uint32_t*)d_out, (uint8_t*)d_out_inf);
         HIP_TRY(hipGetLastError());
@@ -450,6 +458,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_HORNER_NP_THRESHOLD")) c->horner_np_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_LANE_THRESHOLD")) c->msm_lane_threshold = (size_t)strtoull(e, nullptr, 10);
     // pack all tables into one device allocation (16-byte aligned pieces)
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };

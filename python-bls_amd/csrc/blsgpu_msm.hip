@@ -392,6 +392,53 @@ __global__ void __launch_bounds__(64) k_msm_pip_horner(VmTables T, const uint32_
     if (out_inf && lane == 0) out_inf[blockIdx.x] = (nz == 0) ? 1 : 0;
 }
 
+// The same Horner for a BATCH of G2 sums (the threshold combine of BASELINE config 4): BLSVM_HMSM2_NP sums per team in
+// lock step (vmgen/msm_programs.build_horner) -- a G2 doubling is 10-12 lane operations, so one sum per team leaves
+// five lanes in six idle.  winsums: groups x nwin projective points; out: groups x 192 bytes.
+__global__ void __launch_bounds__(64) k_msm_horner_np(VmTables T, const uint32_t* __restrict__ winsums, uint32_t nwin, uint32_t cbits,
+                                                      uint32_t groups, uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf) {
+    constexpr uint32_t DEG = 2, PJ_DW = 36 * DEG, PT_DW = 24 * DEG, NP = BLSVM_HMSM2_NP;
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t first = blockIdx.x * NP;
+    const uint32_t cnt = min(NP, groups - first);
+    team_init_consts(T, team, lane);
+    wave_fence();
+    auto load = [&](uint32_t slot0, uint32_t w) {            // point w of every sum of the team (infinity past the end)
+        for (uint32_t d = lane; d < NP * PJ_DW; d += 64) {
+            const uint32_t p = d / PJ_DW, o = d % PJ_DW;
+            team[slot0 * 12 + d] = (p < cnt) ? winsums[((size_t)(first + p) * nwin + w) * PJ_DW + o] : inf_dword<DEG>(team, o);
+        }
+        wave_fence();
+    };
+    load(BLSVM_HMSM2_R, nwin - 1u);
+    for (int w = (int)nwin - 2; w >= 0; w--) {
+        for (uint32_t s = 0; s < cbits; s++) run_rounds<true>(T, T.segflat + BLSVM_SEGF_G2H_DBL_OFF, BLSVM_SEGF_G2H_DBL_LEN, 0, lane);
+        wave_fence();
+        load(BLSVM_HMSM2_S, (uint32_t)w);
+        run_rounds<true>(T, T.segflat + BLSVM_SEGF_G2H_ACC_OFF, BLSVM_SEGF_G2H_ACC_LEN, 0, lane);
+    }
+    run_rounds(T, T.segflat + BLSVM_SEGF_G2H_AFFINE_OFF, BLSVM_SEGF_G2H_AFFINE_LEN, 0, lane);
+    if (lane < NP * 2u * DEG) {
+        uint32_t X[12];
+        lds_load12(X, (BLSVM_HMSM2_OUT + lane) * 3);
+        bls::fq_canon(X);
+        lds_store12(X, (BLSVM_HMSM2_OUT + lane) * 3);
+    }
+    wave_fence();
+    for (uint32_t p = 0; p < cnt; p++) {
+        uint32_t any = 0;
+        for (uint32_t d = lane; d < PT_DW; d += 64) {
+            const uint32_t e = d / 12, w = d % 12;
+            const uint32_t v = team[(BLSVM_HMSM2_OUT + p * 2 * DEG + e) * 12 + (11 - w)];
+            any |= v;
+            out[(size_t)(first + p) * PT_DW + d] = bswap32(v);
+        }
+        const uint64_t nz = __ballot(any != 0);
+        if (out_inf && lane == 0) out_inf[first + p] = (nz == 0) ? 1 : 0;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Bucket method with ONE (group, chunk, window) PER LANE (blsgpu_reg.hip): the lanes of a
 // wavefront are the 64 windows of the same chunk of points, so they read the same point

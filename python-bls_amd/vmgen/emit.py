@@ -177,6 +177,7 @@ DIRECT_SEGS = ["mul_0_1", "from_mont_1_0", "to_mont_0_1", "copy_1_0", "line_dbl"
                "h1_a", "h1w_a", "h1_b", "h1_c", "d1_a", "d1_c", "d2_a", "d2_b", "d2_c"]
 POW_SEG = re.compile(r"^(h1_(sqr|mul)[23]|d1_(sqr|mul)|d2[pq]_(sqr|mul))$")
 MSM_NP = {1: 6, 2: 2}                                         # points per team in the MSM kernels
+HORNER_NP = {2: 5}                                            # sums per team in the batch Horner (k_msm_horner_np)
 H1_NE, H2_NM = 12, 5                                          # encodings / messages per team (hash to G2)
 D1_NE, D2_NE = 32, 16                                         # points per team (decompression)
 
@@ -193,6 +194,11 @@ def build_tables(verbose=False):
         msegs, lay = MP.build(deg, NP, verbose=verbose)
         msm[deg] = (msegs, lay)
         segs.update(msegs)
+    hmsm = {}
+    for deg, NP in HORNER_NP.items():
+        hsegs, hlay = MP.build_horner(deg, NP, verbose=verbose)
+        hmsm[deg] = (hsegs, hlay)
+        segs.update(hsegs)
     h1segs, h1lay, h1script = HP.build_h1(H1_NE, verbose=verbose)
     h1wsegs, _, h1wscript = HP.build_h1(H1_NE, verbose=verbose, wide=True)
     segs["h1w_a"] = h1wsegs["h1w_a"]
@@ -213,7 +219,7 @@ def build_tables(verbose=False):
     return dict(segs=segs, mscript=mscript, fscript=fscript, mpsegs=mpsegs, mpscript=mpscript, mplay=mplay, msm=msm,
                 h1=(h1segs, h1lay, h1script), h1w=(h1segs, h1lay, h1wscript), h2=(h2segs, h2lay, h2script),
                 d1=(d1segs, d1lay, d1script), d2=(d2segs, d2lay, d2script), order=order,
-                slow=(slowsegs, slowscript), mp2=(mp2segs, mp2script, mp2lay),
+                slow=(slowsegs, slowscript), mp2=(mp2segs, mp2script, mp2lay), hmsm=hmsm,
                 seg_rounds=seg_rounds, data=data)
 
 
@@ -228,7 +234,7 @@ def generate(path=None, verbose=False):
     # (the kernel's fallback for special pairs runs the single-pair program in the same scratchpad)
     mp_team_slots = max(team_slots, P.mp_team_slots(mpsegs))
     for deg, (msegs, lay) in msm.items():
-        team_slots = max(team_slots, lay.TEMP0 + max(s.ntemp for s in msegs.values()))
+        team_slots = max(team_slots, lay.TEMP0 + max(s.ntemp for n, s in msegs.items()))
     consts = P.const_table()
     mflat = [r for n in mscript for r in seg_rounds[n]]
     fflat = [r for n in fscript for r in seg_rounds[n]]
@@ -293,8 +299,12 @@ def generate(path=None, verbose=False):
     for deg, (msegs, lay) in msm.items():
         for nm in ("NP", "IN", "R", "A", "S", "PR0", "PR1", "OUT"):
             w("#define BLSVM_MSM%d_%s %d\n" % (deg, nm, getattr(lay, nm)))
+    for deg, (hsegs, hlay) in tb["hmsm"].items():
+        for nm in ("NP", "R", "S", "OUT"):
+            w("#define BLSVM_HMSM%d_%s %d\n" % (deg, nm, getattr(hlay, nm)))
+        w("#define BLSVM_HMSM%d_SLOTS %d\n" % (deg, hlay.TEMP0 + max(s.ntemp for s in hsegs.values())))
     direct = []
-    for n in DIRECT_SEGS + sorted(n for n in segs if n.startswith("g1_") or n.startswith("g2_")):
+    for n in DIRECT_SEGS + sorted(n for n in segs if n.startswith(("g1_", "g2_", "g1h_", "g2h_"))):
         w("#define BLSVM_SEGF_%s_OFF %d\n#define BLSVM_SEGF_%s_LEN %d\n" % (n.upper(), len(direct), n.upper(), len(seg_rounds[n])))
         direct += seg_rounds[n]
     flat("BLSVM_SEG_FLAT", direct)

@@ -192,3 +192,56 @@ def build(deg, NP, cfg=None, verbose=False):
     for b in builders:
         segs[b.name] = schedule(b, temp_base=lay.TEMP0, verbose=verbose)
     return segs, lay
+
+
+class HornerLayout:
+    """Slot map of a Horner team (k_msm_horner_np): NP running sums R_p, NP addends S_p, NP affine outputs."""
+
+    def __init__(self, deg, NP):
+        self.deg, self.NP = deg, NP
+        o = NCONST
+        self.R = o; o += NP * 3 * deg
+        self.S = o; o += NP * 3 * deg
+        self.OUT = o; o += NP * 2 * deg
+        self.TEMP0 = o
+
+    def pt(self, base, p=0):
+        return base + p * 3 * self.deg
+
+
+def build_horner(deg, NP, cfg=None, verbose=False):
+    """The window Horner of a BATCH of sums (k_msm_pip_horner does one sum per team and leaves most lanes idle: a
+    doubling is a handful of products): NP sums per team in lock step.
+      <tag>_dbl:    R_p <- 2 R_p
+      <tag>_acc:    R_p <- R_p + S_p
+      <tag>_affine: OUT_p <- canonical affine of R_p (Z = 0 gives (0, 0))"""
+    cfg = cfg or tw.Cfg(mat2=False)
+    F = FA(deg, cfg)
+    lay = HornerLayout(deg, NP)
+    c = deg
+    tag = "g%dh" % deg
+    builders = []
+    b = Builder(tag + "_dbl")
+    zero = b.inp(C_ZERO)
+    for p in range(NP):
+        _out_pt(b, lay, pdbl(F, _in_pt(b, lay, lay.R, p)), lay.R, p, zero)
+    builders.append(b)
+    b = Builder(tag + "_acc")
+    zero = b.inp(C_ZERO)
+    for p in range(NP):
+        _out_pt(b, lay, padd(F, _in_pt(b, lay, lay.R, p), _in_pt(b, lay, lay.S, p)), lay.R, p, zero)
+    builders.append(b)
+    b = Builder(tag + "_affine")
+    raw1, zero = b.inp(C_RAW1), b.inp(C_ZERO)
+    for p in range(NP):
+        X, Y, Z = _in_pt(b, lay, lay.R, p)
+        zi = (Z[0].inv(),) if deg == 1 else tw.f2_inv(cfg, Z)
+        for k, v in enumerate((F.mul(X, zi), F.mul(Y, zi))):
+            for i in range(c):
+                e = v[i].mat() * raw1
+                b.out(e if not e.is_zero() else zero, lay.OUT + (p * 2 + k) * c + i)
+    builders.append(b)
+    segs = {}
+    for b in builders:
+        segs[b.name] = schedule(b, temp_base=lay.TEMP0, verbose=verbose)
+    return segs, lay

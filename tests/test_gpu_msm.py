@@ -258,6 +258,35 @@ def test_lane_bucket_method_degenerate(lane_engine, engine, golden):
 
 
 @pytest.fixture(scope="module")
+def horner_engine():
+    """Batches of G2 sums through the bucket kernels with the window Horner of SEVERAL sums per team (k_msm_horner_np,
+    what a batch of >= 1024 sums selects) from 1 sum on."""
+    return _engine_with(("BLSGPU_PIP_GROUP_THRESHOLD", "BLSGPU_HORNER_NP_THRESHOLD"))
+
+
+@pytest.mark.parametrize("k,groups", [(3, 2), (5, 4), (7, 5), (4, 6), (3, 11), (67, 7)])
+def test_batch_horner_vs_oracle(horner_engine, oracle, seeded_pairs, k, groups):
+    """ragged team counts (5 sums per team), a sum that is the point at infinity, zero and extreme scalars"""
+    _, g2 = seeded_pairs
+    rnd = random.Random(k * 17 + groups)
+    n = k * groups
+    pts = bytearray((g2 * 2)[192 * 4:192 * (4 + n)])
+    sc = [rnd.choice([rnd.randrange(N), rnd.randrange(1 << 40), 0, N - 1, 1]) for _ in range(n)]
+    if groups >= 4:                                             # sum number 2: P, -P and zeros -> infinity
+        P = bytes(pts[192 * 2 * k:192 * 2 * k + 192])
+        negP = P[:96] + b"".join(((Q - int.from_bytes(P[96 + 48 * j:144 + 48 * j], "big")) % Q).to_bytes(48, "big") for j in range(2))
+        pts[192 * (2 * k + 1):192 * (2 * k + 2)] = negP
+        for i in range(k):
+            sc[2 * k + i] = 9 if i < 2 else 0
+    out, inf = horner_engine.g2_msm(bytes(pts), sc, k, groups)
+    for g in range(groups):
+        want, _ = oracle.g2_msm(bytes(pts[192 * k * g:192 * k * (g + 1)]), sc[k * g:k * (g + 1)], k)
+        assert out[192 * g:192 * (g + 1)] == want and inf[g] == (want == bytes(192)), g
+    if groups >= 4:
+        assert inf[2]
+
+
+@pytest.fixture(scope="module")
 def sorted_engine():
     """An engine whose single G1 sums with scalars use the sorted buckets (k_srt_*) from 1 point on."""
     return _engine_with(("BLSGPU_MSM_SORT_THRESHOLD",))
