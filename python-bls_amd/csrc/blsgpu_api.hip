@@ -233,7 +233,6 @@ constexpr int MSM_WAVES = 4;
 // result when the digits are too unevenly spread for equal list pieces to pay (a run of very many pieces is
 // finished by ONE wavefront of k_srt_fix_long); the caller then takes the fixed-window path.
 static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* d_out_inf, hipStream_t st) {
-    using C = blsgpu::MsmCfg<1>;
     // Window bits: with 131 072 equal pieces a run covers 131072 / (2^cb windows) pieces whatever n is -- 0.8 for
     // 13 bits, 1.5 for 12, 5 for 10 -- and a run of more than three pieces costs a whole wavefront in
     // k_srt_fix_long, so only 12 and 13 bits (or very few keys: <= 7 bits) are cheap.  Measured (tools/c5_probe.py,
@@ -258,9 +257,7 @@ static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars
     const uint32_t* sc = (const uint32_t*)d_scalars;
     HIP_TRY(hipMemsetAsync(W + o_cnt, 0, nkeys * 4, st));
     HIP_TRY(hipMemsetAsync(W + o_long, 0, 16, st));          // counter of the long runs (the key list follows it)
-    size_t pblocks = (n + (size_t)MSM_WAVES * C::NP - 1) / ((size_t)MSM_WAVES * C::NP);
-    hipLaunchKernelGGL(blsgpu::k_msm_prep<1>, dim3((unsigned)pblocks), dim3(MSM_WAVES * 64), (size_t)MSM_WAVES * blsgpu::TEAM_BYTES, st,
-                       c->tabs, (const uint32_t*)d_pts, (uint32_t)n, W + o_prep);
+    hipLaunchKernelGGL(blsgpu::k_srt_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (uint32_t)n, W + o_prep);
     HIP_TRY(hipGetLastError());
     uint8_t* live = (uint8_t*)(W + o_live);
     const dim3 sgrid((unsigned)((n + blsgpu::SRT_SLICE - 1) / blsgpu::SRT_SLICE), nwin);

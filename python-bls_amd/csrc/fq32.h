@@ -234,6 +234,8 @@ BLS_HD void fat_reduce(uint32_t* __restrict__ out, const uint64_t* __restrict__ 
 // ---- sign of a field element (the VM's SGN rounds) ----------------------------
 #define BLS_HALF_LIMBS /* (q - 1) / 2 */ \
     {0xffffd555u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u, 0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u}
+#define BLS_R2_LIMBS /* R^2 mod q: x * R2 (Montgomery product) = x R */ \
+    {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu, 0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u}
 #define BLS_ONE_MONT_LIMBS /* R mod q */ \
     {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u, 0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u}
 // out = Montgomery 1 if the canonical value of a (Montgomery, relaxed) exceeds (q-1)/2, else 0:
