@@ -103,6 +103,28 @@ def test_one_message_per_lane_clearing(golden):
         assert got[:192] == H.g2_affine_bytes(H.hash_to_g2_prehashed(msgs[:32], hash512))
 
 
+def test_default_selection_at_65536_messages(engine):
+    """from 65 536 messages on the default engine clears cofactors one message per lane: same bytes as the VM form
+    (an engine with the threshold out of reach), a strided sample against the host"""
+    import os
+    from bls_py import _native
+    n = 65536 + 7
+    msgs = b"".join(hashlib.sha256(b"h2c-65k-%d" % i).digest() for i in range(n))
+    got = engine.hash_to_g2(msgs)
+    old = os.environ.get("BLSGPU_H2C_REG_THRESHOLD")
+    os.environ["BLSGPU_H2C_REG_THRESHOLD"] = str(1 << 40)
+    try:
+        vm = _native.Engine(0)
+    finally:
+        if old is None:
+            del os.environ["BLSGPU_H2C_REG_THRESHOLD"]
+        else:
+            os.environ["BLSGPU_H2C_REG_THRESHOLD"] = old
+    assert got == vm.hash_to_g2(msgs)
+    for i in range(0, n, 8191):
+        assert got[192 * i:192 * (i + 1)] == H.g2_affine_bytes(H.hash_to_g2_prehashed(msgs[32 * i:32 * (i + 1)], hash512))
+
+
 def test_candidate_with_real_u_is_skipped(engine, golden):
     """tests/golden/g2_real_u.json (reference-generated): t whose first Shallue-van de Woestijne candidate has
     a u with zero imaginary part -- the reference skips it; blsgpu_map_to_g2 must return the reference's point."""
