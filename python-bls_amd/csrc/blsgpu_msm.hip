@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(64) k_msm_lane_fold(const uint32_t* __restrict
     const uint32_t w = L / nfold, f = L % nfold;
     const uint32_t lo = f * per, hi = min(chunks, lo + per);
     reg::ptT<E> acc = lane_inf<E>();
-    for (uint32_t i = lo; i < hi; i++) acc = reg::padd(acc, lane_ld_pt<E>(partials + ((size_t)w * chunks + i) * PJ_DW, false));
+    for (uint32_t i = lo; i < hi; i++) acc = reg::padd<E, DEG == 1>(acc, lane_ld_pt<E>(partials + ((size_t)w * chunks + i) * PJ_DW, false));
     lane_st_pt(acc, out + ((size_t)w * nfold + f) * PJ_DW);
 }
 
@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(64, BLSGPU_SRT_WAVES) k_srt_accum(const uint32
             reg::fe x2, y2;
             lane_ld(x2, pt, true);
             lane_ld(y2, pt + 12, true);
-            reg::pmadd(acc, x2, y2);
+            reg::pmadd<reg::fe, true>(acc, x2, y2);
         }
         if (head) { lane_st_pt(acc, headpart + (size_t)L * 36); hk = key; }
         else lane_st_pt(acc, bsum + (size_t)key * 36);
@@ -765,7 +765,7 @@ __global__ void __launch_bounds__(64) k_srt_fix(const uint32_t* __restrict__ sta
     reg::ptT<reg::fe> acc = lane_ld_pt<reg::fe>(bsum + (size_t)key * 36, false);
 #pragma unroll 1
     for (uint32_t l = l0 + 1; l <= l1; l++)
-        if (headkey[l] == key) acc = reg::padd(acc, lane_ld_pt<reg::fe>(headpart + (size_t)l * 36, false));
+        if (headkey[l] == key) acc = reg::padd<reg::fe, true>(acc, lane_ld_pt<reg::fe>(headpart + (size_t)l * 36, false));
     lane_st_pt(acc, bsum + (size_t)key * 36);
 }
 
@@ -780,7 +780,7 @@ __global__ void __launch_bounds__(64) k_srt_fix_long(const uint32_t* __restrict_
         const uint32_t l0 = start[key] / per, l1 = (start[key + 1] - 1u) / per;
         reg::ptT<reg::fe> acc = lane_inf<reg::fe>();
 #pragma unroll 1
-        for (uint32_t l = l0 + 1u + lane; l <= l1; l += 64u) acc = reg::padd(acc, lane_ld_pt<reg::fe>(headpart + (size_t)l * 36, false));
+        for (uint32_t l = l0 + 1u + lane; l <= l1; l += 64u) acc = reg::padd<reg::fe, true>(acc, lane_ld_pt<reg::fe>(headpart + (size_t)l * 36, false));
 #pragma unroll 1
         for (int off = 32; off > 0; off >>= 1) {
             reg::ptT<reg::fe> o;
@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(64) k_srt_bits(const uint32_t* __restrict__ bs
 #pragma unroll 1
     for (uint32_t m = j * SRT_BITADDS; m < (j + 1u) * SRT_BITADDS; m++) {
         const uint32_t d = ((m >> b) << (b + 1u)) | (1u << b) | (m & ((1u << b) - 1u));
-        acc = reg::padd(acc, lane_ld_pt<reg::fe>(bsum + ((size_t)(w << cb) + d) * 36, false));
+        acc = reg::padd<reg::fe, true>(acc, lane_ld_pt<reg::fe>(bsum + ((size_t)(w << cb) + d) * 36, false));
     }
     lane_st_pt(acc, out + (size_t)L * 36);
 }

@@ -21,6 +21,13 @@ __device__ __attribute__((noinline)) fe fe_mul(fe x, fe y) {
     bls::fq_mul(r.v, x.v, y.v);
     return r;
 }
+// the same product expanded in place: for a loop whose body is ONE G1 addition (11 products = 64 KB of code, still
+// cached) the call's operand moves are worth 11 % (k_srt_accum); G2 additions (36 products) are faster with the call
+__device__ __forceinline__ fe fe_mul_inl(const fe& x, const fe& y) {
+    fe r;
+    bls::fq_mul(r.v, x.v, y.v);
+    return r;
+}
 // modular addition / subtraction of canonical values as three carry chains of 12 (sum, trial subtraction, select)
 __device__ __forceinline__ fe fe_add(const fe& x, const fe& y) {
     const uint32_t q[12] = BLS_Q_LIMBS;
@@ -82,9 +89,15 @@ template <class E> __device__ __forceinline__ E eb3(const E& x) {               
     return eadd(edbl(t), t);
 }
 template <class E> struct ptT { E X, Y, Z; };
-// complete addition, RCB algorithm 7 (a = 0) -- msm_programs.padd
-template <class E>
+template <bool INL> __device__ __forceinline__ fe emul_sel(const fe& x, const fe& y) {
+    if constexpr (INL) return fe_mul_inl(x, y);
+    else return fe_mul(x, y);
+}
+template <bool INL> __device__ __forceinline__ fe2 emul_sel(const fe2& x, const fe2& y) { return f2_mul(x, y); }
+// complete addition, RCB algorithm 7 (a = 0) -- msm_programs.padd.  INL: G1 products expanded in place (fe_mul_inl)
+template <class E, bool INL = false>
 __device__ ptT<E> padd(const ptT<E>& P, const ptT<E>& Q) {
+    auto emul = [](const E& a, const E& b) { return emul_sel<INL>(a, b); };
     E t0 = emul(P.X, Q.X), t1 = emul(P.Y, Q.Y), t2 = emul(P.Z, Q.Z);
     E t3 = esub(esub(emul(eadd(P.X, P.Y), eadd(Q.X, Q.Y)), t0), t1);
     E t4 = esub(esub(emul(eadd(P.Y, P.Z), eadd(Q.Y, Q.Z)), t1), t2);
@@ -110,8 +123,9 @@ __device__ ptT<E> pdbl(const ptT<E>& P) {
 }
 // complete mixed addition, RCB algorithm 8 (a = 0): P += (x2 : y2 : 1); (x2, y2) is an affine point, P any
 // point including (0 : 1 : 0).  11 products; the operands die early, so a G1 addition fits 256 registers.
-template <class E>
+template <class E, bool INL = false>
 __device__ __forceinline__ void pmadd(ptT<E>& P, const E& x2, const E& y2) {
+    auto emul = [](const E& a, const E& b) { return emul_sel<INL>(a, b); };
     E t0 = emul(P.X, x2), t1 = emul(P.Y, y2);
     E t3 = esub(esub(emul(eadd(x2, y2), eadd(P.X, P.Y)), t0), t1);
     E t4 = eadd(emul(y2, P.Z), P.Y);
