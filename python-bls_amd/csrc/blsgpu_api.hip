@@ -13,7 +13,7 @@
 
 #include "../../include/blsgpu.h"
 #include "blsgpu_kernels.hip"
-#include "blsgpu_reg.hip"
+#include "fp28.h"
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
 
@@ -248,20 +248,20 @@ static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars
     // workspace: prep | cnt | start (+1) | cursor | maxcnt, total | idx | bsum | headpart | headkey | bit sums (two buffers) | winsums
     size_t off = 0;
     auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
-    const size_t o_prep = take(n * 36), o_cnt = take(nkeys), o_start = take(nkeys + 1), o_cur = take(nkeys), o_max = take(2),
-                 o_idx = take((size_t)nwin * n), o_bsum = take(nkeys * 36), o_hp = take(lanes * 36), o_hk = take(lanes),
-                 o_b0 = take(nsum * nch * 36), o_b1 = take(nsum * ((nch + 7) / 8) * 36), o_win = take((size_t)nwin * 36), o_live = take((n + 3) / 4),
+    const size_t PJ = blsgpu::SRT_PJ;
+    const size_t o_prep = take(n * blsgpu::L28_AFF), o_cnt = take(nkeys), o_start = take(nkeys + 1), o_cur = take(nkeys), o_max = take(2),
+                 o_idx = take((size_t)nwin * n), o_bsum = take(nkeys * PJ), o_hp = take(lanes * PJ), o_hk = take(lanes),
+                 o_b0 = take(nsum * nch * PJ), o_b1 = take(nsum * ((nch + 7) / 8) * PJ), o_win = take((size_t)nwin * 36), o_live = take((n + 3) / 4),
                  o_wtot = take(2 * (size_t)nwin), o_long = take(nkeys + 4);
     if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, off)) return rc_;
     uint32_t* W = c->d_buckets;
     const uint32_t* sc = (const uint32_t*)d_scalars;
     HIP_TRY(hipMemsetAsync(W + o_cnt, 0, nkeys * 4, st));
     HIP_TRY(hipMemsetAsync(W + o_long, 0, 16, st));          // counter of the long runs (the key list follows it)
-    hipLaunchKernelGGL(blsgpu::k_srt_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (uint32_t)n, W + o_prep);
-    HIP_TRY(hipGetLastError());
     uint8_t* live = (uint8_t*)(W + o_live);
+    hipLaunchKernelGGL(blsgpu::k_lane_prep<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (uint32_t)n, W + o_prep, live);
+    HIP_TRY(hipGetLastError());
     const dim3 sgrid((unsigned)((n + blsgpu::SRT_SLICE - 1) / blsgpu::SRT_SLICE), nwin);
-    hipLaunchKernelGGL(blsgpu::k_srt_live, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W + o_prep, (uint32_t)n, live);
     hipLaunchKernelGGL(blsgpu::k_srt_count, sgrid, dim3(1024), 0, st, sc, live, (uint32_t)n, cb, W + o_cnt);
     hipLaunchKernelGGL(blsgpu::k_srt_scan_window, dim3(nwin), dim3(1024), 0, st, W + o_cnt, cb, W + o_start, W + o_wtot, W + o_wtot + nwin);
     hipLaunchKernelGGL(blsgpu::k_srt_scan_add, dim3(nwin), dim3(1024), 0, st, nwin, cb, W + o_wtot, W + o_wtot + nwin, W + o_start, W + o_cur,
@@ -287,7 +287,7 @@ static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars
     for (size_t cur = nch; cur > 1;) {                        // runs of 8 partial sums per lane until one is left per (window, bit)
         const size_t nfold = (cur + 7) / 8, ftotal = nsum * nfold;
         hipLaunchKernelGGL(blsgpu::k_msm_lane_fold<1>, dim3((unsigned)((ftotal + 63) / 64)), dim3(64), 0, st, src, (uint32_t)cur, 8u,
-                           (uint32_t)nfold, (uint32_t)ftotal, dst);
+                           (uint32_t)nfold, (uint32_t)ftotal, dst, nfold == 1 ? 1u : 0u);   // the last fold: the VM's form
         HIP_TRY(hipGetLastError());
         uint32_t* t = src; src = dst; dst = t;
         cur = nfold;
@@ -329,30 +329,33 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
         if (chunk == 0) chunk = 1;
         size_t chunks = (k + chunk - 1) / chunk;
         const size_t fold_n = (lane_path && chunks > 96) ? (chunks + 63) / 64 : 0;
-        size_t need = (chunks + 1) * groups * blsgpu::PIP_W * 36 * DEG + n * 36 * DEG;
+        // partials: the VM's form (36 DEG dwords) except between the lane kernel and its fold (L28: 42 DEG); prep: the VM's
+        // projective triples (36 DEG) or the lane path's affine L28 points (28 DEG) + live flags
+        constexpr size_t PJ28 = blsgpu::L28_PJ * DEG;
+        size_t need = (chunks + 1) * groups * blsgpu::PIP_W * PJ28 + n * 36 * DEG + (n + 3) / 4 + 4;
         if (int rc_ = grow_elems(c, &c->d_msm_part, &c->msm_part_cap, need)) return rc_;
-        uint32_t* d_win = c->d_msm_part + chunks * groups * blsgpu::PIP_W * 36 * DEG;
-        uint32_t* d_prep = d_win + groups * blsgpu::PIP_W * 36 * DEG;
-        size_t pblocks = (n + (size_t)MSM_WAVES * C::NP - 1) / ((size_t)MSM_WAVES * C::NP);
-        hipLaunchKernelGGL(blsgpu::k_msm_prep<DEG>, dim3((unsigned)pblocks), dim3(MSM_WAVES * 64), (size_t)MSM_WAVES * blsgpu::TEAM_BYTES,
-                           st, c->tabs, (const uint32_t*)d_pts, (uint32_t)n, d_prep);
-        HIP_TRY(hipGetLastError());
+        uint32_t* d_win = c->d_msm_part + chunks * groups * blsgpu::PIP_W * PJ28;
+        uint32_t* d_prep = d_win + groups * blsgpu::PIP_W * PJ28;
         if (lane_path) {
             // one (group, chunk, window) per lane, buckets in HBM
+            uint8_t* d_live = (uint8_t*)(d_prep + n * blsgpu::L28_AFF * DEG);
+            hipLaunchKernelGGL(blsgpu::k_lane_prep<DEG>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (uint32_t)n,
+                               d_prep, d_live);
+            HIP_TRY(hipGetLastError());
             const size_t lanes = groups * chunks * blsgpu::PIP_W;
-            const size_t bneed = lanes * (blsgpu::PIP_NB - 1) * 36 * DEG + fold_n * groups * blsgpu::PIP_W * 36 * DEG;
+            const size_t bneed = lanes * (blsgpu::PIP_NB - 1) * PJ28 + fold_n * groups * blsgpu::PIP_W * 36 * DEG;
             if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, bneed)) return rc_;
-            hipLaunchKernelGGL(blsgpu::k_msm_lane<DEG>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, d_prep,
+            hipLaunchKernelGGL(blsgpu::k_msm_lane<DEG>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, d_prep, d_live,
                                (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, (uint32_t)chunks, (uint32_t)lanes, c->d_buckets,
-                               c->d_msm_part);
+                               c->d_msm_part, fold_n ? 0u : 1u);
             HIP_TRY(hipGetLastError());
             const uint32_t* winsrc = c->d_msm_part;
             size_t wchunks = chunks;
             if (fold_n) {                                    // many chunks: fold runs of 64 partials per lane first
-                uint32_t* d_fold = c->d_buckets + lanes * (blsgpu::PIP_NB - 1) * 36 * DEG;
+                uint32_t* d_fold = c->d_buckets + lanes * (blsgpu::PIP_NB - 1) * PJ28;
                 const size_t ftotal = groups * blsgpu::PIP_W * fold_n;
                 hipLaunchKernelGGL(blsgpu::k_msm_lane_fold<DEG>, dim3((unsigned)((ftotal + 63) / 64)), dim3(64), 0, st, c->d_msm_part,
-                                   (uint32_t)chunks, 64u, (uint32_t)fold_n, (uint32_t)ftotal, d_fold);
+                                   (uint32_t)chunks, 64u, (uint32_t)fold_n, (uint32_t)ftotal, d_fold, 1u);
                 HIP_TRY(hipGetLastError());
                 winsrc = d_fold;
                 wchunks = fold_n;
@@ -361,6 +364,10 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
                                c->tabs, winsrc, (uint32_t)wchunks, d_win);
             HIP_TRY(hipGetLastError());
         } else {
+            size_t pblocks = (n + (size_t)MSM_WAVES * C::NP - 1) / ((size_t)MSM_WAVES * C::NP);
+            hipLaunchKernelGGL(blsgpu::k_msm_prep<DEG>, dim3((unsigned)pblocks), dim3(MSM_WAVES * 64), (size_t)MSM_WAVES * blsgpu::TEAM_BYTES,
+                               st, c->tabs, (const uint32_t*)d_pts, (uint32_t)n, d_prep);
+            HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(blsgpu::k_msm_pip<DEG>, dim3((unsigned)chunks, blsgpu::PIP_W, (unsigned)groups), dim3(64), (size_t)P::SLOTS * 48,
                                st, c->tabs, d_prep, (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, c->d_msm_part);
             HIP_TRY(hipGetLastError());

@@ -94,42 +94,43 @@ __global__ void __launch_bounds__(256) k_pow(uint32_t* __restrict__ img, uint32_
     const uint32_t team = v / cnt, k = v % cnt;
     const uint32_t* src = img + ((size_t)team * img_slots + base_off + k) * 12;
     uint32_t* dst = img + ((size_t)team * img_slots + acc_off + k) * 12;
-    // sliding window over the fixed exponent (vmgen/emit.pow_windows): odd powers b, b^3, ... in registers
+    // sliding window over the fixed exponent (vmgen/emit.pow_windows): odd powers b, b^3, ... in registers, on the
+    // carry-free 28-bit limbs of fp28.h (a squaring: 105 + 196 multiply-accumulates, nothing else)
     constexpr int NT = 1 << (BLSVM_POW_WINDOW - 1);
-    uint32_t tbl[NT][12], a[12], t[12];
+    r28::fe tbl[NT], a;
+    {
+        uint32_t x[12];
 #pragma unroll
-    for (int j = 0; j < 12; j++) tbl[0][j] = src[j];
-    bls::fq_sqr_relaxed(t, tbl[0]);
+        for (int j = 0; j < 12; j++) x[j] = src[j];
+        tbl[0] = r28::from_vm(x);
+    }
+    const r28::fe t = r28::sqr(tbl[0]);
 #pragma unroll
-    for (int i = 1; i < NT; i++) bls::fq_mul_relaxed(tbl[i], tbl[i - 1], t);
-    auto pick = [&](uint32_t* m, uint32_t k) {
+    for (int i = 1; i < NT; i++) tbl[i] = r28::mul(tbl[i - 1], t);
+    auto pick = [&](uint32_t k) {
+        r28::fe m;
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
-            m[j] = tbl[0][j];
+        for (int j = 0; j < r28::NL; j++) {
+            m.v[j] = tbl[0].v[j];
 #pragma unroll
-            for (int i = 1; i < NT; i++) m[j] = (k == (uint32_t)i) ? tbl[i][j] : m[j];
+            for (int i = 1; i < NT; i++) m.v[j] = (k == (uint32_t)i) ? tbl[i].v[j] : m.v[j];
         }
+        return m;
     };
-    pick(a, BLSVM_POW_WIN[0][1]);
+    a = pick(BLSVM_POW_WIN[0][1]);
 #pragma unroll 1
     for (int s = 1; s < BLSVM_POW_STEPS; s++) {
         const uint32_t nsq = BLSVM_POW_WIN[s][0], k = BLSVM_POW_WIN[s][1];
 #pragma unroll 1
-        for (uint32_t i = 0; i < nsq; i++) {
-            bls::fq_sqr_relaxed(t, a);
-#pragma unroll
-            for (int j = 0; j < 12; j++) a[j] = t[j];
-        }
-        if (k != 255u) {
-            uint32_t m[12];
-            pick(m, k);
-            bls::fq_mul_relaxed(t, a, m);
-#pragma unroll
-            for (int j = 0; j < 12; j++) a[j] = t[j];
-        }
+        for (uint32_t i = 0; i < nsq; i++) a = r28::sqr(a);
+        if (k != 255u) a = r28::mul(a, pick(k));
     }
+    {
+        uint32_t y[12];
+        r28::to_vm(y, a);
 #pragma unroll
-    for (int j = 0; j < 12; j++) dst[j] = a[j];
+        for (int j = 0; j < 12; j++) dst[j] = y[j];
+    }
 }
 
 __device__ __forceinline__ void img_load(uint32_t* team, const uint32_t* __restrict__ img, uint32_t state0, uint32_t nslots, uint32_t lane) {
@@ -250,41 +251,51 @@ __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t*
 // out: n_msg x 192 bytes canonical affine (x.c0 || x.c1 || y.c0 || y.c1), (0,0) for infinity.
 __global__ void __launch_bounds__(64) k_h2c_clear_reg(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg,
                                                       uint32_t* __restrict__ out) {
-    using namespace reg;
+    using namespace r28;
+    typedef ptT<fe2> pt;
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_msg) return;
-    auto cfe = [&](uint32_t slot) { fe r; for (int j = 0; j < 12; j++) r.v[j] = T.consts[slot * 12 + j]; return r; };
+    auto vm = [&](const uint32_t* p) { uint32_t x[12]; for (int j = 0; j < 12; j++) x[j] = p[j]; return from_vm(x); };   // the VM leaves values < 2q
     pt S[2];
     for (int s = 0; s < 2; s++) {
         const uint32_t e = 2 * m + s;
         const uint32_t* src = enc + ((size_t)(e / BLSVM_H1_NE) * H1_IMG + (BLSVM_H1_S - BLSVM_H1_STATE0) + 5 * (e % BLSVM_H1_NE)) * 12;
-        fe c[5];
-        for (int k = 0; k < 5; k++) {
-            for (int j = 0; j < 12; j++) c[k].v[j] = src[k * 12 + j];
-            bls::fq_canon(c[k].v);                               // the VM leaves values < 2q
-        }
-        S[s] = {{c[0], c[1]}, {c[2], c[3]}, {c[4], fe_zero()}};
+        S[s] = {{vm(src), vm(src + 12)}, {vm(src + 24), vm(src + 36)}, {vm(src + 48), fe_zero()}};
     }
     constexpr uint32_t PSIX = BLSVM_HC_PSIX - BLSVM_HC_SLOT0 + BLSVM_HC_TBL0, PSIY = BLSVM_HC_PSIY - BLSVM_HC_SLOT0 + BLSVM_HC_TBL0;
-    const fe2 psix = {cfe(PSIX), cfe(PSIX + 1)}, psiy = {cfe(PSIY), cfe(PSIY + 1)};
-    auto psi = [&](const pt& P) { return pt{f2_mul(f2_conj(P.X), psix), f2_mul(f2_conj(P.Y), psiy), f2_conj(P.Z)}; };
-    const pt P = padd(S[0], S[1]);
+    const fe2 psix = {vm(T.consts + PSIX * 12), vm(T.consts + (PSIX + 1) * 12)}, psiy = {vm(T.consts + PSIY * 12), vm(T.consts + (PSIY + 1) * 12)};
+    auto psi = [&](const pt& P) { return pt{mul(conj(P.X), psix), mul(conj(P.Y), psiy), norm(conj(P.Z))}; };
+    auto mul_x = [&](const pt& P) {                              // [|x|] P, |x| = 0xd201000000010000
+        pt A = P;
+#pragma unroll 1
+        for (int bit = 62; bit >= 0; bit--) {
+            A = pdbl_fn(A);
+            if ((0xd201000000010000ull >> bit) & 1ull) A = padd_fn(A, P);
+        }
+        return A;
+    };
+    const pt P = padd_fn(S[0], S[1]);
     const pt T0 = mul_x(P);                                      // [x] P       (ec.py:540-550)
     const pt T1 = mul_x(T0);                                     // [x^2] P
-    const pt t2 = padd(padd(T1, T0), pneg(P));
-    const pt t3 = psi(padd(T0, P));
-    const pt p2 = psi(psi(pdbl(P)));
-    const pt R = padd(padd(t2, pneg(t3)), p2);
-    // affine: (X, Y) / Z with 1 / Z = conj(Z) / N(Z); Z = 0 gives (0, 0)
-    fe n = fe_add(fe_mul(R.Z.a, R.Z.a), fe_mul(R.Z.b, R.Z.b)), ninv;
-    bls::fq_inv(ninv.v, n.v);
-    const fe2 zi = {fe_mul(R.Z.a, ninv), fe_neg(fe_mul(R.Z.b, ninv))};
-    const fe2 xa = f2_mul(R.X, zi), ya = f2_mul(R.Y, zi);
-    fe raw1 = fe_zero();
-    raw1.v[0] = 1;                                               // content 1: x R -> x
-    const fe o[4] = {fe_mul(xa.a, raw1), fe_mul(xa.b, raw1), fe_mul(ya.a, raw1), fe_mul(ya.b, raw1)};
-    for (int k = 0; k < 4; k++)
-        for (int w = 0; w < 12; w++) out[(size_t)m * 48 + k * 12 + w] = bswap32(o[k].v[11 - w]);
+    const pt t2 = padd_fn(padd_fn(T1, T0), pneg(P));
+    const pt t3 = psi(padd_fn(T0, P));
+    const pt p2 = psi(psi(pdbl_fn(P)));
+    const pt R = padd_fn(padd_fn(t2, pneg(t3)), p2);
+    // affine: (X, Y) / Z with 1 / Z = conj(Z) / N(Z); Z = 0 gives (0, 0).  The inversion is the safegcd routine of fq32.h on
+    // the VM's form of the norm.
+    const fe n = dot2(R.Z.a, R.Z.a, R.Z.b, R.Z.b);
+    uint32_t nv[12], niv[12];
+    to_vm(nv, n);
+    bls::fq_inv(niv, nv);
+    const fe ninv = from_vm(niv);
+    const fe2 zi = {mul(R.Z.a, ninv), mul(neg(R.Z.b), ninv)};
+    const fe2 xa = mul(R.X, zi), ya = mul(R.Y, zi);
+    const fe o[4] = {xa.a, xa.b, ya.a, ya.b};
+    for (int k = 0; k < 4; k++) {
+        uint32_t y[12];
+        to_raw(y, o[k]);
+        for (int w = 0; w < 12; w++) out[(size_t)m * 48 + k * 12 + w] = bswap32(y[11 - w]);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -440,72 +440,71 @@ __global__ void __launch_bounds__(64) k_msm_horner_np(VmTables T, const uint32_t
 }
 
 // ---------------------------------------------------------------------------
-// Bucket method with ONE (group, chunk, window) PER LANE (blsgpu_reg.hip): the lanes of a
-// wavefront are the 64 windows of the same chunk of points, so they read the same point
-// (one broadcast load) and add it to the bucket their own digit selects (signed nibbles:
-// buckets 1 .. 8 take +-P; 15 buckets for a scalar too large to recode).  The buckets
-// of a lane live in HBM (144 B G1 / 288 B G2 each, read and written once per addition:
-// ~0.3 KB of traffic against ~9 k / 25 k instructions).  Used when a batch offers enough
-// lanes to fill the chip (blsgpu_api.hip); the LDS-bucket kernels above serve the rest.
+// Bucket method with ONE (group, chunk, window) PER LANE (fp28.h: 14 signed 28-bit limbs, sums of
+// products): the lanes of a wavefront are the 64 windows of the same chunk of points, so they read
+// the same point (one broadcast load) and add it to the bucket their own digit selects (signed
+// nibbles: buckets 1 .. 8 take +-P; 15 buckets for a scalar too large to recode).  The buckets of
+// a lane live in HBM in the L28 form (168 B G1 / 336 B G2 each, read and written once per addition:
+// ~0.4 KB of traffic against ~4.5 k / 14 k instructions).  Used when a batch offers enough lanes to
+// fill the chip (blsgpu_api.hip); the LDS-bucket kernels above serve the rest.
 template <int DEG> struct LaneElem;
-template <> struct LaneElem<1> { typedef reg::fe E; };
-template <> struct LaneElem<2> { typedef reg::fe2 E; };
+template <> struct LaneElem<1> { typedef r28::fe E; };
+template <> struct LaneElem<2> { typedef r28::fe2 E; };
+constexpr uint32_t L28_AFF = 2 * r28::NL;                     // dwords of an affine L28 point per degree
+constexpr uint32_t L28_PJ = 3 * r28::NL;                      // dwords of a projective L28 point per degree
 
-__device__ __forceinline__ void lane_ld(reg::fe& x, const uint32_t* p, bool canon) {
-    for (int j = 0; j < 12; j++) x.v[j] = p[j];
-    if (canon) bls::fq_canon(x.v);
-}
-__device__ __forceinline__ void lane_ld(reg::fe2& x, const uint32_t* p, bool canon) { lane_ld(x.a, p, canon); lane_ld(x.b, p + 12, canon); }
-__device__ __forceinline__ void lane_st(const reg::fe& x, uint32_t* p) { for (int j = 0; j < 12; j++) p[j] = x.v[j]; }
-__device__ __forceinline__ void lane_st(const reg::fe2& x, uint32_t* p) { lane_st(x.a, p); lane_st(x.b, p + 12); }
-template <class E> __device__ __forceinline__ reg::ptT<E> lane_ld_pt(const uint32_t* p, bool canon) {
-    reg::ptT<E> r;
-    constexpr int W = sizeof(E) / 4;
-    lane_ld(r.X, p, canon); lane_ld(r.Y, p + W, canon); lane_ld(r.Z, p + 2 * W, canon);
-    return r;
-}
-template <class E> __device__ __forceinline__ void lane_st_pt(const reg::ptT<E>& r, uint32_t* p) {
-    constexpr int W = sizeof(E) / 4;
-    lane_st(r.X, p); lane_st(r.Y, p + W); lane_st(r.Z, p + 2 * W);
-}
-__device__ __forceinline__ void lane_one(reg::fe& x) { const uint32_t o[12] = BLS_ONE_MONT_LIMBS; for (int j = 0; j < 12; j++) x.v[j] = o[j]; }
-__device__ __forceinline__ void lane_one(reg::fe2& x) { lane_one(x.a); x.b = reg::fe_zero(); }
-template <class E> __device__ __forceinline__ reg::ptT<E> lane_inf() {         // (0 : 1 : 0)
-    reg::ptT<E> r;
-    E z;
-    uint32_t* zp = reinterpret_cast<uint32_t*>(&z);
-    for (unsigned j = 0; j < sizeof(E) / 4; j++) zp[j] = 0;
-    r.X = z; r.Z = z; lane_one(r.Y);
-    return r;
+// the VM's projective form (36 * DEG dwords, x 2^384, canonical) of an L28 point
+__device__ __forceinline__ void lane_st_vm(const r28::fe& x, uint32_t* p) { r28::to_vm(p, x); }
+__device__ __forceinline__ void lane_st_vm(const r28::fe2& x, uint32_t* p) { r28::to_vm(p, x.a); r28::to_vm(p + 12, x.b); }
+template <class E> __device__ __forceinline__ void lane_st_pt_vm(const r28::ptT<E>& r, uint32_t* p) {
+    constexpr int W = 12 * (r28::Elem<E>::DW / r28::NL);
+    lane_st_vm(r.X, p); lane_st_vm(r.Y, p + W); lane_st_vm(r.Z, p + 2 * W);
 }
 
-// prep: projective Montgomery points of k_msm_prep; partial (win, chunk) of group g is written at
-// partials[((g * PIP_W + win) * chunks + chunk) * PJ_DW] -- the layout k_msm_pip_windows reads.
+// affine big-endian points (96 * DEG bytes, (0, 0) = infinity) -> affine L28 points + live flags, one point per
+// lane: a product by R^2 per coordinate
 template <int DEG>
-__global__ void __launch_bounds__(64) k_msm_lane(const uint32_t* __restrict__ prep, const uint32_t* __restrict__ scalars, uint32_t k,
+__global__ void __launch_bounds__(256) k_lane_prep(const uint32_t* __restrict__ pts, uint32_t n, uint32_t* __restrict__ prep,
+                                                   uint8_t* __restrict__ live) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t any = 0;
+#pragma unroll 1
+    for (int k = 0; k < 2 * DEG; k++) {
+        uint32_t c[12];
+#pragma unroll
+        for (int w = 0; w < 12; w++) { c[11 - w] = bswap32(pts[(size_t)i * 24 * DEG + k * 12 + w]); any |= c[11 - w]; }
+        r28::st(r28::from_raw(c), prep + (size_t)i * L28_AFF * DEG + k * r28::NL);
+    }
+    live[i] = any ? 1 : 0;
+}
+
+// prep / live: k_lane_prep's; partial (win, chunk) of group g is written at partials[((g * PIP_W + win) * chunks +
+// chunk) * PJ] -- the layout k_msm_pip_windows reads -- in the VM's form (PJ = 36 DEG) when vm_out, else L28 (42 DEG).
+template <int DEG>
+__global__ void __launch_bounds__(64) k_msm_lane(const uint32_t* __restrict__ prep, const uint8_t* __restrict__ live,
+                                                 const uint32_t* __restrict__ scalars, uint32_t k,
                                                  uint32_t chunk, uint32_t chunks, uint32_t total, uint32_t* __restrict__ buckets,
-                                                 uint32_t* __restrict__ partials) {
+                                                 uint32_t* __restrict__ partials, uint32_t vm_out) {
     typedef typename LaneElem<DEG>::E E;
-    constexpr uint32_t PJ_DW = 36 * DEG;
+    constexpr uint32_t PJ_DW = L28_PJ * DEG, AF_DW = L28_AFF * DEG;
     const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= total) return;
     const uint32_t win = L & 63u, cidx = (L >> 6) % chunks, grp = (L >> 6) / chunks;
     const uint32_t lo = grp * k + cidx * chunk, hi = min(grp * k + k, lo + chunk);
     uint32_t* B = buckets + (size_t)L * (PIP_NB - 1) * PJ_DW;                   // buckets 1 .. 15
     {
-        const reg::ptT<E> inf = lane_inf<E>();
-        for (int j = 0; j < PIP_NB - 1; j++) lane_st_pt(inf, B + j * PJ_DW);
+        const r28::ptT<E> inf = r28::pt_inf<E>();
+        for (int j = 0; j < PIP_NB - 1; j++) r28::pt_st(inf, B + j * PJ_DW);
     }
     // Signed digits: the nibbles of s + 0x88..8 minus 8 are digits in [-8, 7] with the same value (no carry out of
     // 256 bits while s < 2^256 - 0x88..8, which covers every scalar below the group order), so 8 buckets take
     // +-P and the running sums below cover 8 buckets instead of 15.  A larger scalar keeps its plain nibbles
     // (buckets 1 .. 15); the lanes of a wavefront see the same scalars, so `wide` is uniform.
     bool wide = false;
+#pragma unroll 1
     for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t* pt = prep + (size_t)i * PJ_DW;
-        uint32_t z = 0;
-        for (uint32_t j = 0; j < 12u * DEG; j++) z |= pt[24u * DEG + j];
-        if (z == 0) continue;                                                   // the point at infinity
+        if (!live[i]) continue;                                                 // the point at infinity
         uint32_t word;                                                          // the 32 bits that hold this window's nibble
         bool big = false;
         if (scalars) {
@@ -526,43 +525,52 @@ __global__ void __launch_bounds__(64) k_msm_lane(const uint32_t* __restrict__ pr
         wide = wide || big;
         if (d != 0) {
             uint32_t* b = B + ((d < 0 ? -d : d) - 1) * PJ_DW;
-            E x2, y2;
-            lane_ld(x2, pt, true);
-            lane_ld(y2, pt + 12 * DEG, true);
-            if (d < 0) y2 = reg::eneg(y2);
-            reg::ptT<E> r = lane_ld_pt<E>(b, false);
-            reg::pmadd(r, x2, y2);
-            lane_st_pt(r, b);
+            const uint32_t* pt = prep + (size_t)i * AF_DW;
+            const E x2 = r28::Elem<E>::load(pt);
+            E y2 = r28::Elem<E>::load(pt + r28::Elem<E>::DW);
+            if (d < 0) y2 = r28::norm(r28::neg(y2));
+            r28::ptT<E> r = r28::pt_ld<E>(b);
+            r28::pmadd(r, x2, y2);
+            r28::pt_st(r, b);
         }
     }
-    reg::ptT<E> acc = lane_inf<E>(), tot = lane_inf<E>();                       // sum_j j B_j by running sums
+    r28::ptT<E> acc = r28::pt_inf<E>(), tot = r28::pt_inf<E>();                 // sum_j j B_j by running sums
 #pragma unroll 1
     for (int j = wide ? PIP_NB - 2 : PIP_NB / 2 - 1; j >= 0; j--) {
-        acc = reg::padd(acc, lane_ld_pt<E>(B + j * PJ_DW, false));
-        tot = reg::padd(tot, acc);
+        if constexpr (DEG == 1) {
+            acc = r28::padd(acc, r28::pt_ld<E>(B + j * PJ_DW));
+            tot = r28::padd(tot, acc);
+        } else {                                                                // a twist addition is ~140 KB of code: one copy
+            acc = r28::padd_fn(acc, r28::pt_ld<E>(B + j * PJ_DW));
+            tot = r28::padd_fn(tot, acc);
+        }
     }
-    lane_st_pt(tot, partials + (((size_t)grp * PIP_W + win) * chunks + cidx) * PJ_DW);
+    const size_t o = ((size_t)grp * PIP_W + win) * chunks + cidx;
+    if (vm_out) lane_st_pt_vm(tot, partials + o * 36 * DEG);
+    else r28::pt_st(tot, partials + o * PJ_DW);
 }
 
-// out[w * nfold + f] = sum of partials[w * chunks + f * per .. + per): one run per lane
+// out[w * nfold + f] = sum of partials[w * chunks + f * per .. + per): one run per lane; L28 in, L28 or the VM's form out
 template <int DEG>
 __global__ void __launch_bounds__(64) k_msm_lane_fold(const uint32_t* __restrict__ partials, uint32_t chunks, uint32_t per, uint32_t nfold,
-                                                      uint32_t total, uint32_t* __restrict__ out) {
+                                                      uint32_t total, uint32_t* __restrict__ out, uint32_t vm_out) {
     typedef typename LaneElem<DEG>::E E;
-    constexpr uint32_t PJ_DW = 36 * DEG;
+    constexpr uint32_t PJ_DW = L28_PJ * DEG;
     const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= total) return;
     const uint32_t w = L / nfold, f = L % nfold;
     const uint32_t lo = f * per, hi = min(chunks, lo + per);
-    reg::ptT<E> acc = lane_inf<E>();
-    for (uint32_t i = lo; i < hi; i++) acc = reg::padd<E, DEG == 1>(acc, lane_ld_pt<E>(partials + ((size_t)w * chunks + i) * PJ_DW, false));
-    lane_st_pt(acc, out + ((size_t)w * nfold + f) * PJ_DW);
+    r28::ptT<E> acc = r28::pt_inf<E>();
+#pragma unroll 1
+    for (uint32_t i = lo; i < hi; i++) acc = r28::padd(acc, r28::pt_ld<E>(partials + ((size_t)w * chunks + i) * PJ_DW));
+    if (vm_out) lane_st_pt_vm(acc, out + ((size_t)w * nfold + f) * 36 * DEG);
+    else r28::pt_st(acc, out + ((size_t)w * nfold + f) * PJ_DW);
 }
 
 // ---------------------------------------------------------------------------
 // Sorted buckets: ONE large G1 sum with scalars (BLS.aggregate_pub_keys(secure) at scale, bls.py:203-223 --
 // BASELINE config 5).  Windows of `cb` bits (13 for 2^20 points: 20 windows instead of 64); key = window * 2^cb +
-// digit.  A counting sort (k_srt_live, k_srt_count, k_srt_scan_*, k_srt_scatter) lists the point indices by key; the list is cut
+// digit.  A counting sort (k_srt_count, k_srt_scan_*, k_srt_scatter) lists the point indices by key; the list is cut
 // into EQUAL pieces, one per lane (k_srt_accum): a lane keeps its running bucket sum in registers and adds affine
 // points to it (complete mixed addition, two wavefronts per SIMD), writing a sum out whenever the key changes.  A
 // bucket whose run begins in the lane is written by that lane alone; the piece of a run that continues from the lane
@@ -570,31 +578,9 @@ __global__ void __launch_bounds__(64) k_msm_lane_fold(const uint32_t* __restrict
 // bit -- S_b = sum of the buckets whose digit has bit b (k_srt_bits + k_msm_lane_fold: plain sums, no dependent
 // chain over 8191 buckets), W_w = sum_b 2^b S_b (k_srt_windows) -- then Horner over the windows.
 // Same value as the reference's double-and-add summed over the points (fields_t.py:705-740); parity is on the
-// affine result.  Points at infinity ((0,0)) and zero digits are left out of the list.
+// affine result.  Points at infinity ((0,0)) and zero digits are left out of the list.  Points and sums are in the
+// L28 form of fp28.h (k_lane_prep<1>); the last fold hands the VM its own form.
 constexpr uint32_t SRT_LANES = 2048u * 64u;                   // two wavefronts per SIMD
-
-// affine big-endian G1 points -> the projective Montgomery triples of k_msm_prep ((0:1:0) for the (0,0) encoding), one
-// point per lane: two products by R^2 in registers (the team kernel k_msm_prep takes 0.32 ms for 2^20 points, this 0.05)
-__global__ void __launch_bounds__(256) k_srt_prep(const uint32_t* __restrict__ pts, uint32_t n, uint32_t* __restrict__ prep) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t r2[12] = BLS_R2_LIMBS, one[12] = BLS_ONE_MONT_LIMBS;
-    reg::fe c[2], rr;
-    for (int j = 0; j < 12; j++) rr.v[j] = r2[j];
-    uint32_t any = 0;
-    for (int k = 0; k < 2; k++)
-        for (int w = 0; w < 12; w++) { c[k].v[11 - w] = bswap32(pts[(size_t)i * 24 + k * 12 + w]); any |= c[k].v[11 - w]; }
-    uint32_t* o = prep + (size_t)i * 36;
-    if (any == 0) {
-        for (int j = 0; j < 12; j++) { o[j] = 0; o[12 + j] = one[j]; o[24 + j] = 0; }
-        return;
-    }
-    for (int k = 0; k < 2; k++) {
-        const reg::fe m = reg::fe_mul(c[k], rr);
-        for (int j = 0; j < 12; j++) o[k * 12 + j] = m.v[j];
-    }
-    for (int j = 0; j < 12; j++) o[24 + j] = one[j];
-}
 
 // digit of window w straight from the big-endian scalar (one or two of its eight words)
 __device__ __forceinline__ uint32_t srt_digit_at(const uint32_t* __restrict__ sc, uint32_t w, uint32_t cb) {
@@ -602,15 +588,6 @@ __device__ __forceinline__ uint32_t srt_digit_at(const uint32_t* __restrict__ sc
     uint32_t v = bswap32(sc[7u - j]) >> sft;
     if (sft + cb > 32u && j < 7u) v |= bswap32(sc[6u - j]) << (32u - sft);
     return v & ((1u << cb) - 1u);
-}
-
-// live[i] = 0 for the (0,0) encoding of infinity (Z = 0 after k_msm_prep): such points are left out of the list
-__global__ void __launch_bounds__(256) k_srt_live(const uint32_t* __restrict__ prep, uint32_t n, uint8_t* __restrict__ live) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t z = 0;
-    for (int j = 0; j < 12; j++) z |= prep[(size_t)i * 36 + 24 + j];
-    live[i] = z ? 1 : 0;
 }
 
 // Counting sort by key, histograms in LDS.  Workgroup (slice, window) owns SRT_SLICE consecutive points and the
@@ -705,10 +682,12 @@ __global__ void __launch_bounds__(1024) k_srt_scatter(const uint32_t* __restrict
 #ifndef BLSGPU_SRT_WAVES
 #define BLSGPU_SRT_WAVES 2
 #endif
+constexpr uint32_t SRT_PJ = L28_PJ;                           // dwords of a G1 sum (L28)
 __global__ void __launch_bounds__(64, BLSGPU_SRT_WAVES) k_srt_accum(const uint32_t* __restrict__ prep, const uint32_t* __restrict__ idx,
                                                      const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
                                                      uint32_t* __restrict__ bsum, uint32_t* __restrict__ headpart,
                                                      uint32_t* __restrict__ headkey) {
+    using r28::fe;
     const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= nlanes) return;
     const uint32_t total = start[nkeys], per = (total + nlanes - 1u) / nlanes;
@@ -722,28 +701,26 @@ __global__ void __launch_bounds__(64, BLSGPU_SRT_WAVES) k_srt_accum(const uint32
         }
         uint32_t key = lo, nxt = start[key + 1];
         bool head = start[key] < p0;
-        reg::ptT<reg::fe> acc = lane_inf<reg::fe>();
+        r28::ptT<fe> acc = r28::pt_inf<fe>();
 #pragma unroll 1
         for (uint32_t p = p0; p < p1; p++) {
             if (p == nxt) {                                   // the run of `key` ends here
-                if (head) { lane_st_pt(acc, headpart + (size_t)L * 36); hk = key; }
-                else lane_st_pt(acc, bsum + (size_t)key * 36);
+                if (head) { r28::pt_st(acc, headpart + (size_t)L * SRT_PJ); hk = key; }
+                else r28::pt_st(acc, bsum + (size_t)key * SRT_PJ);
                 head = false;
-                acc = lane_inf<reg::fe>();
+                acc = r28::pt_inf<fe>();
                 do { key++; nxt = start[key + 1]; } while (nxt <= p);
             }
 #ifdef BLSGPU_EXP_NOGATHER
-            const uint32_t* pt = prep + (size_t)(p & 1023u) * 36;
+            const uint32_t* pt = prep + (size_t)(p & 1023u) * L28_AFF;
 #else
-            const uint32_t* pt = prep + (size_t)idx[p] * 36;
+            const uint32_t* pt = prep + (size_t)idx[p] * L28_AFF;
 #endif
-            reg::fe x2, y2;
-            lane_ld(x2, pt, true);
-            lane_ld(y2, pt + 12, true);
-            reg::pmadd<reg::fe, true>(acc, x2, y2);
+            const fe x2 = r28::ld(pt), y2 = r28::ld(pt + r28::NL);
+            r28::pmadd(acc, x2, y2);
         }
-        if (head) { lane_st_pt(acc, headpart + (size_t)L * 36); hk = key; }
-        else lane_st_pt(acc, bsum + (size_t)key * 36);
+        if (head) { r28::pt_st(acc, headpart + (size_t)L * SRT_PJ); hk = key; }
+        else r28::pt_st(acc, bsum + (size_t)key * SRT_PJ);
     }
     headkey[L] = hk;
 }
@@ -754,45 +731,49 @@ constexpr uint32_t SRT_LONG = 3;
 __global__ void __launch_bounds__(64) k_srt_fix(const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
                                                 const uint32_t* __restrict__ headpart, const uint32_t* __restrict__ headkey,
                                                 uint32_t* __restrict__ bsum, uint32_t* __restrict__ nlong, uint32_t* __restrict__ longkeys) {
+    using r28::fe;
     const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     const uint32_t total = start[nkeys], per = (total + nlanes - 1u) / nlanes;
     const uint32_t s = start[key], e = start[key + 1];
-    if (s == e) { lane_st_pt(lane_inf<reg::fe>(), bsum + (size_t)key * 36); return; }
+    if (s == e) { r28::pt_st(r28::pt_inf<fe>(), bsum + (size_t)key * SRT_PJ); return; }
     const uint32_t l0 = s / per, l1 = (e - 1u) / per;
     if (l0 == l1) return;
     if (l1 - l0 > SRT_LONG) { longkeys[atomicAdd(nlong, 1u)] = key; return; }
-    reg::ptT<reg::fe> acc = lane_ld_pt<reg::fe>(bsum + (size_t)key * 36, false);
+    r28::ptT<fe> acc = r28::pt_ld<fe>(bsum + (size_t)key * SRT_PJ);
 #pragma unroll 1
     for (uint32_t l = l0 + 1; l <= l1; l++)
-        if (headkey[l] == key) acc = reg::padd<reg::fe, true>(acc, lane_ld_pt<reg::fe>(headpart + (size_t)l * 36, false));
-    lane_st_pt(acc, bsum + (size_t)key * 36);
+        if (headkey[l] == key) acc = r28::padd(acc, r28::pt_ld<fe>(headpart + (size_t)l * SRT_PJ));
+    r28::pt_st(acc, bsum + (size_t)key * SRT_PJ);
 }
 
 // one wavefront per long run: lane j sums the pieces l0 + 1 + j, + 64, ..; butterfly over the lanes; lane 0 adds the bucket
 __global__ void __launch_bounds__(64) k_srt_fix_long(const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
                                                      const uint32_t* __restrict__ headpart, uint32_t* __restrict__ bsum,
                                                      const uint32_t* __restrict__ nlong, const uint32_t* __restrict__ longkeys) {
+    using r28::fe;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = start[nkeys], per = (total + nlanes - 1u) / nlanes, cnt = *nlong;
     for (uint32_t k = blockIdx.x; k < cnt; k += gridDim.x) {
         const uint32_t key = longkeys[k];
         const uint32_t l0 = start[key] / per, l1 = (start[key + 1] - 1u) / per;
-        reg::ptT<reg::fe> acc = lane_inf<reg::fe>();
+        r28::ptT<fe> acc = r28::pt_inf<fe>();
 #pragma unroll 1
-        for (uint32_t l = l0 + 1u + lane; l <= l1; l += 64u) acc = reg::padd<reg::fe, true>(acc, lane_ld_pt<reg::fe>(headpart + (size_t)l * 36, false));
+        for (uint32_t l = l0 + 1u + lane; l <= l1; l += 64u) acc = r28::padd(acc, r28::pt_ld<fe>(headpart + (size_t)l * SRT_PJ));
 #pragma unroll 1
         for (int off = 32; off > 0; off >>= 1) {
-            reg::ptT<reg::fe> o;
-            uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
-            const uint32_t* aw = reinterpret_cast<const uint32_t*>(&acc);
+            r28::ptT<fe> o;
 #pragma unroll
-            for (int q = 0; q < 36; q++) ow[q] = (uint32_t)__shfl_xor((int)aw[q], off);
-            acc = reg::padd(acc, o);
+            for (int q = 0; q < r28::NL; q++) {
+                o.X.v[q] = __shfl_xor(acc.X.v[q], off);
+                o.Y.v[q] = __shfl_xor(acc.Y.v[q], off);
+                o.Z.v[q] = __shfl_xor(acc.Z.v[q], off);
+            }
+            acc = r28::padd(acc, o);
         }
         if (lane == 0) {
-            acc = reg::padd(acc, lane_ld_pt<reg::fe>(bsum + (size_t)key * 36, false));
-            lane_st_pt(acc, bsum + (size_t)key * 36);
+            acc = r28::padd(acc, r28::pt_ld<fe>(bsum + (size_t)key * SRT_PJ));
+            r28::pt_st(acc, bsum + (size_t)key * SRT_PJ);
         }
     }
 }
@@ -803,17 +784,18 @@ __global__ void __launch_bounds__(64) k_srt_fix_long(const uint32_t* __restrict_
 constexpr uint32_t SRT_BITADDS = 8;
 __global__ void __launch_bounds__(64) k_srt_bits(const uint32_t* __restrict__ bsum, uint32_t nwin, uint32_t cb, uint32_t total,
                                                  uint32_t* __restrict__ out) {
+    using r28::fe;
     const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= total) return;
     const uint32_t nitem = (1u << (cb - 1u)) / SRT_BITADDS;
     const uint32_t j = L % nitem, b = (L / nitem) % cb, w = L / (nitem * cb);
-    reg::ptT<reg::fe> acc = lane_inf<reg::fe>();
+    r28::ptT<fe> acc = r28::pt_inf<fe>();
 #pragma unroll 1
     for (uint32_t m = j * SRT_BITADDS; m < (j + 1u) * SRT_BITADDS; m++) {
         const uint32_t d = ((m >> b) << (b + 1u)) | (1u << b) | (m & ((1u << b) - 1u));
-        acc = reg::padd<reg::fe, true>(acc, lane_ld_pt<reg::fe>(bsum + ((size_t)(w << cb) + d) * 36, false));
+        acc = r28::padd(acc, r28::pt_ld<fe>(bsum + ((size_t)(w << cb) + d) * SRT_PJ));
     }
-    lane_st_pt(acc, out + (size_t)L * 36);
+    r28::pt_st(acc, out + (size_t)L * SRT_PJ);
 }
 
 // W_w = sum_b 2^b S_(w,b): one team per window, Horner over the bits
