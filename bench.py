@@ -19,8 +19,9 @@ A "step" is one pass of the hot path over one batch already resident in HBM.
   c3  (BASELINE configs[2]; strong scaling) ONE multi-pairing of 65 536 pairs, sharded N ways
       (8 192 per GPU at N = 8): one Miller product per rank, all-gather of one 576-byte partial
       per rank, one final exponentiation on every rank.
-  c4  threshold k = 67 of n = 100: 10 000 combines (G2 multi-scalar sums) + 10 000 two-pair verifies.
-  c5  one G1 multi-scalar sum over 2^20 different points (aggregate_pub_keys, secure = True).
+  c4  threshold k = 67 of n = 100: 10 000 combines (G2 multi-scalar sums) + 10 000 two-pair verifies per GPU.
+  c5  ONE G1 multi-scalar sum over 2^20 different points (aggregate_pub_keys, secure = True), the points split over the
+      ranks (strong scaling): per-rank sum, all-gather of one 100-byte record per rank, `world` additions.
   h2c hash 16 384 message hashes to G2.
 
 Every configuration checks its results (reference golden vectors where they exist, bilinearity /
@@ -328,6 +329,8 @@ def run_pairing(env, args):
     for e in engs:
         e.reserve((n + 3) * B)
         e.set_mp_threshold(0 if n * B >= 2048 else 1 << 40)    # throughput kernel once the batch can fill the GPU
+    from bls_py.dist import GpuShardBackend                    # the product's own multi-GPU class does the steps
+    shard = [GpuShardBackend(e, dev) for e in engs]
 
     # A step = Miller loops + per-verification products (stream k), [all-gather,] then the B final
     # exponentiations.  Miller launches of consecutive steps are serialised with an event (they would
@@ -341,15 +344,19 @@ def run_pairing(env, args):
         st = stream.cuda_stream
         if miller_done[0] is not None:
             stream.wait_event(miller_done[0])
-        engs[k].miller_product_batch_dev(t1.data_ptr(), t2.data_ptr(), n, B, parts[k].data_ptr(), st)
+        shard[k].miller_partials_batch_dev(t1, t2, n, B, parts[k], st)
         ev = torch.cuda.Event()
         ev.record(stream)
         miller_done[0] = ev
         if env.dist is None:
-            engs[k].final_exp_product_batch_dev(parts[k].data_ptr(), 1, B, outs[k].data_ptr(), st)
+            shard[k].final_batch_dev(parts[k], 1, B, outs[k], st)
         else:
-            env.all_gather_partials(stream, parts[k], gath[k], B * 144)     # B x 576 bytes per rank
-            engs[k].final_exp_product_batch_dev(gath[k].data_ptr(), world, B, outs[k].data_ptr(), st)
+            if env.backend == "nccl":
+                with torch.cuda.stream(stream):
+                    shard[k].all_gather_into(gath[k], parts[k])             # RCCL: B x 576 bytes per rank
+            else:
+                env.all_gather_partials(stream, parts[k], gath[k], B * 144)  # gloo rehearsal through host memory
+            shard[k].final_batch_dev(gath[k], world, B, outs[k], st)
 
     dt, step_ms, ktimes = timed_steps(env, args, step, engs, streams)
     results = [bytes(o.cpu().numpy()) for o in outs[:min(S, args.steps)]]
@@ -438,7 +445,43 @@ def run_pairing(env, args):
             if not cb["matches_gpu"]:
                 raise SystemExit("CPU oracle and GPU disagree -- bench invalid")
             line["cpu_baseline"] = cb
-        print(json.dumps(line))
+        if not c3 and world == 1 and not args.no_secondary:
+            line["secondary"] = secondary(env, args, eng, gen1, gen2)
+        return line
+    return None
+
+
+def secondary(env, args, eng, gen1, gen2):
+    """The other BASELINE configs once each, after the timed region (N = 1 only): c3 = ONE 65 536-pair multi-pairing
+    against the reference's digest, c4, c5, h2c as `--config` runs them (2 timed repetitions).  Every entry carries the
+    check it passed; a mismatch aborts the bench like the headline's."""
+    torch = env.torch
+    out = {}
+    # c3: the 65 536 pairs of tests/golden/pairing_seeded_65536.json (PRF indices 0 .. 65535), one call, one final exponentiation
+    n3 = C3_PAIRS
+    g1, g2, _, _ = seeded_points(eng, gen1, gen2, list(range(n3)))
+    x1, x2 = env.up(g1), env.up(g2)
+    o3 = torch.zeros(576, dtype=torch.uint8, device=env.dev)
+    eng.reserve(n3 + 3)
+    eng.set_mp_threshold(4096)
+    st = torch.cuda.current_stream().cuda_stream
+    dt3 = device_timed(env, lambda: eng.pairing_multi_dev(x1.data_ptr(), x2.data_ptr(), n3, o3.data_ptr(), st), 3)
+    with open(os.path.join(ROOT, "tests", "golden", "pairing_seeded_%d.json" % n3)) as f:
+        if bytes(o3.cpu().numpy()).hex() != json.load(f)["out"]:
+            raise SystemExit("c3 result differs from the reference's digest -- bench invalid")
+    out["c3"] = {"value": n3 / dt3, "unit": "pairings/s", "ms": dt3 * 1e3, "check": "reference-digest-ok",
+                 "workload": "ONE multi-pairing of %d pairs on one GPU incl. its final exponentiation (BASELINE configs[2] unsharded)" % n3,
+                 "roofline_frac": (MAC_PER_PAIRING * n3 + MAC_PER_FINAL_EXP) / dt3 / 1e12 / PEAK_TMACS}
+    del x1, x2
+    sub = argparse.Namespace(**vars(args))
+    sub.steps = 2
+    for name, fn in (("c4", run_c4), ("c5", run_c5), ("h2c", run_h2c)):
+        ln = fn(env, sub)
+        out[name] = {"value": ln["value"], "unit": ln["unit"], "ms": ln["ms_per_step"], "check": ln["config"]["check"],
+                     "workload": ln["config"]["workload"], "roofline_frac": ln["roofline"]["frac"]}
+        if name == "c4":
+            out[name].update(combine_ms=ln["combine_s"] * 1e3, verify_ms=ln["verify_s"] * 1e3)
+    return out
 
 
 def device_timed(env, fn, reps):
@@ -502,7 +545,7 @@ def run_c4(env, args):
         # additions of 36 Fq-mults; two Miller loops + one final exponentiation per verify
         mac_combine = 64 * (k + 30) * 36 * MAC_PER_FQ_MUL
         mac_verify = 2 * MAC_PER_PAIRING + MAC_PER_FINAL_EXP
-        print(json.dumps({
+        return {
             "metric": "threshold groups/sec (k=67 of n=100: combine + verify)", "value": groups * env.world / dt, "unit": "groups/s",
             "n_gpus": env.world, "steps": reps, "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
@@ -510,61 +553,87 @@ def run_c4(env, args):
                                    "bucket method with signed 4-bit digits, one (group, window) per lane, 8 buckets in HBM, complete mixed additions" % groups, "name": "c4",
                        "check": "combine == c_g x reference golden, every verify == 1"},
             "combine_s": dt_c, "verify_s": dt_v,
-            "roofline": {"bound": "valu-int32-mac", "kernel": "k_msm_lane<2> (+ k_msm_prep, windows, horner)", "peak": PEAK_TMACS, "unit": "TMAC/s",
+            "roofline": {"bound": "valu-int32-mac", "kernel": "k_msm_lane<2> (+ k_lane_prep, windows, horner)", "peak": PEAK_TMACS, "unit": "TMAC/s",
                          "achieved": mac_combine * groups / dt_c / 1e12, "frac": mac_combine * groups / dt_c / 1e12 / PEAK_TMACS,
                          "verify_achieved": mac_verify * groups / dt_v / 1e12, "traffic": None,
-                         "algorithmic_bytes": groups * k * (192 + 32)}}))
+                         "algorithmic_bytes": groups * k * (192 + 32)}}
+    return None
 
 
 def run_c5(env, args):
-    """C5: one G1 multi-scalar sum over 2^20 DIFFERENT points (aggregate_pub_keys at scale)."""
+    """C5: ONE G1 multi-scalar sum over 2^20 DIFFERENT points (aggregate_pub_keys at scale), split over the ranks
+    (bls_py.dist: contiguous point split, one all-gather of a 100-byte record per rank, `world` additions on every rank)."""
     torch = env.torch
     from bls_py import _native
+    from bls_py.dist import GpuShardBackend, shard_bounds
     eng = _native.Engine(env.local_dev)
+    shard = GpuShardBackend(eng, env.dev)
     with open(os.path.join(ROOT, "tests", "golden", "pairing.json")) as f:
         gen1 = bytes.fromhex(json.load(f)["gen"]["g1"])
-    n = args.points
-    base = env.rank * n
-    a = [prf_scalar(b"blsgpu/a", 5, base + i) for i in range(n)]
-    t = [prf_scalar(b"blsgpu/t", 5, base + i) for i in range(n)]
+    total = args.points
+    lo, hi = shard_bounds(total, env.rank, env.world)
+    n = hi - lo
+    a = [prf_scalar(b"blsgpu/a", 5, lo + i) for i in range(n)]
+    t = [prf_scalar(b"blsgpu/t", 5, lo + i) for i in range(n)]
     pts = b""
-    for lo in range(0, n, 1 << 18):                     # the points a_i G1, in slices
-        m = min(1 << 18, n - lo)
-        p, _ = eng.g1_msm(gen1 * m, a[lo:lo + m], 1, m)
+    for s0 in range(0, n, 1 << 18):                     # the points a_i G1, in slices
+        m = min(1 << 18, n - s0)
+        p, _ = eng.g1_msm(gen1 * m, a[s0:s0 + m], 1, m)
         pts += p
     assert len(set(pts[96 * i:96 * (i + 1)] for i in range(0, n, max(1, n // 4096)))) == len(range(0, n, max(1, n // 4096)))
     tp, ts = env.up(pts), env.up(b"".join(x.to_bytes(32, "big") for x in t))
+    rec = torch.zeros(100, dtype=torch.uint8, device=env.dev)
+    gath = torch.zeros(100 * env.world, dtype=torch.uint8, device=env.dev)
     tout = torch.zeros(96, dtype=torch.uint8, device=env.dev)
-    tinf = torch.zeros(1, dtype=torch.uint8, device=env.dev)
-    lib, h = eng.lib, eng.h
+    tinf = torch.zeros(4, dtype=torch.uint8, device=env.dev)
     reps = max(1, args.steps)
-    dt = device_timed(env, lambda: lib.blsgpu_g1_msm_dev(h, tp.data_ptr(), ts.data_ptr(), n, 1, tout.data_ptr(), tinf.data_ptr(), 0), reps)
+
+    def one():
+        if env.dist is None:
+            shard._msm_dev(1, tp, ts, n, 1, tout, tinf)
+            return
+        shard.msm_partial_dev(1, tp, ts, n, rec)
+        if env.backend == "nccl":
+            shard.all_gather_into(gath, rec)
+        else:
+            host = [torch.zeros(100, dtype=torch.uint8) for _ in range(env.world)]
+            env.dist.all_gather(host, rec.cpu())
+            gath.copy_(torch.cat(host).to(env.dev))
+        shard.msm_finish_dev(1, gath, env.world, tout, tinf)
+    one()
+    env.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+    env.barrier()
+    dtm = env.max_over_ranks((time.perf_counter() - t0) / reps)
     got = bytes(tout.cpu().numpy())
-    s = sum(x * y for x, y in zip(a, t)) % N_ORDER       # sum t_i (a_i G) = (sum t_i a_i) G
-    want, _ = eng.g1_msm(gen1, [s], 1, 1)
-    ok = got == want
-    dtm = env.max_over_ranks(dt)
-    oks = env.gather_objects(ok)
+    parts = env.gather_objects(sum(x * y for x, y in zip(a, t)) % N_ORDER)       # sum t_i (a_i G) = (sum t_i a_i) G
+    want, _ = eng.g1_msm(gen1, [sum(parts) % N_ORDER], 1, 1)
+    oks = env.gather_objects(got == want)
     if env.rank == 0:
         if not all(oks):
             raise SystemExit("result mismatch -- bench invalid")
         # algorithmic work, SURVEY 8(d): Pippenger with 16-bit windows = 16 windows x (n + 2^16) mixed G1 additions of 11
         # Fq-mults (1.9e8 Fq-mults for 2^20 points).  Executed: 20 windows of 13 bits -- 20 n list additions of 11 Fq-mults
         # plus 20 x 13 x 4096 + 20 x 8191 full additions (12) for the buckets' bit sums and continuation pieces.
-        mac = 16 * (n + 65536) * 11 * MAC_PER_FQ_MUL
-        executed = (20 * n * 11 + (20 * 13 * 4096 + 20 * 8191) * 12) * MAC_PER_FQ_MUL
-        print(json.dumps({
-            "metric": "G1 multi-scalar-sum points/sec", "value": n * env.world / dtm, "unit": "points/s", "n_gpus": env.world,
-            "steps": reps, "warmup": 1, "ms_per_step": dtm * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        mac = 16 * (total + 65536) * 11 * MAC_PER_FQ_MUL
+        executed = (20 * total * 11 + (20 * 13 * 4096 + 20 * 8191) * 12) * MAC_PER_FQ_MUL
+        return {
+            "metric": "G1 multi-scalar-sum points/sec", "value": total / dtm, "unit": "points/s", "n_gpus": env.world,
+            "steps": reps, "warmup": 1, "ms_per_step": dtm * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4]: one G1 multi-scalar sum over %d different PRF points per GPU; sorted buckets: "
+            "config": {"workload": "BASELINE configs[4]: ONE G1 multi-scalar sum over %d different PRF points, %d per GPU; sorted buckets: "
                                    "13-bit windows, counting sort of the (window, digit) keys, equal pieces of the sorted list per lane "
-                                   "(complete mixed additions in registers), bit sums of the buckets, Horner (DESIGN.md 2d)" % n, "name": "c5",
+                                   "(complete mixed additions on 28-bit limbs in registers), bit sums of the buckets, Horner (DESIGN.md 2d)" % (total, n),
+                       "name": "c5", "parallelism": "points split %d ways + all-gather of 100 B per rank" % env.world,
                        "check": "sum t_i (a_i G) == (sum t_i a_i) G"},
-            "roofline": {"bound": "valu-int32-mac", "kernel": "k_srt_accum (+ k_msm_prep, k_srt_count/scan/scatter/fix/bits, fold, windows, horner)",
-                         "peak": PEAK_TMACS, "unit": "TMAC/s", "achieved": mac / dt / 1e12, "frac": mac / dt / 1e12 / PEAK_TMACS, "traffic": None,
-                         "executed_TMACs": executed / dt / 1e12 if n == 1 << 20 else None,
-                         "algorithmic_bytes": n * (96 + 32), "hbm_GBps_algorithmic": n * 128 / dt / 1e9}}))
+            "roofline": {"bound": "valu-int32-mac", "kernel": "k_srt_accum (+ k_lane_prep, k_srt_count/scan/scatter/fix/bits, fold, windows, horner)",
+                         "peak": PEAK_TMACS, "unit": "TMAC/s", "achieved": mac / dtm / 1e12 / env.world, "frac": mac / dtm / 1e12 / PEAK_TMACS / env.world,
+                         "traffic": None,
+                         "executed_TMACs": executed / dtm / 1e12 if total == 1 << 20 and env.world == 1 else None,
+                         "algorithmic_bytes": total * (96 + 32), "hbm_GBps_algorithmic": total * 128 / dtm / 1e9}}
+    return None
 
 
 def run_h2c(env, args):
@@ -587,14 +656,15 @@ def run_h2c(env, args):
             raise SystemExit("result mismatch -- bench invalid")
         # algorithmic work per message: 2 encodings x 5 fixed powers of ~380 squarings + 64 projective G2 steps of cofactor clearing
         mac = (2 * 5 * 380 * 2 + 2 * 64 * 36 + 400) * MAC_PER_FQ_MUL
-        print(json.dumps({
+        return {
             "metric": "hash-to-G2 messages/sec", "value": n * env.world / dtm, "unit": "messages/s", "n_gpus": env.world, "steps": reps,
             "warmup": 1, "ms_per_step": dtm * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "hash_to_point_prehashed_Fq2 of %d message hashes per GPU (SHA-256 chain, two SW encodings, cofactor clearing)" % n,
                        "name": "h2c", "check": "3 messages against the host integer code (itself pinned to the reference's vectors)"},
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_pow + k_h2c_stage + k_h2c_clear", "peak": PEAK_TMACS, "unit": "TMAC/s",
-                         "achieved": mac * n / dt / 1e12, "frac": mac * n / dt / 1e12 / PEAK_TMACS, "traffic": None}}))
+                         "achieved": mac * n / dt / 1e12, "frac": mac * n / dt / 1e12 / PEAK_TMACS, "traffic": None}}
+    return None
 
 
 def dry_run(args):
@@ -639,6 +709,7 @@ def main():
                     help="form the process group and run the all-gather even with one rank (RCCL rehearsal on a one-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="c2: skip the c3 / c4 / c5 / h2c runs after the timed region")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only (no GPU): form the process group, all-gather one 576-byte partial per rank over gloo, report")
     args = ap.parse_args()
@@ -651,7 +722,9 @@ def main():
     env = Env(args)
     if env.world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, env.world))
-    {"c2": run_pairing, "c3": run_pairing, "c4": run_c4, "c5": run_c5, "h2c": run_h2c}[args.config](env, args)
+    line = {"c2": run_pairing, "c3": run_pairing, "c4": run_c4, "c5": run_c5, "h2c": run_h2c}[args.config](env, args)
+    if line is not None:
+        print(json.dumps(line))
     env.finish()
 
 

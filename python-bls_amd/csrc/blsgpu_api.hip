@@ -120,6 +120,7 @@ static int grow_buffer(blsgpu_ctx* c, void** p, size_t* cap_bytes, size_t bytes)
     size_t want = bytes + bytes / 4;                     // headroom: fewer regrowths
     void* n = nullptr;
     if (hipMalloc(&n, want) != hipSuccess) {
+        (void)hipGetLastError();                         // the failed attempt must not show up in a later launch check
         want = bytes;
         HIP_TRY(hipMalloc(&n, want));
     }
@@ -229,9 +230,9 @@ int decompress_host(blsgpu_ctx* c, const uint8_t* in, size_t n, uint8_t* out, ui
 namespace {
 constexpr int MSM_WAVES = 4;
 
-// One large G1 sum with scalars by sorted buckets (blsgpu_msm.hip, k_srt_*).  Returns 1 without having written a
-// result when the digits are too unevenly spread for equal list pieces to pay (a run of very many pieces is
-// finished by ONE wavefront of k_srt_fix_long); the caller then takes the fixed-window path.
+// One large G1 sum with scalars by sorted buckets (blsgpu_msm.hip, k_srt_*): enqueues on `st` and returns, like every
+// _dev path (no synchronisation, usable under stream capture).  Returns 1 only when the key list would not fit 32 bits;
+// the caller then takes the fixed-window path.
 static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* d_out_inf, hipStream_t st) {
     // Window bits: with 131 072 equal pieces a run covers 131072 / (2^cb windows) pieces whatever n is -- 0.8 for
     // 13 bits, 1.5 for 12, 5 for 10 -- and a run of more than three pieces costs a whole wavefront in
@@ -249,7 +250,7 @@ static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars
     size_t off = 0;
     auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
     const size_t PJ = blsgpu::SRT_PJ;
-    const size_t o_prep = take(n * blsgpu::L28_AFF), o_cnt = take(nkeys), o_start = take(nkeys + 1), o_cur = take(nkeys), o_max = take(2),
+    const size_t o_prep = take(n * blsgpu::L28_AFF), o_cnt = take(nkeys), o_start = take(nkeys + 1), o_cur = take(nkeys), o_max = take(4),
                  o_idx = take((size_t)nwin * n), o_bsum = take(nkeys * PJ), o_hp = take(lanes * PJ), o_hk = take(lanes),
                  o_b0 = take(nsum * nch * PJ), o_b1 = take(nsum * ((nch + 7) / 8) * PJ), o_win = take((size_t)nwin * 36), o_live = take((n + 3) / 4),
                  o_wtot = take(2 * (size_t)nwin), o_long = take(nkeys + 4);
@@ -267,11 +268,9 @@ static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars
     hipLaunchKernelGGL(blsgpu::k_srt_scan_add, dim3(nwin), dim3(1024), 0, st, nwin, cb, W + o_wtot, W + o_wtot + nwin, W + o_start, W + o_cur,
                        W + o_max);
     HIP_TRY(hipGetLastError());
-    uint32_t h[2] = {0, 0};                                  // longest run, (unused)
-    HIP_TRY(hipMemcpyAsync(h, W + o_max, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h + 1, W + o_start + nkeys, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if ((uint64_t)h[0] * lanes > 2048ull * (uint64_t)h[1] + 2048ull * lanes) return 1;  // a run of more than ~2048 pieces
+    // No read-back, no host decision (round 3): whatever the digit distribution, a long run is finished by a wavefront of
+    // k_srt_fix_long -- all-equal scalars cost ~100 additions per lane there (a millisecond), and only a batch whose scalars
+    // leave all windows but one empty is slow (still correct, and still faster than the fixed windows it used to fall back to).
     hipLaunchKernelGGL(blsgpu::k_srt_scatter, sgrid, dim3(1024), 0, st, sc, live, (uint32_t)n, cb, W + o_cur, W + o_idx);
     hipLaunchKernelGGL(blsgpu::k_srt_accum, dim3((unsigned)(lanes / 64)), dim3(64), 0, st, W + o_prep, W + o_idx, W + o_start, (uint32_t)nkeys,
                        (uint32_t)lanes, W + o_bsum, W + o_hp, W + o_hk);

@@ -441,9 +441,10 @@ __device__ __forceinline__ void wg_product_tree(const VmTables& T, uint32_t* sme
 // workgroup's Miller values -> one Montgomery Fq12 partial (144 u32) per block.
 //   g1: n x 96 bytes (x || y), g2: n x 192 bytes (x.c0 || x.c1 || y.c0 || y.c1),
 //   big-endian canonical coordinates (the reference's serialisation, fields.py:87-88).
-// Infinity follows the reference's observable behaviour (tests/golden/pairing.json
-// "edge"): coordinates (0,0) for Q contribute 1 (0 if P.y is 0 too), (0,0) for P
-// contributes 1.
+// Every input gives the reference's bytes: a team whose pair fails the fast program's
+// validity tests (Q off the twist, final Z = 0, or a flagged Q -- zero coordinates, low-order
+// and off-curve points all end there) puts its block on the DegenList and k_miller_slow
+// recomputes that block's partial with the reference's own affine formulas.
 #ifndef BLSGPU_MILLER_WPS
 #define BLSGPU_MILLER_WPS 4
 #endif

@@ -652,6 +652,57 @@ def gen_hash_to_curve():
     dump("hash_to_curve.json", out)
 
 
+def scale_stream(tag, n, size):
+    """n pseudo-random strings of `size` bytes: sha256(tag || be32(i) || be32(j)) blocks (tests regenerate the same inputs)."""
+    out = []
+    for i in range(n):
+        b = b"".join(hashlib.sha256(tag + i.to_bytes(4, "big") + j.to_bytes(4, "big")).digest() for j in range((size + 31) // 32))
+        out.append(b[:size])
+    return out
+
+
+def gen_scale():
+    """SURVEY 8f ranks 1 and 3 pinned to the reference AT SCALE: 1024 message hashes through
+    hash_to_point_prehashed_Fq2 (ec.py:528-550); 2048 48-byte and 1024 96-byte encodings through PublicKey.from_bytes
+    (keys.py:28-40) / Signature.from_bytes (signature.py:21-38) -- half of them random strings (about half of which the
+    reference rejects), half the serialisations of real points with the flag bit either way.  Recorded: the digest of all
+    outputs, the accept / reject verdicts, every 64th output in full.  Inputs are regenerated by the tests (scale_stream)."""
+    out = {"rule": "inputs: sha256(tag || be32(i) || be32(j)) blocks, tag = blsgpu/h2c (32 bytes: the message hash), "
+                   "blsgpu/d1 (48), blsgpu/d2 (96); the SECOND half of the d1 / d2 inputs are i G1 / i G2 (i = index + 1) "
+                   "serialised by the reference, first byte ^ 0x80 for odd indices"}
+    msgs = scale_stream(b"blsgpu/h2c", 1024, 32)
+    pts = [g2_bytes(hash_to_point_prehashed_Fq2(m)) for m in msgs]
+    out["hash_to_g2"] = {"n": len(msgs), "inputs_sha256": hashlib.sha256(b"".join(msgs)).hexdigest(),
+                         "outputs_sha256": hashlib.sha256(b"".join(pts)).hexdigest(),
+                         "every_64th": {str(i): pts[i].hex() for i in range(0, len(pts), 64)}}
+    print("  hash_to_g2 done")
+    g1 = generator_Fq(default_ec)
+    g2 = generator_Fq2(default_ec_twist)
+    for name, tag, size, n, frm, gen, tobytes in (("g1_decompress", b"blsgpu/d1", 48, 2048, PublicKey.from_bytes, g1, g1_bytes),
+                                                  ("g2_decompress", b"blsgpu/d2", 96, 1024, Signature.from_bytes, g2, g2_bytes)):
+        enc = scale_stream(tag, n // 2, size)
+        for i in range(n // 2):
+            pt = (i + 1) * gen
+            e = bytearray((pt if isinstance(pt, AffinePoint) else pt.to_affine()).serialize())
+            if i & 1:
+                e[0] ^= 0x80
+            enc.append(bytes(e))
+        verdict, acc = [], []
+        for e in enc:
+            try:
+                v = frm(e).value.to_affine()
+                verdict.append(1)
+                acc.append(tobytes(v))
+            except Exception:
+                verdict.append(0)
+        bits = "".join(str(v) for v in verdict)
+        out[name] = {"n": n, "inputs_sha256": hashlib.sha256(b"".join(enc)).hexdigest(), "verdicts": bits,
+                     "accepted": sum(verdict), "accepted_points_sha256": hashlib.sha256(b"".join(acc)).hexdigest(),
+                     "every_64th_accepted": {str(i): acc[i].hex() for i in range(0, len(acc), 64)}}
+        print(" ", name, "accepted", sum(verdict), "of", n)
+    dump("scale.json", out)
+
+
 def gen_threshold(big):
     """Deterministic Joint-Feldman-free variant: one polynomial per group from
     the PRF, shares = P(j); unit signatures combined with Lagrange weights
@@ -750,6 +801,9 @@ if __name__ == "__main__":
             "verify4": gen_verify4, "scheme": gen_scheme,
             "hash": gen_hash_to_curve, "threshold": lambda: gen_threshold(big),
             "msm": lambda: gen_msm(big), "points": gen_points, "degenerate": gen_degenerate, "lines": gen_lines, "real_u": gen_real_u}
+    if "scale" in only:                     # opt-in: a few minutes of pure Python
+        gen_scale()
+        only = [a for a in only if a != "scale"] or ["-"]
     if "seeded8192" in only:                # opt-in: ~10 minutes of pure Python
         gen_seeded_digest(8192)
         only = [a for a in only if a != "seeded8192"] or ["-"]

@@ -59,6 +59,44 @@ class OracleShardBackend:
         return res
 
 
+    # ---- group sums: the same method names and arguments as GpuShardBackend, host tensors ----
+    def _sum(self, deg, pts, scalars, k):
+        if k == 0:
+            return bytes(96 * deg), True
+        fn = self.o.g1_msm if deg == 1 else self.o.g2_msm
+        return fn(pts, None if scalars is None else list(scalars), k)
+
+    def msm_partial(self, deg, pts, scalars, k):
+        out, inf = self._sum(deg, pts, scalars, k)
+        return torch.frombuffer(bytearray(out + bytes([1 if inf else 0, 0, 0, 0])), dtype=torch.uint8).clone()
+
+    def all_gather_records(self, rec, group=None):
+        world = dist.get_world_size(group)
+        outs = [torch.zeros(rec.numel(), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(outs, rec, group=group)
+        return torch.cat(outs), world
+
+    def msm_finish(self, deg, gathered, world):
+        raw = bytes(gathered.numpy())
+        per = 96 * deg + 4
+        return self._sum(deg, b"".join(raw[per * r:per * r + 96 * deg] for r in range(world)), None, world)
+
+    def msm_groups(self, deg, pts, scalars, k, groups):
+        rec = b""
+        for g in range(groups):
+            out, inf = self._sum(deg, pts[96 * deg * k * g:96 * deg * k * (g + 1)], None if scalars is None else scalars[k * g:k * (g + 1)], k)
+            rec += out + bytes([1 if inf else 0, 0, 0, 0])
+        return torch.frombuffer(bytearray(rec or b"\0"), dtype=torch.uint8).clone()[:len(rec)]
+
+    def all_gather_ragged(self, rec, per, counts, group=None):
+        mx = max(counts)
+        pad = torch.zeros(mx * per, dtype=torch.uint8)
+        pad[:rec.numel()] = rec
+        outs = [torch.zeros(mx * per, dtype=torch.uint8) for _ in counts]
+        dist.all_gather(outs, pad, group=group)
+        return b"".join(bytes(outs[r].numpy())[:counts[r] * per] for r in range(len(counts)))
+
+
 def _worker(rank, world, port, n, q):
     for p in (os.path.join(ROOT, "python-bls_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
@@ -78,6 +116,21 @@ def _worker(rank, world, port, n, q):
     batch = pairing_multi_batch_sharded(OracleShardBackend(O), g1s, g2s, rank, world)
     want = [O.pairing_multi(a, b, n) for a, b in zip(g1s, g2s)]
     assert batch == want and batch[0] == batch[1] == out and batch[2] != out
+    # group sums: ONE sum split by points (C5), a batch of sums split by groups (C4) -- uneven splits,
+    # a rank with no group at all, infinity among the partials
+    from bls_py.dist import msm_sharded, msm_groups_sharded
+    be = OracleShardBackend(O)
+    sc = [3, 0x1234567, 5, (1 << 255) - 19, 7, 0, 11][:min(n, 7)]
+    k = len(sc)
+    assert msm_sharded(be, 1, g1[:96 * k], sc, k, rank, world) == (O.g1_msm(g1[:96 * k], sc, k)[0], False)
+    assert msm_sharded(be, 2, g2[:192 * k], None, k, rank, world) == (O.g2_msm(g2[:192 * k], [1] * k, k)[0], False)
+    assert msm_sharded(be, 1, g1[:96], [0], 1, rank, world) == (bytes(96), True)          # one rank idle, the other sums to infinity
+    groups, kk = 3, 2
+    gs = [2, 3, 5, 7, 0, 0]
+    got, inf = msm_groups_sharded(be, 2, g2[:192 * kk * groups], gs, kk, groups, rank, world)
+    want = [O.g2_msm(g2[192 * kk * g:192 * kk * (g + 1)], gs[kk * g:kk * (g + 1)], kk)[0] for g in range(groups)]
+    assert got == b"".join(want) and inf == [False, False, True]
+    assert msm_groups_sharded(be, 1, g1[:96], [9], 1, 1, rank, world) == (O.g1_msm(g1[:96], [9], 1)[0], [False])
     q.put((rank, out.hex()))
     dist.barrier()
     dist.destroy_process_group()

@@ -294,7 +294,8 @@ def sorted_engine():
 
 @pytest.mark.parametrize("k", [1, 2, 65, 700, 3000])
 def test_sorted_buckets_vs_oracle(sorted_engine, oracle, seeded_pairs, k):
-    """k_srt_count/scan/scatter/accum/fix/bits/windows (8-bit windows at these sizes) against the oracle:
+    """k_srt_count/scan/scatter/accum/fix/bits/windows (12-bit windows at these sizes: the default below 2^18 points)
+    against the oracle:
     random, short, zero and extreme scalars, a point at infinity and repeated points in the list."""
     g1, _ = seeded_pairs
     rnd = random.Random(k * 13 + 1)
@@ -316,10 +317,52 @@ def test_sorted_buckets_degenerate(sorted_engine, engine, golden):
     assert sorted_engine.g1_msm(P + negP, [5, 5], 2) == (bytes(96), [True])
     assert sorted_engine.g1_msm(P * 3, [0, 0, 0], 3) == (bytes(96), [True])
     assert sorted_engine.g1_msm(P + bytes(96), [7, 9], 2) == engine.g1_msm(P, [7], 1)
-    # every point in the same buckets: the list is one run per window -> the uneven-digits guard hands the sum to
-    # the fixed-window kernels; same result
+    # every point in the same buckets: the list is one run per window
     assert sorted_engine.g1_msm(P * 400, [5] * 400, 400) == engine.g1_msm(P, [2000], 1)
     assert sorted_engine.g1_msm(P * 40, [N - 1] * 40, 40) == engine.g1_msm(P, [(N - 1) * 40 % N], 1)
+
+
+def test_sorted_buckets_one_scalar_for_all(sorted_engine, engine, seeded_pairs):
+    """All points share ONE scalar: every window's list is a single run that spans thousands of the equal pieces --
+    k_srt_fix_long's strided sums and butterfly finish it (round 3: no host-side guard, no fall-back to the fixed
+    windows, the call never synchronises).  sum s P_i = s (sum P_i), the plain sum through the fixed-window kernels."""
+    g1, _ = seeded_pairs
+    k = 6000
+    pts = (g1 * 6)[:96 * k]
+    for s in (0x1234567, N - 2):
+        plain, _ = engine.g1_msm(pts, None, k, 1)
+        want, _ = engine.g1_msm(plain, [s], 1, 1)
+        assert sorted_engine.g1_msm(pts, [s] * k, k, 1) == (want, [False])
+
+
+@pytest.mark.parametrize("n", [20000, 100000])
+def test_sorted_buckets_12_bit_windows_default_selection(engine, golden, n):
+    """The DEFAULT selection between 16 384 and 2^18 points: sorted buckets with 12-bit windows.  n different points
+    a_i G with PRF scalars t_i, checked by  sum t_i (a_i G) = (sum t_i a_i) G."""
+    gen1 = bytes.fromhex(golden("pairing.json")["gen"]["g1"])
+    a = [_prf(b"blsgpu/a", 7, i) for i in range(n)]
+    t = [_prf(b"blsgpu/t", 7, i) for i in range(n)]
+    pts, _ = engine.g1_msm(gen1 * n, a, 1, n)
+    got, inf = engine.g1_msm(pts, t, n, 1)
+    want, _ = engine.g1_msm(gen1, [sum(x * y for x, y in zip(a, t)) % N_ORDER], 1, 1)
+    assert got == want and not inf[0]
+
+
+def test_reference_1024_key_aggregate_through_sorted_buckets(sorted_engine, golden):
+    """BLS.aggregate_pub_keys(secure) of the reference's 1024 keys (msm.json, reference-generated) through the sorted
+    buckets (the engine of C5), and 16 copies of the list (16 384 points: the size from which it is the default)."""
+    import hashlib
+    rec = golden("msm.json")["1024"]
+    g = bytes.fromhex(golden("points.json")["g1"][0]["p"])
+    n = 1024
+    sks = [_prf(b"blsgpu/a", 1, i) for i in range(n)]
+    pks, _ = sorted_engine.g1_msm(g * n, sks, 1, n)
+    pts = sorted((pks[96 * i:96 * (i + 1)] for i in range(n)), key=_compress_g1)
+    digest = hashlib.sha256(b"".join(_compress_g1(p) for p in pts)).digest()
+    ts = [int.from_bytes(hashlib.sha256(i.to_bytes(4, "big") + digest).digest(), "big") % N for i in range(n)]
+    assert sorted_engine.g1_msm(b"".join(pts), ts, n)[0].hex() == rec["secure_affine"]
+    want, _ = sorted_engine.g1_msm(bytes.fromhex(rec["secure_affine"]), [16], 1, 1)
+    assert sorted_engine.g1_msm(b"".join(pts) * 16, ts * 16, 16 * n)[0] == want
 
 
 N_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
@@ -366,8 +409,8 @@ def test_c4_full_size_10000_groups(engine, golden):
 
 def test_c5_full_size_distinct_points(engine, golden):
     """BASELINE configs[4] at full size with the DEFAULT kernel selection: one G1 multi-scalar sum over
-    2^20 DIFFERENT points a_i G (PRF scalars), checked by  sum t_i (a_i G) = (sum t_i a_i) G;  and the
-    reference's 1024-key aggregate (msm.json) through the same default path."""
+    2^20 DIFFERENT points a_i G (PRF scalars), checked by  sum t_i (a_i G) = (sum t_i a_i) G  (the reference's 1024-key
+    aggregate through the same kernels: test_reference_1024_key_aggregate_through_sorted_buckets)."""
     gen1 = bytes.fromhex(golden("pairing.json")["gen"]["g1"])
     n = 1 << 20
     a = [_prf(b"blsgpu/a", 5, i) for i in range(n)]
