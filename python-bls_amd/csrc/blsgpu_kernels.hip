@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "fq32.h"
+#include "fp28.h"
 #include "vm_tables.h"
 
 namespace blsgpu {
@@ -210,7 +211,11 @@ __device__ __forceinline__ bool run_rounds(const VmTables& T, const uint2* __res
 #if defined(BLSGPU_EXP) && (BLSGPU_EXP & 1)
             for (int j = 0; j < 12; j++) D[j] = A[j] ^ B[j];  // timing experiment only
 #else
-            bls::fq_mul_relaxed(D, A, B);
+#if defined(BLSGPU_MUL32)
+            bls::fq_mul_relaxed(D, A, B);                     // rounds 1-2: v_mad_u64_u32 + v_addc_co_u32 columns
+#else
+            r28::vm_mul28(D, A, B);                           // carry-free 28-bit limbs inside the round (fp28.h)
+#endif
 #endif
             if (rd != 0xFFFFu) lds_store12(D, base16 + rd);
         } else if (kind == 1u) {                             // LIN
