@@ -44,6 +44,15 @@ def _g1_sums(groups_of_points, groups_of_scalars):
             for i in range(len(groups_of_points))]
 
 
+def _jac_g1_bytes(J):
+    """affine bytes (x || y, (0,0) for infinity) of a G1 JacobianPoint; no inversion when z = 1"""
+    if J.infinity:
+        return bytes(96)
+    if J.z.Z == 1:
+        return int(J.x.Z).to_bytes(48, "big") + int(J.y.Z).to_bytes(48, "big")
+    return H.g1_affine_bytes(J.to_affine()._aff())
+
+
 class BLS:
     @staticmethod
     def aggregate_sigs_simple(signatures):
@@ -94,11 +103,41 @@ class BLS:
             except KeyError:
                 return False
             key_groups.append([pk.value for pk in uniq])
+        prov = backend.get()
+        # (an infinity SIGNATURE keeps the tuple path: its flag is the one flag the reference's Miller loop reads)
+        if hasattr(prov, "verify_pipeline") and not signature.value.infinity and all(len(m) == 32 for m in by_message):
+            return BLS._verify_on_device(prov, signature, list(by_message), key_groups, exp_groups)
         Qs = hash_to_points_prehashed_Fq2(list(by_message))
         Ps = [t.to_affine() for t in _g1_sums(key_groups, exp_groups)]
         neg_g1 = generator_Fq() * (GROUP_ORDER - 1)
         res = ate_pairing_multi([neg_g1] + Ps, [signature.value.to_affine()] + Qs, default_ec)
         return res == Fq12.one(default_ec.q)
+
+    _NEG_G1 = None
+
+    @staticmethod
+    def _verify_on_device(prov, signature, hashes, key_groups, exp_groups):
+        """The same Ps / Qs as above (bls.py:177-199), assembled as bytes and left on the GPU between hash-to-G2, the
+        per-message key sums and the multi-pairing (HipProvider.verify_pipeline): no Python point objects per pair."""
+        if BLS._NEG_G1 is None:
+            BLS._NEG_G1 = H.g1_affine_bytes((generator_Fq() * (GROUP_ORDER - 1))._aff())
+        n = len(hashes)
+        sig = H.g2_affine_bytes(signature.value.to_affine()._aff())
+        if all(len(g) == 1 and e[0] % GROUP_ORDER == 1 for g, e in zip(key_groups, exp_groups)):
+            # one key with exponent 1 per message (a plain aggregate): the key itself is the pairing's P
+            keys = b"".join(_jac_g1_bytes(g[0]) for g in key_groups)
+            out = prov.verify_pipeline(BLS._NEG_G1, sig, b"".join(hashes), n, keys_affine=keys)
+        else:
+            k = max(len(g) for g in key_groups)
+            pts, sc = bytearray(), bytearray()
+            for g, e in zip(key_groups, exp_groups):
+                for p, x in zip(g, e):
+                    pts += _jac_g1_bytes(p)
+                    sc += (int(x) % GROUP_ORDER).to_bytes(32, "big")
+                pts += bytes(96) * (k - len(g))
+                sc += bytes(32) * (k - len(g))
+            out = prov.verify_pipeline(BLS._NEG_G1, sig, b"".join(hashes), n, key_pts=bytes(pts), key_scalars=bytes(sc), k=k)
+        return out == Fq12.one(default_ec.q).serialize()
 
     @staticmethod
     def verify_batch(signatures):

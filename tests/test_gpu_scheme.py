@@ -173,3 +173,42 @@ def test_secure_aggregation_and_division_on_gpu(golden):
     sF2 = BLS.aggregate_sigs([sF, sR2])
     quo2 = sF2.divide_by([sR2])
     assert BLS.verify(quo2) and quo2.serialize().hex() == n["quotient2"]
+
+
+def test_verify_pipeline_equals_the_tuple_path(golden):
+    """BLS.verify's device-resident pipeline (HipProvider.verify_pipeline: hash-to-G2, key sums and the multi-pairing without a
+    host round trip) against the object / tuple path of bls.py:153-201 through the same engine: plain aggregates (one key per
+    message, exponent 1), a secure aggregate (several keys and large exponents per message), tampered infos, an infinity
+    signature (which keeps the tuple path)."""
+    from bls_py import backend
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    from bls_py.signature import Signature
+    from bls_py.ec import JacobianPoint
+    from bls_py import hostmath as H
+
+    class TupleOnly:
+        """the HIP provider without the pipeline entry: BLS.verify falls back to ate_pairing_multi"""
+        def __init__(self, p):
+            self._p = p
+
+        def __getattr__(self, k):
+            if k == "verify_pipeline":
+                raise AttributeError(k)
+            return getattr(self._p, k)
+    hip = backend.get()
+    sks = [PrivateKey.from_seed(bytes([i + 1] * 5)) for i in range(6)]
+    plain = BLS.aggregate_sigs([sk.sign(bytes([i, 100 + i])) for i, sk in enumerate(sks)])
+    same_msg = BLS.aggregate_sigs([sk.sign(b"one message") for sk in sks[:4]])                      # secure: exponents from hash_pks
+    nested = BLS.aggregate_sigs([same_msg, sks[4].sign(b"one message"), sks[5].sign(b"another")])
+    bad = BLS.aggregate_sigs([sk.sign(bytes([i, 100 + i])) for i, sk in enumerate(sks[:5])])
+    bad.set_aggregation_info(plain.aggregation_info)
+    inf_sig = Signature.from_g2(JacobianPoint._from(H.F2, None), plain.aggregation_info)
+    cases = [plain, same_msg, nested, bad, inf_sig]
+    fast = [BLS.verify(s) for s in cases]
+    backend.use(TupleOnly(hip))
+    try:
+        slow = [BLS.verify(s) for s in cases]
+    finally:
+        backend.use(None)
+    assert fast == slow == [True, True, True, False, False]
