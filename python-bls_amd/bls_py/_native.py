@@ -23,7 +23,7 @@ SYMBOLS = (
     "blsgpu_g1_decompress", "blsgpu_g2_decompress", "blsgpu_g1_decompress_dev", "blsgpu_g2_decompress_dev",
     "blsgpu_hash_to_g2", "blsgpu_hash_to_g2_dev",
     "blsgpu_miller_loop_batch", "blsgpu_miller_loop_batch_dev", "blsgpu_line_eval_batch", "blsgpu_ctx_trim",
-    "blsgpu_fq12_op_batch", "blsgpu_fq12_pow_batch", "blsgpu_ctx_set_mp3_threshold",
+    "blsgpu_fq12_op_batch", "blsgpu_fq12_pow_batch", "blsgpu_ctx_set_mp3_threshold", "blsgpu_ctx_set_ls_threshold",
 )
 
 _lib = None
@@ -63,6 +63,7 @@ def load_library(path=None):
         L.blsgpu_ctx_reserve.argtypes = [vp, sz]
         L.blsgpu_ctx_set_mp_threshold.argtypes = [vp, sz]
         L.blsgpu_ctx_set_mp3_threshold.argtypes = [vp, sz]
+        L.blsgpu_ctx_set_ls_threshold.argtypes = [vp, sz, sz]
         L.blsgpu_ctx_trim.argtypes = [vp]
         L.blsgpu_pairing_multi.argtypes = [vp, cp, cp, cp, sz, cp]
         L.blsgpu_pairing_multi_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
@@ -136,6 +137,11 @@ class Engine:
     def set_mp3_threshold(self, pairs):
         """Throughput kernel: three pairs per wavefront from `pairs` pairs per call on, two below."""
         self._check(self.lib.blsgpu_ctx_set_mp3_threshold(self.h, pairs), "blsgpu_ctx_set_mp3_threshold")
+
+    def set_ls_threshold(self, pairs, min_group=64):
+        """Calls >= pairs with groups >= min_group use the line-stream kernels; pairs = None: never."""
+        self._check(self.lib.blsgpu_ctx_set_ls_threshold(self.h, (1 << 64) - 1 if pairs is None else pairs, min_group),
+                    "blsgpu_ctx_set_ls_threshold")
 
     def reserve(self, max_pairs):
         self._check(self.lib.blsgpu_ctx_reserve(self.h, max_pairs), "blsgpu_ctx_reserve")

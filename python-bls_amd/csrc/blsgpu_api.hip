@@ -14,6 +14,7 @@
 #include "../../include/blsgpu.h"
 #include "blsgpu_kernels.hip"
 #include "fp28.h"
+#include "blsgpu_ml.hip"
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
 
@@ -61,6 +62,19 @@ struct blsgpu_ctx {
     uint32_t* d_buckets = nullptr;     // their buckets (HBM)
     size_t bucket_cap = 0;
     uint32_t* d_msm_part = nullptr;    // MSM partials
+    // line-stream multi-pairing (blsgpu_ml.hip): used from ls_threshold pairs per call when every group has at least
+    // ls_min_group pairs
+    size_t ls_threshold = 16384;
+    size_t ls_min_group = 64;
+    size_t ls_teams = 40960;           // accumulators k_ml_accum aims at (10 per wavefront)
+    void* d_lines = nullptr;           // 68 x pairs line records
+    size_t lines_cap = 0;              // bytes
+    void* d_lsp[2] = {nullptr, nullptr};   // dense partial products (ping-pong over the merge levels)
+    size_t lsp_cap[2] = {0, 0};        // bytes
+    void* d_bad = nullptr;             // one byte per pair: left to the slow program
+    size_t bad_cap = 0;
+    void* d_extra = nullptr;           // Miller values of the listed pairs (VM form)
+    size_t extra_cap = 0;
     size_t msm_part_cap = 0;           // in u32
     // optional per-kernel timing (blsgpu_timing_enable): HIP events recorded on
     // the launch stream around every kernel, ring of TIMING_SLOTS launches
@@ -457,6 +471,9 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     c->device = device;
     c->mp_threshold = default_mp_threshold();
     if (const char* e = getenv("BLSGPU_MP3_THRESHOLD")) c->mp3_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_LS_THRESHOLD")) c->ls_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_LS_MIN_GROUP")) c->ls_min_group = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_LS_TEAMS")) c->ls_teams = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -569,6 +586,11 @@ BLSGPU_EXPORT void blsgpu_ctx_destroy(blsgpu_ctx* c) {
     if (c->d_msm_part) (void)hipFree(c->d_msm_part);
     if (c->d_buckets) (void)hipFree(c->d_buckets);
     if (c->d_degen) (void)hipFree(c->d_degen);
+    if (c->d_lines) (void)hipFree(c->d_lines);
+    for (int i = 0; i < 2; i++)
+        if (c->d_lsp[i]) (void)hipFree(c->d_lsp[i]);
+    if (c->d_bad) (void)hipFree(c->d_bad);
+    if (c->d_extra) (void)hipFree(c->d_extra);
     for (void* q : c->retired) (void)hipFree(q);
     if (c->last_event) (void)hipEventDestroy(c->last_event);
     if (c->ev0) {
@@ -609,6 +631,14 @@ BLSGPU_EXPORT int blsgpu_timing_read(blsgpu_ctx* c, float* ms, int* kind, size_t
 BLSGPU_EXPORT int blsgpu_ctx_set_mp_threshold(blsgpu_ctx* c, size_t pairs) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
     c->mp_threshold = pairs;
+    return 0;
+}
+// Calls of at least `pairs` pairs whose groups all have at least `min_group` pairs run the line-stream kernels
+// (blsgpu_ml.hip); (size_t)-1 for `pairs` keeps every call on the wavefront-VM kernels.
+BLSGPU_EXPORT int blsgpu_ctx_set_ls_threshold(blsgpu_ctx* c, size_t pairs, size_t min_group) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    c->ls_threshold = pairs;
+    c->ls_min_group = min_group ? min_group : 1;
     return 0;
 }
 BLSGPU_EXPORT int blsgpu_ctx_set_mp3_threshold(blsgpu_ctx* c, size_t pairs) {
@@ -707,6 +737,74 @@ static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, cons
     return 0;
 }
 
+// The line-stream form of launch_miller (blsgpu_ml.hip): ONE partial per group comes out (bpg = 1).
+static bool use_ls(const blsgpu_ctx* c, size_t gsz, size_t groups) {
+    return gsz >= c->ls_min_group && gsz * groups >= c->ls_threshold && gsz * groups <= 0x3FFFFFF0ull;
+}
+static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups,
+                            uint32_t* d_partials, hipStream_t st) {
+    using namespace blsgpu;
+    const size_t n = gsz * groups;
+    // chunk: pairs per accumulator, so that about ls_teams accumulators exist (never fewer than 8 pairs each)
+    size_t chunk = (n * ml::LINES + c->ls_teams - 1) / c->ls_teams;
+    if (chunk < 8) chunk = 8;
+    if (chunk > gsz) chunk = gsz;
+    size_t cpg = (gsz + chunk - 1) / chunk;
+    constexpr size_t FAN = 8;
+    if (int rc = grow_buffer(c, &c->d_lines, &c->lines_cap, n * ml::LINES * ml::LINE_DW * 4)) return rc;
+    if (int rc = grow_buffer(c, &c->d_lsp[0], &c->lsp_cap[0], groups * cpg * ml::LINES * ml::DENSE_DW * 4)) return rc;
+    if (int rc = grow_buffer(c, &c->d_lsp[1], &c->lsp_cap[1], groups * ((cpg + FAN - 1) / FAN) * ml::LINES * ml::DENSE_DW * 4)) return rc;
+    if (int rc = grow_buffer(c, &c->d_bad, &c->bad_cap, n)) return rc;
+    if (int rc = grow_buffer(c, &c->d_extra, &c->extra_cap, n * 576)) return rc;
+    if (int rc = grow_elems(c, &c->d_degen, &c->degen_cap, n + 2)) return rc;
+    DegenList dg{c->d_degen, c->d_degen + 1, (const uint8_t*)d_inf};
+    HIP_TRY(hipMemsetAsync(c->d_degen, 0, sizeof(uint32_t), st));
+    {
+        KernelTimer kt(c, st, 4);
+        hipLaunchKernelGGL(ml::k_ml_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1, (const uint32_t*)d_g2,
+                           (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
+    }
+    HIP_TRY(hipGetLastError());
+    {
+        KernelTimer kt(c, st, 3);
+        hipLaunchKernelGGL(k_ml_slow_pairs, dim3(SLOW_GRID), dim3(64), (size_t)SLOW_TEAM_BYTES, st, c->tabs, (const uint32_t*)d_g1,
+                           (const uint32_t*)d_g2, dg, (uint32_t*)c->d_extra);
+    }
+    HIP_TRY(hipGetLastError());
+    size_t teams = groups * cpg * ml::LINES;
+    {
+        KernelTimer kt(c, st, 5);
+        hipLaunchKernelGGL(ml::k_ml_accum, dim3((unsigned)((teams + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st, (const int32_t*)c->d_lines,
+                           (const uint8_t*)c->d_bad, (uint32_t)n, (uint32_t)gsz, (uint32_t)chunk, (uint32_t)cpg, (uint32_t)teams,
+                           (int32_t*)c->d_lsp[0]);
+    }
+    HIP_TRY(hipGetLastError());
+    int cur = 0;
+    while (cpg > 1) {
+        const size_t cpo = (cpg + FAN - 1) / FAN;
+        teams = groups * cpo * ml::LINES;
+        KernelTimer kt(c, st, 6);
+        hipLaunchKernelGGL(ml::k_ml_merge, dim3((unsigned)((teams + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur],
+                           (uint32_t)cpg, (uint32_t)FAN, (uint32_t)cpo, (uint32_t)teams, (int32_t*)c->d_lsp[cur ^ 1]);
+        HIP_TRY(hipGetLastError());
+        cpg = cpo;
+        cur ^= 1;
+    }
+    {
+        KernelTimer kt(c, st, 7);
+        hipLaunchKernelGGL(ml::k_ml_horner, dim3((unsigned)((groups + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur],
+                           (uint32_t)groups, d_partials, 144u);
+    }
+    HIP_TRY(hipGetLastError());
+    {
+        KernelTimer kt(c, st, 3);
+        hipLaunchKernelGGL(k_ml_fold_extras, dim3((unsigned)groups), dim3(64), (size_t)TEAM_BYTES, st, c->tabs, dg, (const uint32_t*)c->d_extra,
+                           (uint32_t)gsz, d_partials, 144u);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // Miller loops + per-group product; final exponentiation iff d_out_bytes
 static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups,
                            uint32_t* d_out_partial, void* d_out_bytes, hipStream_t st) {
@@ -728,7 +826,11 @@ static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, co
         if (rc) return rc;
     }
     size_t bpg = 0;
-    if (gsz > 0) {
+    if (gsz > 0 && use_ls(c, gsz, groups)) {
+        int rc = launch_miller_ls(c, d_g1, d_g2, d_inf, gsz, groups, c->d_part[0], st);
+        if (rc) return rc;
+        bpg = 1;
+    } else if (gsz > 0) {
         int rc = launch_miller(c, d_g1, d_g2, d_inf, gsz, groups, false, c->d_part[0], st, &bpg);
         if (rc) return rc;
     }

@@ -1,0 +1,429 @@
+// blsgpu_ml.hip -- the LINE-STREAM multi-pairing (round 3): the Miller loops of a large batch as two data-parallel
+// register kernels joined through HBM instead of one accumulator per wavefront (included by blsgpu_api.hip).
+//
+// Replaces the loop of fq_ate_pairing_multi / fq_miller_loop (fields_t.py:1091-1121; lines :1035-1078) for batches
+// that fill the chip.  vmgen/linestream_model.py is the integer model of exactly this data flow (CPU-tested against
+// the oracle and the reference's vectors):
+//
+//   k_ml_lines   one PAIR PER LANE, 28-bit-limb register arithmetic (fp28.h).  The twist-point chain T <- 2T (+ Q)
+//                does not depend on the Miller accumulator, so it runs alone; every step stores its line
+//                l = l0 + l2 w^2 + l3 w^3 (three Fq2 values, P already multiplied in) as an 84-dword record:
+//                lines[(L * n + pair) * 84], L = 0 .. 67 in execution order (63 tangents, 5 chords).
+//                22.8 KB per pair: the 8 TB/s of HBM3E are what makes cutting the loop here affordable.
+//   k_ml_accum   SIX LANES PER ACCUMULATOR (ten accumulators per wavefront): lane k holds the coefficient f_k of
+//                f = sum f_k w^k (Fq12 = Fq2[w]/(w^6 - xi)).  A team multiplies the line L of the pairs of its chunk
+//                into its accumulator: c_k = f_k l0 + F_{k-2} l2 + F_{k-3} l3 with F_i = f_i (i >= 0), xi f_{i+6}
+//                (i < 0) fetched from the team's lanes with ds_bpermute; each part of c_k is ONE sum of six products
+//                with one Montgomery reduction (fp28_dot6).  No squarings, no dependency between line indices.
+//   k_ml_merge   dense products of the chunks' partial products (same lane layout).
+//   k_ml_horner  f <- f^2 (before a tangent) ; f <- f M_L over the 68 per-line products of a group; hands the
+//                result to the wavefront VM's form (one partial per group for k_reduce / the final exponentiation).
+//
+// The value differs from the reference's Miller product by the line scalings (Fq2 factors and w^3 per line) that
+// the final exponentiation removes iff they are non-zero: a pair whose Q is off the twist, flagged,
+// or whose chain ends with Z = 0 is marked in bad[] and listed; k_ml_accum leaves it out, k_ml_slow_pairs computes
+// the reference's own Miller value for it (the VM's slow program) and k_ml_fold_extras multiplies those in.
+#pragma once
+
+namespace blsgpu {
+namespace ml {
+using r28::fe;
+using r28::fe2;
+using r28::NL;
+
+constexpr int LINES = 68;                  // 63 tangent steps + 5 chord steps of |x| = 0xd201000000010000
+constexpr int LINE_DW = 6 * NL;            // l0, l2, l3 (re, im each)
+constexpr int DENSE_DW = 12 * NL;          // f_0 .. f_5 (re, im each), w-power order
+constexpr int TEAMS = 10;                  // accumulators per wavefront (lanes 60 .. 63 idle)
+constexpr uint64_t ML_NX = 0xd201000000010000ull;
+
+// line index -> 1 iff it is a tangent (a new step of the loop: the accumulator is squared first)
+__device__ __forceinline__ bool line_is_tangent(uint32_t L) {
+    // chords follow the tangents of bits 62, 60, 57, 48, 16: line indices 1, 4, 8, 18, 51
+    return !(L == 1u || L == 4u || L == 8u || L == 18u || L == 51u);
+}
+
+// ---- stage A ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ fe load_coord(const uint32_t* __restrict__ src) {       // 48 big-endian bytes -> x R
+    uint32_t c[12];
+#pragma unroll
+    for (int w = 0; w < 12; w++) c[11 - w] = bswap32(src[w]);
+    return r28::from_raw(c);
+}
+__device__ __forceinline__ void store_line(int32_t* __restrict__ rec, const int32_t* l0a, const int32_t* l0b, const fe& l2a, const fe& l2b,
+                                           const fe& l3a, const fe& l3b) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        rec[j] = l0a[j]; rec[NL + j] = l0b[j];
+        rec[2 * NL + j] = l2a.v[j]; rec[3 * NL + j] = l2b.v[j];
+        rec[4 * NL + j] = l3a.v[j]; rec[5 * NL + j] = l3b.v[j];
+    }
+}
+
+// tangent step (vmgen/programs.t_double): X3 = 2XY(B - F), Y3 = (B + F)^2 - 12 E^2, Z3 = 4 B H with B = Y^2,
+// E = 3b' Z^2, F = 3E, H = 2YZ; line (B - E, X^2 (-3 px), H py)
+__device__ __forceinline__ void tangent_step(fe2& X, fe2& Y, fe2& Z, const fe& px3n, const fe& py2, int32_t* __restrict__ rec) {
+    const fe2 A = r28::mul(X, Y), B = r28::sqr(Y), C = r28::sqr(Z), XX = r28::sqr(X), YZ = r28::mul(Y, Z);
+    const fe2 E = r28::b3(C);
+    const auto F3 = r28::mulc<3>(E);
+    const fe2 BmF = r28::norm(r28::sub(B, F3));
+    const fe2 G = r28::norm(r28::add(B, F3));
+    const fe2 nE12 = r28::mulc_norm<12>(r28::neg(E));
+    const auto l0 = r28::sub(B, E);
+    const fe l2a = r28::mul(XX.a, px3n), l2b = r28::mul(XX.b, px3n);
+    const fe l3a = r28::mul(YZ.a, py2), l3b = r28::mul(YZ.b, py2);
+    store_line(rec, l0.a.v, l0.b.v, l2a, l2b, l3a, l3b);
+    X = r28::mul(r28::add(A, A), BmF);
+    Y = r28::dot2(G, G, nE12, E);
+    Z = r28::mul(B, r28::mulc_norm<8>(YZ));
+}
+// chord step (vmgen/programs.t_add, px_is_m3): th = Y - yq Z, la = X - xq Z, ...; line 3 (th xq - la yq), th (-3 px), la 3 py
+__device__ __forceinline__ void chord_step(fe2& X, fe2& Y, fe2& Z, const fe2& xq, const fe2& yq, const fe& px3n, const fe& py3,
+                                           int32_t* __restrict__ rec) {
+    const fe2 th = r28::norm(r28::sub(Y, r28::mul(yq, Z))), la = r28::norm(r28::sub(X, r28::mul(xq, Z)));
+    const fe2 C = r28::sqr(th), D = r28::sqr(la), E = r28::mul(la, D), Fz = r28::mul(Z, C), Gg = r28::mul(X, D);
+    const fe2 H = r28::norm(r28::sub(r28::add(E, Fz), r28::add(Gg, Gg)));
+    const fe2 GH = r28::norm(r28::sub(Gg, H));
+    const fe2 xq3 = r28::mulc_norm<3>(xq), nyq3 = r28::mulc_norm<3>(r28::neg(yq));
+    const fe2 l0 = r28::dot2(th, xq3, la, nyq3);
+    const fe l2a = r28::mul(th.a, px3n), l2b = r28::mul(th.b, px3n);
+    const fe l3a = r28::mul(la.a, py3), l3b = r28::mul(la.b, py3);
+    store_line(rec, l0.a.v, l0.b.v, l2a, l2b, l3a, l3b);
+    const fe2 nE = r28::norm(r28::neg(E));
+    const fe2 Y3 = r28::dot2(th, GH, nE, Y);
+    X = r28::mul(la, H);
+    Z = r28::mul(Z, E);
+    Y = Y3;
+}
+
+// One pair per lane.  bad[pair] = 1 and the pair goes on the work list iff the fast formulas are not the reference's
+// value for it (Q flagged, Q off the twist, final Z = 0); its lines are then ignored by k_ml_accum.
+#ifndef BLSGPU_ML_LINES_WAVES
+#define BLSGPU_ML_LINES_WAVES 1
+#endif
+__global__ void __launch_bounds__(64, BLSGPU_ML_LINES_WAVES) k_ml_lines(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
+                                                                         int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg) {
+    const uint32_t p = blockIdx.x * 64u + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t* s1 = g1 + (size_t)p * 24;
+    const uint32_t* s2 = g2 + (size_t)p * 48;
+    fe px3n, py2;
+    fe2 X, Y, Z = r28::fe2_one();
+    bool ok = !q_flagged(dg, p);
+    {
+        const fe px = load_coord(s1), py = load_coord(s1 + 12);
+        px3n = r28::mulc_norm<3>(r28::neg(px));
+        py2 = r28::mulc_norm<2>(py);
+        X = {load_coord(s2), load_coord(s2 + 12)};
+        Y = {load_coord(s2 + 24), load_coord(s2 + 36)};
+        // Q on the twist: y^2 - x^3 - 4 (1 + u) = 0
+        const fe2 yy = r28::sqr(Y), xxx = r28::mul(r28::sqr(X), X);
+        const auto four = r28::mulc<4>(r28::fe_one());
+        const auto da = r28::sub(r28::sub(yy.a, xxx.a), four), db = r28::sub(r28::sub(yy.b, xxx.b), four);
+        ok = ok && r28::is_zero(r28::mul(da, r28::fe_one())) && r28::is_zero(r28::mul(db, r28::fe_one()));
+    }
+    int32_t* rec = lines + (size_t)p * LINE_DW;
+    const size_t lstride = (size_t)n * LINE_DW;
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; bit--) {
+        tangent_step(X, Y, Z, px3n, py2, rec);
+        rec += lstride;
+        if ((ML_NX >> bit) & 1ull) {
+            const fe2 xq = {load_coord(s2), load_coord(s2 + 12)}, yq = {load_coord(s2 + 24), load_coord(s2 + 36)};
+            const fe py3 = r28::mulc_norm<3>(load_coord(s1 + 12));
+            chord_step(X, Y, Z, xq, yq, px3n, py3, rec);
+            rec += lstride;
+        }
+    }
+    ok = ok && !r28::is_zero(Z);
+    bad[p] = ok ? 0 : 1;
+    if (!ok) {
+        const uint32_t at = atomicAdd(dg.count, 1u);
+        dg.blocks[at] = p;
+    }
+}
+
+// ---- stages B / merge / Horner: six lanes per accumulator -----------------------------------------------------------
+struct Team {
+    uint32_t c;            // the lane's coefficient: power of w
+    uint32_t slot;         // team within the wavefront (10 = the idle lanes)
+    uint32_t base4;        // byte address (lane * 4) of the team's first lane, for ds_bpermute
+};
+__device__ __forceinline__ Team team_of_lane() {
+    const uint32_t lane = threadIdx.x & 63u;
+    Team t;
+    t.slot = lane / 6u;
+    t.c = lane - t.slot * 6u;
+    t.base4 = (lane - t.c) * 4u;
+    return t;
+}
+__device__ __forceinline__ void bperm14(int32_t* __restrict__ d, const int32_t* __restrict__ s, uint32_t addr) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) d[j] = __builtin_amdgcn_ds_bpermute((int)addr, s[j]);
+}
+// What a lane offers its team for one product: f_k and xi f_k, with the negated imaginary parts (a sum of products has
+// no subtraction).  NORM: the xi forms with normalised digits (dense products sum three wrapped terms per reduction).
+struct Pub { int32_t re[NL], im[NL], nim[NL], xre[NL], xim[NL], nxim[NL]; };
+template <bool NORM>
+__device__ __forceinline__ void publish(Pub& P, const int32_t* __restrict__ fre, const int32_t* __restrict__ fim) {
+    if (NORM) {
+        r28::F<1, 1> d; r28::F<0, 2> s;
+#pragma unroll
+        for (int j = 0; j < NL; j++) { d.v[j] = fre[j] - fim[j]; s.v[j] = fre[j] + fim[j]; }
+        const fe dn = r28::norm(d), sn = r28::norm(s);
+#pragma unroll
+        for (int j = 0; j < NL; j++) { P.xre[j] = dn.v[j]; P.xim[j] = sn.v[j]; P.nxim[j] = -sn.v[j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NL; j++) { P.xre[j] = fre[j] - fim[j]; P.xim[j] = fre[j] + fim[j]; P.nxim[j] = -(fre[j] + fim[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < NL; j++) { P.re[j] = fre[j]; P.im[j] = fim[j]; P.nim[j] = -fim[j]; }
+}
+// the operand F_{c - J} of the lane: from lane (c - J) mod 6 of the team, the xi form iff J > c
+struct Xop { int32_t re[NL], im[NL], nim[NL]; };
+template <int J>
+__device__ __forceinline__ void fetch(Xop& X, const Pub& P, const Team& t) {
+    if (J == 0) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) { X.re[j] = P.re[j]; X.im[j] = P.im[j]; X.nim[j] = P.nim[j]; }
+        return;
+    }
+    const uint32_t src = t.c >= (uint32_t)J ? t.c - J : t.c + 6u - J;
+    const uint32_t addr = t.base4 + src * 4u;
+    const bool wrap = t.c < (uint32_t)J;
+    int32_t a[NL], b[NL];
+    bperm14(a, P.re, addr); bperm14(b, P.xre, addr);
+#pragma unroll
+    for (int j = 0; j < NL; j++) X.re[j] = wrap ? b[j] : a[j];
+    bperm14(a, P.im, addr); bperm14(b, P.xim, addr);
+#pragma unroll
+    for (int j = 0; j < NL; j++) X.im[j] = wrap ? b[j] : a[j];
+    bperm14(a, P.nim, addr); bperm14(b, P.nxim, addr);
+#pragma unroll
+    for (int j = 0; j < NL; j++) X.nim[j] = wrap ? b[j] : a[j];
+}
+// (re, im) = sum over three terms of F_{c - J} y_J; y given as (re, im) arrays.  Column bound of fp28_dot6 (units of
+// 2^56): an unwrapped term 1 + 1, a wrapped one 1 + 2 (|xi f| limbs below 2^29 when not normalised) -- at most
+// 2 + 3 + 3 = 8 for the line positions (0, 2, 3), 3 x 2 = 6 with normalised xi forms: inside the 8 that 64 bits hold.
+template <int J0, int J1, int J2>
+__device__ __forceinline__ void mul3(int32_t* __restrict__ re, int32_t* __restrict__ im, const Pub& P, const Team& t,
+                                     const int32_t* y0r, const int32_t* y0i, const int32_t* y1r, const int32_t* y1i,
+                                     const int32_t* y2r, const int32_t* y2i) {
+    Xop X0, X1, X2;
+    fetch<J0>(X0, P, t);
+    fetch<J1>(X1, P, t);
+    fetch<J2>(X2, P, t);
+    bls28::fp28_dot6(re, X0.re, y0r, X0.nim, y0i, X1.re, y1r, X1.nim, y1i, X2.re, y2r, X2.nim, y2i);
+    bls28::fp28_dot6(im, X0.re, y0i, X0.im, y0r, X1.re, y1i, X1.im, y1r, X2.re, y2i, X2.im, y2r);
+}
+// f <- f g for a dense g given as 12 x 14 dwords (w-power order) behind `ld` (global or LDS): two half sums, added
+// and normalised (value in (-2q, 4q), digits below 2^28: a valid operand)
+template <class LD>
+__device__ __forceinline__ void mul_dense(int32_t* __restrict__ fre, int32_t* __restrict__ fim, const Team& t, const LD& ld) {
+    Pub P;
+    publish<true>(P, fre, fim);
+    int32_t y[6][NL], r0[NL], i0[NL], r1[NL], i1[NL];
+#pragma unroll
+    for (int k = 0; k < 6; k++) ld(y[k], k);
+    mul3<0, 1, 2>(r0, i0, P, t, y[0], y[1], y[2], y[3], y[4], y[5]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) ld(y[k], 6 + k);
+    mul3<3, 4, 5>(r1, i1, P, t, y[0], y[1], y[2], y[3], y[4], y[5]);
+    r28::F<0, 2> sr, si;
+#pragma unroll
+    for (int j = 0; j < NL; j++) { sr.v[j] = r0[j] + r1[j]; si.v[j] = i0[j] + i1[j]; }
+    const fe nr = r28::norm(sr), ni = r28::norm(si);
+#pragma unroll
+    for (int j = 0; j < NL; j++) { fre[j] = nr.v[j]; fim[j] = ni.v[j]; }
+}
+struct GlobalRec {
+    const int32_t* __restrict__ p;
+    __device__ __forceinline__ void operator()(int32_t* __restrict__ d, int k) const {
+#pragma unroll
+        for (int j = 0; j < NL; j++) d[j] = p[k * NL + j];
+    }
+};
+struct LdsRec {
+    const int32_t* p;
+    __device__ __forceinline__ void operator()(int32_t* __restrict__ d, int k) const {
+#pragma unroll
+        for (int j = 0; j < NL; j++) d[j] = p[k * NL + j];
+    }
+};
+__device__ __forceinline__ void set_one(int32_t* __restrict__ fre, int32_t* __restrict__ fim, const Team& t) {
+    const int32_t one[NL] = BLS28_ONE;
+#pragma unroll
+    for (int j = 0; j < NL; j++) { fre[j] = t.c == 0u ? one[j] : 0; fim[j] = 0; }
+}
+
+// Team (group g, chunk j, line L) = index ((g * cpg + j) * 68 + L): the product of line L over the pairs
+// [j * chunk, min(gsz, (j + 1) * chunk)) of group g that are not marked bad -> out[index * 168].
+#ifndef BLSGPU_ML_ACCUM_WAVES
+#define BLSGPU_ML_ACCUM_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad, uint32_t n,
+                                                                         uint32_t gsz, uint32_t chunk, uint32_t cpg, uint32_t nteams,
+                                                                         int32_t* __restrict__ out) {
+    const Team t = team_of_lane();
+    const uint32_t id = blockIdx.x * TEAMS + t.slot;
+    const bool valid = t.slot < (uint32_t)TEAMS && id < nteams;
+    const uint32_t idc = valid ? id : 0u;
+    const uint32_t L = idc % LINES, gj = idc / LINES, j = gj % cpg, g = gj / cpg;
+    const uint32_t lo = j * chunk, hi = min(gsz, lo + chunk);
+    const uint32_t cnt = valid ? hi - lo : 0u;
+    const size_t first = (size_t)g * gsz + lo;
+    int32_t fre[NL], fim[NL];
+    set_one(fre, fim, t);
+    const int32_t* base = lines + ((size_t)L * n + first) * LINE_DW;
+#pragma unroll 1
+    for (uint32_t i = 0; __any(i < cnt); i++) {
+        const bool act = i < cnt;
+        const uint32_t ii = act ? i : 0u;
+        const bool use = act && bad[first + ii] == 0;
+        const int4* rec = reinterpret_cast<const int4*>(base + (size_t)ii * LINE_DW);
+        int32_t y[6][NL];
+        {
+            int4 q[LINE_DW / 4];
+#pragma unroll
+            for (int k = 0; k < LINE_DW / 4; k++) q[k] = rec[k];
+#pragma unroll
+            for (int k = 0; k < LINE_DW / 4; k++) {
+                const int e = 4 * k;
+                y[e / NL][e % NL] = q[k].x; y[(e + 1) / NL][(e + 1) % NL] = q[k].y;
+                y[(e + 2) / NL][(e + 2) % NL] = q[k].z; y[(e + 3) / NL][(e + 3) % NL] = q[k].w;
+            }
+        }
+        Pub P;
+        publish<false>(P, fre, fim);
+        int32_t re[NL], im[NL];
+        mul3<0, 2, 3>(re, im, P, t, y[0], y[1], y[2], y[3], y[4], y[5]);
+#pragma unroll
+        for (int k = 0; k < NL; k++) { fre[k] = use ? re[k] : fre[k]; fim[k] = use ? im[k] : fim[k]; }
+    }
+    if (valid) {
+        int32_t* o = out + (size_t)id * DENSE_DW + t.c * 2 * NL;
+#pragma unroll
+        for (int k = 0; k < NL; k++) { o[k] = fre[k]; o[NL + k] = fim[k]; }
+    }
+}
+
+// One level of the product tree over the chunks: team (g, j', L) multiplies the records (g, j, L), j in
+// [j' * fan, min(cpg_in, (j' + 1) * fan)), of `in` (indexed as k_ml_accum's output with cpg_in) -> out (cpg_out).
+__global__ void __launch_bounds__(64, 2) k_ml_merge(const int32_t* __restrict__ in, uint32_t cpg_in, uint32_t fan, uint32_t cpg_out,
+                                                    uint32_t nteams, int32_t* __restrict__ out) {
+    const Team t = team_of_lane();
+    const uint32_t id = blockIdx.x * TEAMS + t.slot;
+    const bool valid = t.slot < (uint32_t)TEAMS && id < nteams;
+    const uint32_t idc = valid ? id : 0u;
+    const uint32_t L = idc % LINES, gj = idc / LINES, jo = gj % cpg_out, g = gj / cpg_out;
+    const uint32_t lo = jo * fan, hi = min(cpg_in, lo + fan);
+    const uint32_t cnt = valid ? hi - lo : 0u;
+    int32_t fre[NL], fim[NL];
+    {
+        const int32_t* r = in + ((size_t)(g * cpg_in + lo) * LINES + L) * DENSE_DW + t.c * 2 * NL;
+#pragma unroll
+        for (int k = 0; k < NL; k++) { fre[k] = r[k]; fim[k] = r[NL + k]; }
+    }
+#pragma unroll 1
+    for (uint32_t i = 1; __any(i < cnt); i++) {
+        const bool act = i < cnt;
+        const uint32_t ii = act ? i : 0u;
+        int32_t nre[NL], nim[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) { nre[k] = fre[k]; nim[k] = fim[k]; }
+        mul_dense(nre, nim, t, GlobalRec{in + ((size_t)(g * cpg_in + lo + ii) * LINES + L) * DENSE_DW});
+#pragma unroll
+        for (int k = 0; k < NL; k++) { fre[k] = act ? nre[k] : fre[k]; fim[k] = act ? nim[k] : fim[k]; }
+    }
+    if (valid) {
+        int32_t* o = out + (size_t)id * DENSE_DW + t.c * 2 * NL;
+#pragma unroll
+        for (int k = 0; k < NL; k++) { o[k] = fre[k]; o[NL + k] = fim[k]; }
+    }
+}
+
+// Team g: f = M_0; for L = 1 .. 67: (tangent: f <- f^2;) f <- f M_L with M_L = prods[(g * 68 + L) * 168]; then the
+// VM's form: partials[g * pstride + ...] (144 words, the reference's flat order, x 2^384 canonical).
+__global__ void __launch_bounds__(64, 2) k_ml_horner(const int32_t* __restrict__ prods, uint32_t groups, uint32_t* __restrict__ partials,
+                                                     uint32_t pstride) {
+    __shared__ int32_t own[TEAMS + 1][DENSE_DW];
+    const Team t = team_of_lane();
+    const uint32_t g = blockIdx.x * TEAMS + t.slot;
+    const bool valid = t.slot < (uint32_t)TEAMS && g < groups;
+    const uint32_t gc = valid ? g : 0u;
+    const int32_t* rec = prods + (size_t)gc * LINES * DENSE_DW;
+    int32_t fre[NL], fim[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) { fre[k] = rec[t.c * 2 * NL + k]; fim[k] = rec[t.c * 2 * NL + NL + k]; }
+    int32_t* mine = &own[t.slot][0];
+#pragma unroll 1
+    for (uint32_t L = 1; L < (uint32_t)LINES; L++) {
+        if (line_is_tangent(L)) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NL; k++) { mine[t.c * 2 * NL + k] = fre[k]; mine[t.c * 2 * NL + NL + k] = fim[k]; }
+            __syncthreads();
+            mul_dense(fre, fim, t, LdsRec{mine});
+        }
+        mul_dense(fre, fim, t, GlobalRec{rec + (size_t)L * DENSE_DW});
+    }
+    if (valid) {
+        const uint32_t flat = (t.c & 1u) ? 3u + (t.c >> 1) : (t.c >> 1);       // w-powers 0,2,4,1,3,5 in the flat order
+        uint32_t* o = partials + (size_t)g * pstride + flat * 24u;
+        fe a, b;
+#pragma unroll
+        for (int k = 0; k < NL; k++) { a.v[k] = fre[k]; b.v[k] = fim[k]; }
+        uint32_t w[12];
+        r28::to_vm(w, a);
+#pragma unroll
+        for (int k = 0; k < 12; k++) o[k] = w[k];
+        r28::to_vm(w, b);
+#pragma unroll
+        for (int k = 0; k < 12; k++) o[12 + k] = w[k];
+    }
+}
+}  // namespace ml
+
+// The listed pairs through the reference-faithful program: extra[e] = fq_miller_loop of pair dg.blocks[e] (144 words).
+__global__ void __launch_bounds__(64) k_ml_slow_pairs(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+                                                      DegenList dg, uint32_t* __restrict__ extra) {
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
+    if (blockIdx.x >= total) return;
+    team_init_consts(T, team, lane);
+    for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
+        const uint32_t pair = __builtin_amdgcn_readfirstlane(dg.blocks[e]);
+        wave_fence();
+        miller_exact_one(T, team, lane, g1, g2, dg.inf, pair);
+        for (uint32_t i = lane; i < 144; i += 64) extra[(size_t)e * 144 + i] = team[F_DW + i];
+    }
+}
+// Team g multiplies the extras of its group's pairs into the group's partial (pstride words apart).
+__global__ void __launch_bounds__(64) k_ml_fold_extras(VmTables T, DegenList dg, const uint32_t* __restrict__ extra, uint32_t gsz,
+                                                       uint32_t* __restrict__ partials, uint32_t pstride) {
+    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
+    if (total == 0) return;
+    const uint32_t g = blockIdx.x;
+    team_init_consts(T, team, lane);
+    uint32_t* part = partials + (size_t)g * pstride;
+    for (uint32_t i = lane; i < 144; i += 64) team[F_DW + i] = part[i];
+    bool touched = false;
+    for (uint32_t e = 0; e < total; e++) {
+        const uint32_t pair = __builtin_amdgcn_readfirstlane(dg.blocks[e]);
+        if (pair / gsz != g) continue;
+        wave_fence();
+        for (uint32_t i = lane; i < 144; i += 64) team[R1_DW + i] = extra[(size_t)e * 144 + i];
+        wave_fence();
+        run_rounds<true>(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, 0, lane);
+        touched = true;
+    }
+    if (touched) {
+        wave_fence();
+        for (uint32_t i = lane; i < 144; i += 64) part[i] = team[F_DW + i];
+    }
+}
+}  // namespace blsgpu

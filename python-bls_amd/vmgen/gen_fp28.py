@@ -125,7 +125,7 @@ def generate(path=None):
            "// Carry-free Montgomery sums of products on 14 signed 28-bit limbs, R = 2^392 (gfx950 device code only).\n"
            "// Column bound (checked by the callers' types, csrc/fp28.h): 14 * sum_t |a_t limb| |b_t limb| + 14 * 2^56 < 2^63.\n",
            "namespace bls28 {\n"]
-    for K in (1, 2, 3, 4):
+    for K in (1, 2, 3, 4, 6):
         out.append(gen_dot(K))
     for K in (1, 2):
         out.append(gen_sqr(K))
@@ -136,6 +136,7 @@ def generate(path=None):
     out.append(arr("BLS28_R2", R * R % Q, "R^2 mod q: content c (an integer < 2^391) times this is c R"))
     out.append(arr("BLS28_FROM_VM", (1 << 400) % Q, "2^400 mod q: a value of the wavefront VM (x 2^384, 12 x 32 bits) times this is x R"))
     out.append(arr("BLS28_TO_VM", (1 << 384) % Q, "2^384 mod q: x R times this is x 2^384, the VM's Montgomery form"))
+    out.append("// 2^384 mod q as 12 x 32-bit words: the VM's Montgomery form of 1\n#define BLS28_VM_ONE_WORDS {%s}\n" % ", ".join("0x%08xu" % ((((1 << 384) % Q) >> (32 * i)) & 0xFFFFFFFF) for i in range(12)))
     out.append("}  // namespace bls28\n")
     if path is None:
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc", "fp28_mul_gfx950.h")
