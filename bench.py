@@ -55,6 +55,10 @@ MAC_PER_FINAL_EXP = 9500 * MAC_PER_FQ_MUL
 HBM_BYTES_PER_PAIRING = 288
 PEAK_TMACS = 34.65        # measured v_mad_u64_u32 rate, profiles/r01_intrate_microbench.txt
 PEAK_HBM_GBS = 8000.0
+# line-stream Miller stage (csrc/blsgpu_ml.hip): 68 line records of 336 bytes per pair, written once and read once
+LS_LINES = 68
+LS_LINE_BYTES_PER_PAIRING = LS_LINES * 336
+PEAK_MAD28_T = 34.1       # measured v_mad_i64_i32 rate, profiles/r03_fp28_microbench.txt
 N_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 
 
@@ -95,25 +99,38 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def pmc_traffic(kernel, pairings_per_launch):
-    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc passes
-    (FETCH_SIZE + WRITE_SIZE, KB per dispatch; profiles/r0N_bench_pmc_summary.csv, collected by
-    tools/profile_round.sh on this same workload).  Counters cannot be read inside this process,
-    so the figure is only reported for the profiled shape (32 800 pairings per k_miller_mp launch);
-    FETCH_SIZE is left uncorrected (dword table loads are outside the guide's x2 calibration)."""
-    for name in ("r02_bench_pmc_summary.csv", "r01_bench_pmc_summary.csv"):
-        path = os.path.join(ROOT, "profiles", name)
-        if kernel != "k_miller_mp" or pairings_per_launch != 32800 or not os.path.exists(path):
-            continue
-        kb = {}
-        with open(path) as f:
-            for row in f:
-                c = row.strip().split(",")
-                if len(c) == 4 and c[0].split("::")[-1].split("<")[0] == kernel and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-                    kb[c[1]] = float(c[3])
-        if len(kb) == 2:
-            return int((kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), "profiles/" + name
-    return None, None
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources the loaded library was built from"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "python-bls_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernels, pairings_per_launch):
+    """HBM bytes per launch of the Miller-stage kernels from the COMMITTED rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE, KB per dispatch, separate passes; tools/ml_pmc.sh on this same workload).  Counters cannot be read
+    inside this process, so the figure is reported only when the summary's header names THIS build (source hash) and
+    this launch size; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads."""
+    path = os.path.join(ROOT, "profiles", "r03_ls_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None, None
+    kb, ok = {}, False
+    with open(path) as f:
+        for row in f:
+            if row.startswith("#"):
+                ok = ("build " + source_hash()) in row and ("pairs %d" % pairings_per_launch) in row
+                continue
+            c = row.strip().split(",")
+            if len(c) == 4 and c[0].split("::")[-1] in kernels and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                kb[(c[0].split("::")[-1], c[1])] = float(c[3])
+    if not ok or not kb:
+        return None, None
+    total = sum(v * (2 if k[1] == "FETCH_SIZE" else 1) for k, v in kb.items()) * 1024
+    return int(total), "profiles/r03_ls_pmc_summary.csv"
 
 
 def cpu_model():
@@ -338,18 +355,24 @@ def run_pairing(env, args):
     # exponentiations.  Miller launches of consecutive steps are serialised with an event (they would
     # only stretch each other), so the final exponentiations of step i (B wavefronts, latency bound)
     # overlap the Miller loops of step i + 1.
+    # The order is kept with the engine's "bulk" event (blsgpu_ctx_set_bulk_event): recorded right after the last
+    # chip-filling kernel of the stage, so the few dozen wavefronts of Horner / products / final exponentiations of
+    # step i run beside the point chains of step i + 1.
+    bulk = [torch.cuda.Event() for _ in range(S)]
+    for k in range(S):
+        bulk[k].record(streams[k])                   # creates the HIP event behind the torch object
+        engs[k].set_bulk_event(bulk[k].cuda_event)
+    torch.cuda.synchronize()
     miller_done = [None]
 
     def step(i):
         k = i % S
         stream = streams[k]
         st = stream.cuda_stream
-        if miller_done[0] is not None:
+        if miller_done[0] is not None and not args.free_streams:
             stream.wait_event(miller_done[0])
         shard[k].miller_partials_batch_dev(t1, t2, n, B, parts[k], st)
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        miller_done[0] = ev
+        miller_done[0] = bulk[k]
         if env.dist is None:
             shard[k].final_batch_dev(parts[k], 1, B, outs[k], st)
         else:
@@ -368,7 +391,18 @@ def run_pairing(env, args):
     reduce_ms = [ms for k, ms in ktimes if k == 1]
     fexp_ms = [ms for k, ms in ktimes if k == 2]
     slow_ms = [ms for k, ms in ktimes if k == 3]
-    miller_avg = sum(miller_ms) / len(miller_ms)
+    # line-stream Miller stage (csrc/blsgpu_ml.hip): kinds 4 k_ml_lines, 5 k_ml_accum, 6 k_ml_merge, 7 k_ml_horner;
+    # one k_ml_lines launch per step
+    ls = {name: [ms for k, ms in ktimes if k == kind] for kind, name in
+          ((4, "k_ml_lines"), (5, "k_ml_accum"), (6, "k_ml_merge"), (7, "k_ml_horner"))}
+    line_stream = bool(ls["k_ml_lines"])
+    if line_stream:
+        launches = len(ls["k_ml_lines"])
+        ls_avg = {name: sum(v) / launches for name, v in ls.items()}
+        miller_avg = sum(ls_avg.values())
+    else:
+        launches = len(miller_ms)
+        miller_avg = sum(miller_ms) / len(miller_ms)
     # every rank's sums of a_i b_i per verification and its kernel time go to rank 0
     sums = [sum(x * y for x, y in zip(a[v * n:(v + 1) * n], b[v * n:(v + 1) * n])) % N_ORDER for v in range(B)]
     info = env.gather_objects({"rank": rank, "sums": sums, "k_miller_ms_avg": miller_avg, "pairs": n * B,
@@ -406,8 +440,13 @@ def run_pairing(env, args):
         # dominant kernel = the Miller kernel (all the per-pairing work): algorithmic MACs of one launch
         # over its average duration in the timed region (launches do not overlap each other, see step())
         ach = MAC_PER_PAIRING * n * B / (miller_avg * 1e-3) / 1e12
-        kname = "k_miller_mp" if n * B >= 2048 else "k_miller"
-        traffic, traffic_src = pmc_traffic(kname, n * B)
+        if line_stream:
+            kname = "k_ml_lines+k_ml_accum+k_ml_merge+k_ml_horner"
+            alg_bytes = (HBM_BYTES_PER_PAIRING + 2 * LS_LINE_BYTES_PER_PAIRING) * n * B
+        else:
+            kname = "k_miller_mp" if n * B >= 2048 else "k_miller"
+            alg_bytes = HBM_BYTES_PER_PAIRING * n * B + 576 * ((n + 2) // 3) * B
+        traffic, traffic_src = pmc_traffic(kname.split("+"), n * B)
         if c3:
             workload = ("ONE multi-pairing of %d pairs sharded over %d GPU(s) (%d pairs per GPU), one final exponentiation "
                         "(BASELINE configs[2])" % (args.pairs_total, world, n))
@@ -428,20 +467,28 @@ def run_pairing(env, args):
             "roofline": {"bound": "valu-int32-mac", "achieved": ach, "peak": PEAK_TMACS, "unit": "TMAC/s",
                          "frac": ach / PEAK_TMACS, "traffic": traffic,
                          "traffic_unit": "bytes per launch, offline rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (%s)" % traffic_src,
-                         "algorithmic_bytes_per_launch": (HBM_BYTES_PER_PAIRING * n * B + 576 * ((n + 2) // 3) * B),
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel": kname,
-                         "kernel_launches_timed": len(miller_ms), "kernel_ms_avg": miller_avg,
+                         "kernel_launches_timed": launches, "kernel_ms_avg": miller_avg,
                          "pairings_per_launch": n * B, "mac_per_pairing": MAC_PER_PAIRING,
-                         "reduce_kernels_ms_per_step": sum(reduce_ms) / max(1, len(miller_ms)),
-                         "degenerate_pair_kernel_ms_per_step": sum(slow_ms) / max(1, len(miller_ms)),
+                         "reduce_kernels_ms_per_step": sum(reduce_ms) / max(1, launches),
+                         "degenerate_pair_kernel_ms_per_step": sum(slow_ms) / max(1, launches),
                          "final_exp_kernel_ms_avg": (sum(fexp_ms) / len(fexp_ms)) if fexp_ms else None,
                          "whole_step_TMACs": (MAC_PER_PAIRING * n + MAC_PER_FINAL_EXP) * B * world / (dt / args.steps) / 1e12,
                          "step_latency_ms_avg": sum(step_ms) / len(step_ms), "step_latency_ms_min": step_ms[0],
-                         "hbm_GBps_algorithmic": HBM_BYTES_PER_PAIRING * n * B / (miller_avg * 1e-3) / 1e9,
+                         "hbm_GBps_algorithmic": alg_bytes / (miller_avg * 1e-3) / 1e9,
                          "hbm_peak_GBps": PEAK_HBM_GBS},
             "per_rank": [{"rank": i["rank"], "device": i["device"], "k_miller_ms_avg": i["k_miller_ms_avg"]} for i in info],
             "single_call_latency": lat,
         }
+        if line_stream:
+            # the stage's kernels one by one; k_ml_accum also by the multiply-accumulates it EXECUTES (2 x 7 x 196
+            # v_mad_i64_i32 per line product per lane, six lanes; 68 lines per pair) against the measured rate of that
+            # instruction (profiles/r03_fp28_microbench.txt: 34.1 T/s at four wavefronts per SIMD)
+            exec_mads = 2 * 7 * 196 * 6 * LS_LINES * n * B
+            line["roofline"]["stage_kernels_ms_avg"] = ls_avg
+            line["roofline"]["k_ml_accum_executed_mad28_Tps"] = exec_mads / (ls_avg["k_ml_accum"] * 1e-3) / 1e12
+            line["roofline"]["k_ml_accum_frac_of_mad_i64_i32_peak"] = exec_mads / (ls_avg["k_ml_accum"] * 1e-3) / 1e12 / PEAK_MAD28_T
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(g1[:96 * min(n, 1025)], g2[:192 * min(n, 1025)], min(n, 1025), per[0] if n == 1025 else None)
             if not cb["matches_gpu"]:
@@ -709,6 +756,8 @@ def main():
                     help="gloo: CPU-side collective, for rehearsing the multi-rank path on one GPU")
     ap.add_argument("--force-process-group", action="store_true",
                     help="form the process group and run the all-gather even with one rank (RCCL rehearsal on a one-GPU box)")
+    ap.add_argument("--free-streams", action="store_true",
+                    help="do not order the Miller stages of consecutive steps (default: step i + 1's starts after step i's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="c2: skip the c3 / c4 / c5 / h2c runs after the timed region")

@@ -84,6 +84,15 @@ int blsgpu_ctx_set_mp3_threshold(blsgpu_ctx *ctx, size_t pairs);
  * fq_miller_loop, fields_t.py:1091-1111, cut where the data dependency allows.  Default 16384 / 64; (size_t)-1
  * keeps every call on the wavefront-VM kernels.  Results are identical either way. */
 int blsgpu_ctx_set_ls_threshold(blsgpu_ctx *ctx, size_t pairs, size_t min_group);
+/* Number of accumulators the line-stream product kernel aims at (default 163840): a group's pairs are cut into equal
+ * chunks of at least 16 pairs, one accumulator per (chunk, line index); the chunks' products are merged by a tree of
+ * dense products.  A tuning knob; results are identical for every value. */
+int blsgpu_ctx_set_ls_teams(blsgpu_ctx *ctx, size_t teams);
+/* `event` (a hipEvent_t, or NULL for none) is recorded on the call's stream right after the last kernel of a Miller
+ * stage that fills the chip; what follows (Horner over the line products, the product of the partials, the final
+ * exponentiation) occupies a few dozen wavefronts.  A caller that pipelines calls over several contexts lets the
+ * next call's stream wait for this event instead of the end of the call (bench.py does). */
+int blsgpu_ctx_set_bulk_event(blsgpu_ctx *ctx, void *event);
 
 /* fq_ate_pairing_multi(Ps, Qs) -- fields_t.py:1114-1121 / fields_t_c.pyx:2333-2391.
  * Host buffers in, 576 result bytes out; synchronous.  n == 0 returns one. */

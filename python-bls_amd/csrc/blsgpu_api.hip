@@ -66,7 +66,7 @@ struct blsgpu_ctx {
     // ls_min_group pairs
     size_t ls_threshold = 16384;
     size_t ls_min_group = 64;
-    size_t ls_teams = 40960;           // accumulators k_ml_accum aims at (10 per wavefront)
+    size_t ls_teams = 163840;          // accumulators k_ml_accum aims at (10 per wavefront: 8 wavefronts per place at two per SIMD)
     void* d_lines = nullptr;           // 68 x pairs line records
     size_t lines_cap = 0;              // bytes
     void* d_lsp[2] = {nullptr, nullptr};   // dense partial products (ping-pong over the merge levels)
@@ -75,6 +75,8 @@ struct blsgpu_ctx {
     size_t bad_cap = 0;
     void* d_extra = nullptr;           // Miller values of the listed pairs (VM form)
     size_t extra_cap = 0;
+    int ls_lines_form = 2;             // 2: the point chains on lane pairs (k_ml_lines2); 1: one pair per lane (k_ml_lines)
+    hipEvent_t bulk_event = nullptr;   // caller's event, recorded after the last chip-filling kernel of a Miller stage
     size_t msm_part_cap = 0;           // in u32
     // optional per-kernel timing (blsgpu_timing_enable): HIP events recorded on
     // the launch stream around every kernel, ring of TIMING_SLOTS launches
@@ -474,6 +476,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_LS_THRESHOLD")) c->ls_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_MIN_GROUP")) c->ls_min_group = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_TEAMS")) c->ls_teams = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_LS_LINES_FORM")) c->ls_lines_form = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -641,6 +644,21 @@ BLSGPU_EXPORT int blsgpu_ctx_set_ls_threshold(blsgpu_ctx* c, size_t pairs, size_
     c->ls_min_group = min_group ? min_group : 1;
     return 0;
 }
+// The caller's event (or NULL: none) is recorded on the call's stream right after the last kernel of a Miller stage that
+// fills the chip; what follows (Horner, the product of the partials, the final exponentiation) occupies a few dozen
+// wavefronts.  A server that pipelines calls over several contexts lets the next call's stream wait for this event
+// instead of the end of the call.
+BLSGPU_EXPORT int blsgpu_ctx_set_bulk_event(blsgpu_ctx* c, void* event) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    c->bulk_event = (hipEvent_t)event;
+    return 0;
+}
+// accumulators (six lanes each) the line-stream product kernel aims at; decides the chunk of pairs per accumulator
+BLSGPU_EXPORT int blsgpu_ctx_set_ls_teams(blsgpu_ctx* c, size_t teams) {
+    if (!c || teams == 0) return fail(-EINVAL, "bad argument");
+    c->ls_teams = teams;
+    return 0;
+}
 BLSGPU_EXPORT int blsgpu_ctx_set_mp3_threshold(blsgpu_ctx* c, size_t pairs) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
     c->mp3_threshold = pairs;
@@ -728,6 +746,7 @@ static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, cons
                            (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, d_partials, dg);
     }
     HIP_TRY(hipGetLastError());
+    if (c->bulk_event) HIP_TRY(hipEventRecord(c->bulk_event, st));
     {
         KernelTimer kt(c, st, 3);
         hipLaunchKernelGGL(blsgpu::k_miller_slow, dim3(SLOW_GRID), dim3(64), (size_t)blsgpu::SLOW_TEAM_BYTES, st, c->tabs,
@@ -745,11 +764,15 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
                             uint32_t* d_partials, hipStream_t st) {
     using namespace blsgpu;
     const size_t n = gsz * groups;
-    // chunk: pairs per accumulator, so that about ls_teams accumulators exist (never fewer than 8 pairs each)
-    size_t chunk = (n * ml::LINES + c->ls_teams - 1) / c->ls_teams;
-    if (chunk < 8) chunk = 8;
-    if (chunk > gsz) chunk = gsz;
-    size_t cpg = (gsz + chunk - 1) / chunk;
+    // chunks: equal runs of a group's pairs, one accumulator each per line index, sized so that about ls_teams
+    // accumulators exist (a wavefront of ten then runs a few hundred products: many short wavefronts per SIMD, so the
+    // last round of the launch costs little) but never fewer than 16 pairs (the merge is a dense product per chunk)
+    size_t want = (n * ml::LINES + c->ls_teams - 1) / c->ls_teams;
+    if (want < 16) want = 16;
+    if (want > gsz) want = gsz;
+    size_t cpg = (gsz + want - 1) / want;
+    const size_t chunk = (gsz + cpg - 1) / cpg;
+    cpg = (gsz + chunk - 1) / chunk;
     constexpr size_t FAN = 8;
     if (int rc = grow_buffer(c, &c->d_lines, &c->lines_cap, n * ml::LINES * ml::LINE_DW * 4)) return rc;
     if (int rc = grow_buffer(c, &c->d_lsp[0], &c->lsp_cap[0], groups * cpg * ml::LINES * ml::DENSE_DW * 4)) return rc;
@@ -761,8 +784,12 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     HIP_TRY(hipMemsetAsync(c->d_degen, 0, sizeof(uint32_t), st));
     {
         KernelTimer kt(c, st, 4);
-        hipLaunchKernelGGL(ml::k_ml_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1, (const uint32_t*)d_g2,
-                           (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
+        if (c->ls_lines_form == 1)
+            hipLaunchKernelGGL(ml::k_ml_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1, (const uint32_t*)d_g2,
+                               (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
+        else
+            hipLaunchKernelGGL(ml::k_ml_lines2, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1,
+                               (const uint32_t*)d_g2, (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
     }
     HIP_TRY(hipGetLastError());
     {
@@ -790,6 +817,7 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
         cpg = cpo;
         cur ^= 1;
     }
+    if (c->bulk_event) HIP_TRY(hipEventRecord(c->bulk_event, st));
     {
         KernelTimer kt(c, st, 7);
         hipLaunchKernelGGL(ml::k_ml_horner, dim3((unsigned)((groups + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur],

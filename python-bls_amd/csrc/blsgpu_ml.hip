@@ -143,6 +143,226 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_LINES_WAVES) k_ml_lines(const ui
     }
 }
 
+// ---- stage A on LANE PAIRS: an Fq2 value split over two adjacent lanes ---------------------------------------------
+// The even lane holds the real part, the odd lane the imaginary part; the partner's part is one DPP move per limb away
+// (quad_perm 1,0,3,2).  Half the registers and half the code per lane (two wavefronts per SIMD, the step stays in the
+// instruction cache) for about 12 % more instructions than one pair per lane.
+namespace sp {
+template <int M> struct S { int32_t v[NL]; };          // the lane's part; limbs in (-M 2^28, M 2^28)
+typedef S<1> h;
+__device__ __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
+template <int M> __device__ __forceinline__ S<M> swp(const S<M>& x) {
+    S<M> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = __builtin_amdgcn_update_dpp(0, x.v[j], 0xB1, 0xF, 0xF, true);
+    return r;
+}
+template <int A, int B> __device__ __forceinline__ S<A + B> add(const S<A>& x, const S<B>& y) { S<A + B> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = x.v[j] + y.v[j];
+    return r; }
+template <int A, int B> __device__ __forceinline__ S<A + B> sub(const S<A>& x, const S<B>& y) { S<A + B> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = x.v[j] - y.v[j];
+    return r; }
+template <int A> __device__ __forceinline__ S<A> neg(const S<A>& x) { S<A> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = -x.v[j];
+    return r; }
+template <int C, int A> __device__ __forceinline__ S<C * A> mulc(const S<A>& x) { S<C * A> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = x.v[j] * C;
+    return r; }
+template <int A> __device__ __forceinline__ h norm(const S<A>& x) {
+    static_assert(A <= 8, "limb range leaves int32");
+    h r;
+    int32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < NL - 1; j++) { const int32_t t = x.v[j] + c; r.v[j] = t & r28::LMASK; c = t >> r28::LW; }
+    r.v[NL - 1] = x.v[NL - 1] + c;
+    return r;
+}
+template <int C, int A> __device__ __forceinline__ h mulc_norm(const S<A>& x) {
+    static_assert(C > 0 && C < (1 << 20) && A <= 8, "constant too large");
+    h r;
+    int64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < NL - 1; j++) { c += (int64_t)x.v[j] * C; r.v[j] = (int32_t)((uint32_t)c & (uint32_t)r28::LMASK); c >>= r28::LW; }
+    r.v[NL - 1] = (int32_t)(c + (int64_t)x.v[NL - 1] * C);
+    return r;
+}
+// (1 + u) x: re = a - b, im = a + b
+template <int A> __device__ __forceinline__ S<2 * A> mul_xi(const S<A>& x) {
+    const S<A> p = swp(x);
+    S<2 * A> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = odd() ? x.v[j] + p.v[j] : x.v[j] - p.v[j];
+    return r;
+}
+template <int A> __device__ __forceinline__ h b3(const S<A>& x) { return mulc_norm<12>(mul_xi(x)); }      // 12 (1 + u) x
+// operands of a product x y: re = x.re y.re - x.im y.im, im = x.re y.im + x.im y.re.  With o = own part, p = partner's:
+// even lane  o_x o_y + (-p_x) p_y,  odd lane  p_x o_y + o_x p_y  -- both lanes  a o_y + b p_y.
+template <int M> struct Lop { int32_t a[NL], b[NL]; };
+template <int M> struct Rop { int32_t o[NL], p[NL]; };
+template <int M> __device__ __forceinline__ Lop<M> left(const S<M>& x) {
+    const S<M> p = swp(x);
+    Lop<M> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) { r.a[j] = odd() ? p.v[j] : x.v[j]; r.b[j] = odd() ? x.v[j] : -p.v[j]; }
+    return r;
+}
+template <int M> __device__ __forceinline__ Rop<M> right(const S<M>& x) {
+    const S<M> p = swp(x);
+    Rop<M> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) { r.o[j] = x.v[j]; r.p[j] = p.v[j]; }
+    return r;
+}
+// column bound of fp28.h: 14 * (sum of |a||b| in units of 2^56) + 14 <= 126
+template <int MA, int MB> __device__ __forceinline__ h mul(const Lop<MA>& x, const Rop<MB>& y) {
+    static_assert(2 * MA * MB <= 8, "a column of this product may overflow 64 bits");
+    h r;
+    bls28::fp28_dot2(r.v, x.a, y.o, x.b, y.p);
+    return r;
+}
+template <int MA, int MB, int MC, int MD>
+__device__ __forceinline__ h dot2(const Lop<MA>& x0, const Rop<MB>& y0, const Lop<MC>& x1, const Rop<MD>& y1) {
+    static_assert(2 * MA * MB + 2 * MC * MD <= 8, "a column of this sum of products may overflow 64 bits");
+    h r;
+    bls28::fp28_dot4(r.v, x0.a, y0.o, x0.b, y0.p, x1.a, y1.o, x1.b, y1.p);
+    return r;
+}
+// x^2: re = (a + b)(a - b), im = (2 b) a
+__device__ __forceinline__ h sqr(const h& x) {
+    const h p = swp(x);
+    int32_t u[NL], w[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) { u[j] = x.v[j] + (odd() ? x.v[j] : p.v[j]); w[j] = odd() ? p.v[j] : x.v[j] - p.v[j]; }
+    h r;
+    bls28::fp28_dot1(r.v, u, w);                                       // |u|, |w| < 2^29: 4 units
+    return r;
+}
+template <int M> __device__ __forceinline__ h mulf(const S<M>& x, const fe& k) {     // by an Fq value (both lanes hold it)
+    static_assert(M <= 8, "");
+    h r;
+    bls28::fp28_dot1(r.v, x.v, k.v);
+    return r;
+}
+__device__ __forceinline__ h load_part(const uint32_t* __restrict__ src) {       // the lane's 48 bytes -> x R
+    const fe t = load_coord(src);
+    h r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = t.v[j];
+    return r;
+}
+// zero mod q in BOTH lanes of the pair (value in (-q, 2q), normalised digits)
+__device__ __forceinline__ bool is_zero2(const h& x) {
+    fe t;
+#pragma unroll
+    for (int j = 0; j < NL; j++) t.v[j] = x.v[j];
+    const int z = r28::is_zero(t) ? 1 : 0;
+    return (z & __builtin_amdgcn_update_dpp(0, z, 0xB1, 0xF, 0xF, true)) != 0;
+}
+template <int M> __device__ __forceinline__ void store_part(int32_t* __restrict__ rec, int coef, const S<M>& x) {
+    int32_t* o = rec + (coef * 2 + (odd() ? 1 : 0)) * NL;
+#pragma unroll
+    for (int j = 0; j < NL; j++) o[j] = x.v[j];
+}
+
+__device__ __forceinline__ void tangent_step(h& X, h& Y, h& Z, const fe& px3n, const fe& py2, int32_t* __restrict__ rec) {
+    const Lop<1> lx = left(X), ly = left(Y);
+    const Rop<1> ry = right(Y), rz = right(Z);
+    const h A = mul(lx, ry), YZ = mul(ly, rz);
+    const h B = sqr(Y), C = sqr(Z), XX = sqr(X);
+    const h E = b3(C);
+    const S<3> F3 = mulc<3>(E);
+    const h BmF = norm(sub(B, F3)), G = norm(add(B, F3));
+    const h nE12 = mulc_norm<12>(neg(E));
+    store_part(rec, 0, sub(B, E));
+    store_part(rec, 1, mulf(XX, px3n));
+    store_part(rec, 2, mulf(YZ, py2));
+    X = mul(left(add(A, A)), right(BmF));
+    Y = dot2(left(G), right(G), left(nE12), right(E));
+    Z = mul(left(B), right(mulc_norm<8>(YZ)));
+}
+__device__ __forceinline__ void chord_step(h& X, h& Y, h& Z, const h& xq, const h& yq, const fe& px3n, const fe& py3,
+                                           int32_t* __restrict__ rec) {
+    const Rop<1> rz = right(Z);
+    const h th = norm(sub(Y, mul(left(yq), rz))), la = norm(sub(X, mul(left(xq), rz)));
+    const Lop<1> lth = left(th), lla = left(la);
+    const h C = sqr(th), D = sqr(la);
+    const Rop<1> rd = right(D);
+    const h E = mul(lla, rd), Fz = mul(left(Z), right(C)), Gg = mul(left(X), rd);
+    const h H = norm(sub(add(E, Fz), add(Gg, Gg)));
+    const h GH = norm(sub(Gg, H));
+    const h xq3 = mulc_norm<3>(xq), nyq3 = mulc_norm<3>(neg(yq));
+    store_part(rec, 0, dot2(lth, right(xq3), lla, right(nyq3)));
+    store_part(rec, 1, mulf(th, px3n));
+    store_part(rec, 2, mulf(la, py3));
+    const h nE = norm(neg(E));
+    const h Y3 = dot2(lth, right(GH), left(nE), right(Y));
+    X = mul(lla, right(H));
+    Z = mul(left(Z), right(E));
+    Y = Y3;
+}
+}  // namespace sp
+
+// Two lanes per pair (lane 2p: real parts, lane 2p + 1: imaginary parts).  Same lines, flags and work list as k_ml_lines.
+#ifndef BLSGPU_ML_LINES2_WAVES
+#define BLSGPU_ML_LINES2_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines2(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
+                                                                           int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg) {
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t pr = t >> 1;
+    const uint32_t p = pr < n ? pr : n - 1u;                      // the last wavefront's spare lanes repeat the last pair
+    const uint32_t part = t & 1u;
+    const uint32_t* s1 = g1 + (size_t)p * 24;
+    const uint32_t* s2 = g2 + (size_t)p * 48 + part * 12;
+    fe px3n, py2;
+    sp::h X, Y, Z;
+    bool ok = !q_flagged(dg, p);
+    {
+        const fe px = load_coord(s1), py = load_coord(s1 + 12);
+        px3n = r28::mulc_norm<3>(r28::neg(px));
+        py2 = r28::mulc_norm<2>(py);
+        X = sp::load_part(s2);
+        Y = sp::load_part(s2 + 24);
+        const int32_t one[NL] = BLS28_ONE;
+#pragma unroll
+        for (int j = 0; j < NL; j++) Z.v[j] = part ? 0 : one[j];
+        // Q on the twist: y^2 - x^3 - 4 (1 + u) = 0
+        const sp::h yy = sp::sqr(Y), xx = sp::sqr(X);
+        const sp::h xxx = sp::mul(sp::left(xx), sp::right(X));
+        sp::S<4> four;
+#pragma unroll
+        for (int j = 0; j < NL; j++) four.v[j] = 4 * one[j];
+        const auto d = sp::sub(sp::sub(yy, xxx), four);              // S<6>
+        ok = ok && sp::is_zero2(sp::mulf(d, r28::fe_one()));
+    }
+    int32_t* rec = lines + (size_t)p * LINE_DW;
+    const size_t lstride = (size_t)n * LINE_DW;
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; bit--) {
+        sp::tangent_step(X, Y, Z, px3n, py2, rec);
+        rec += lstride;
+        if ((ML_NX >> bit) & 1ull) {
+            const sp::h xq = sp::load_part(s2), yq = sp::load_part(s2 + 24);
+            const fe py3 = r28::mulc_norm<3>(load_coord(s1 + 12));
+            sp::chord_step(X, Y, Z, xq, yq, px3n, py3, rec);
+            rec += lstride;
+        }
+    }
+    ok = ok && !sp::is_zero2(Z);
+    if (part == 0 && pr < n) {
+        bad[p] = ok ? 0 : 1;
+        if (!ok) {
+            const uint32_t at = atomicAdd(dg.count, 1u);
+            dg.blocks[at] = p;
+        }
+    }
+}
+
 // ---- stages B / merge / Horner: six lanes per accumulator -----------------------------------------------------------
 struct Team {
     uint32_t c;            // the lane's coefficient: power of w
