@@ -460,7 +460,8 @@ def run_pairing(env, args):
             "metric": "BLS12-381 pairings/sec (aggregate_verify multi-pairing)",
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if c3 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "scaling": "strong" if c3 else "weak", "vs_baseline": None,
+            "dtype": "i32 limbs of 28 bits, i64 accumulators" if line_stream else "u32", "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "pairs_per_verification_per_gpu": n, "verifications_per_step": B,
                        "pairs_per_step_per_gpu": n * B, "parallelism": par, "steps_in_flight": S, "check": check,
                        "backend": env.backend if env.dist else "none", "ranks_in_process_group": len(info)},

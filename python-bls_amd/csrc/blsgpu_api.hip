@@ -64,7 +64,7 @@ struct blsgpu_ctx {
     uint32_t* d_msm_part = nullptr;    // MSM partials
     // line-stream multi-pairing (blsgpu_ml.hip): used from ls_threshold pairs per call when every group has at least
     // ls_min_group pairs
-    size_t ls_threshold = 16384;
+    size_t ls_threshold = 16384;       // measured crossover (tools/sweep_n.py): 12 288 pairs 3.9 vs 4.3 ms, 16 384 pairs 4.95 vs 4.5 ms
     size_t ls_min_group = 64;
     size_t ls_teams = 163840;          // accumulators k_ml_accum aims at (10 per wavefront: 8 wavefronts per place at two per SIMD)
     void* d_lines = nullptr;           // 68 x pairs line records
@@ -75,6 +75,7 @@ struct blsgpu_ctx {
     size_t bad_cap = 0;
     void* d_extra = nullptr;           // Miller values of the listed pairs (VM form)
     size_t extra_cap = 0;
+    int ls_horner_form = 2;            // 2: one group per wavefront, a product spread over 36 lanes; 1: ten groups per wavefront
     int ls_lines_form = 2;             // 2: the point chains on lane pairs (k_ml_lines2); 1: one pair per lane (k_ml_lines)
     hipEvent_t bulk_event = nullptr;   // caller's event, recorded after the last chip-filling kernel of a Miller stage
     size_t msm_part_cap = 0;           // in u32
@@ -477,6 +478,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_LS_MIN_GROUP")) c->ls_min_group = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_TEAMS")) c->ls_teams = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_LINES_FORM")) c->ls_lines_form = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("BLSGPU_LS_HORNER_FORM")) c->ls_horner_form = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -757,6 +759,7 @@ static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, cons
 }
 
 // The line-stream form of launch_miller (blsgpu_ml.hip): ONE partial per group comes out (bpg = 1).
+constexpr size_t LS_MAX_PAIRS = (size_t)1 << 20;       // pairs per launch sequence: 24 GB of line records
 static bool use_ls(const blsgpu_ctx* c, size_t gsz, size_t groups) {
     return gsz >= c->ls_min_group && gsz * groups >= c->ls_threshold && gsz * groups <= 0x3FFFFFF0ull;
 }
@@ -774,12 +777,14 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     const size_t chunk = (gsz + cpg - 1) / cpg;
     cpg = (gsz + chunk - 1) / chunk;
     constexpr size_t FAN = 8;
-    if (int rc = grow_buffer(c, &c->d_lines, &c->lines_cap, n * ml::LINES * ml::LINE_DW * 4)) return rc;
-    if (int rc = grow_buffer(c, &c->d_lsp[0], &c->lsp_cap[0], groups * cpg * ml::LINES * ml::DENSE_DW * 4)) return rc;
-    if (int rc = grow_buffer(c, &c->d_lsp[1], &c->lsp_cap[1], groups * ((cpg + FAN - 1) / FAN) * ml::LINES * ml::DENSE_DW * 4)) return rc;
-    if (int rc = grow_buffer(c, &c->d_bad, &c->bad_cap, n)) return rc;
-    if (int rc = grow_buffer(c, &c->d_extra, &c->extra_cap, n * 576)) return rc;
-    if (int rc = grow_elems(c, &c->d_degen, &c->degen_cap, n + 2)) return rc;
+    if (grow_buffer(c, &c->d_lines, &c->lines_cap, n * ml::LINES * ml::LINE_DW * 4) ||
+        grow_buffer(c, &c->d_lsp[0], &c->lsp_cap[0], groups * cpg * ml::LINES * ml::DENSE_DW * 4) ||
+        grow_buffer(c, &c->d_lsp[1], &c->lsp_cap[1], groups * ((cpg + FAN - 1) / FAN) * ml::LINES * ml::DENSE_DW * 4) ||
+        grow_buffer(c, &c->d_bad, &c->bad_cap, n) || grow_buffer(c, &c->d_extra, &c->extra_cap, n * 576) ||
+        grow_elems(c, &c->d_degen, &c->degen_cap, n + 2)) {
+        (void)hipGetLastError();
+        return -ENOMEM;                                    // the caller falls back to the wavefront-VM kernels
+    }
     DegenList dg{c->d_degen, c->d_degen + 1, (const uint8_t*)d_inf};
     HIP_TRY(hipMemsetAsync(c->d_degen, 0, sizeof(uint32_t), st));
     {
@@ -820,8 +825,12 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     if (c->bulk_event) HIP_TRY(hipEventRecord(c->bulk_event, st));
     {
         KernelTimer kt(c, st, 7);
-        hipLaunchKernelGGL(ml::k_ml_horner, dim3((unsigned)((groups + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur],
-                           (uint32_t)groups, d_partials, 144u);
+        if (c->ls_horner_form == 1)
+            hipLaunchKernelGGL(ml::k_ml_horner, dim3((unsigned)((groups + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st,
+                               (const int32_t*)c->d_lsp[cur], (uint32_t)groups, d_partials, 144u);
+        else
+            hipLaunchKernelGGL(ml::k_ml_horner_wide, dim3((unsigned)groups), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur],
+                               (uint32_t)groups, d_partials, 144u);
     }
     HIP_TRY(hipGetLastError());
     {
@@ -854,10 +863,37 @@ static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, co
         if (rc) return rc;
     }
     size_t bpg = 0;
+    bool ls_done = false;
     if (gsz > 0 && use_ls(c, gsz, groups)) {
-        int rc = launch_miller_ls(c, d_g1, d_g2, d_inf, gsz, groups, c->d_part[0], st);
-        if (rc) return rc;
-        bpg = 1;
+        // The line records are 22.8 KB per pair: a call is cut into slices of at most LS_MAX_PAIRS pairs -- whole groups,
+        // or, for ONE long group, runs of its pairs that each leave a partial for the product below.
+        int rc = 0;
+        if (gsz * groups <= LS_MAX_PAIRS) {
+            rc = launch_miller_ls(c, d_g1, d_g2, d_inf, gsz, groups, c->d_part[0], st);
+            bpg = 1;
+        } else if (gsz <= LS_MAX_PAIRS) {
+            const size_t per = LS_MAX_PAIRS / gsz;
+            for (size_t g0 = 0; g0 < groups && !rc; g0 += per) {
+                const size_t gn = groups - g0 < per ? groups - g0 : per;
+                rc = launch_miller_ls(c, (const char*)d_g1 + g0 * gsz * BLSGPU_G1_BYTES, (const char*)d_g2 + g0 * gsz * BLSGPU_G2_BYTES,
+                                      d_inf ? (const char*)d_inf + g0 * gsz * 2 : nullptr, gsz, gn, c->d_part[0] + g0 * 144, st);
+            }
+            bpg = 1;
+        } else if (groups == 1) {
+            size_t k = 0;
+            for (size_t p0 = 0; p0 < gsz && !rc; p0 += LS_MAX_PAIRS, k++) {
+                const size_t pn = gsz - p0 < LS_MAX_PAIRS ? gsz - p0 : LS_MAX_PAIRS;
+                rc = launch_miller_ls(c, (const char*)d_g1 + p0 * BLSGPU_G1_BYTES, (const char*)d_g2 + p0 * BLSGPU_G2_BYTES,
+                                      d_inf ? (const char*)d_inf + p0 * 2 : nullptr, pn, 1, c->d_part[0] + k * 144, st);
+            }
+            bpg = k;
+        } else {
+            rc = -ENOMEM;                                  // several groups of more than LS_MAX_PAIRS pairs: the VM kernels
+        }
+        if (rc == 0) ls_done = true;
+        else if (rc != -ENOMEM) return rc;                 // no memory for the line records: the wavefront-VM kernels instead
+    }
+    if (ls_done) {
     } else if (gsz > 0) {
         int rc = launch_miller(c, d_g1, d_g2, d_inf, gsz, groups, false, c->d_part[0], st, &bpg);
         if (rc) return rc;

@@ -603,6 +603,86 @@ __global__ void __launch_bounds__(64, 2) k_ml_horner(const int32_t* __restrict__
         for (int k = 0; k < 12; k++) o[12 + k] = w[k];
     }
 }
+
+// The same chain with ONE GROUP PER WAVEFRONT and the six terms of every coefficient on six different lanes: lane
+// (t, k) = 6 t + k computes the one Fq2 product F_{k-t} g_t (two sums of two products), the six products of a coefficient
+// are added across the lanes (ds_bpermute) and every lane ends up with f_k.  A dense product is then ~1.6 k
+// instructions deep instead of ~6.8 k: the chain of 62 squarings and 67 products is what a single long multi-pairing
+// waits for (2.15 -> 0.5 ms).  Lanes 36 .. 63 repeat lanes 0 .. 27.
+__device__ __forceinline__ void wide_op(int32_t* __restrict__ fre, int32_t* __restrict__ fim, const int32_t* __restrict__ yre,
+                                        const int32_t* __restrict__ yim, uint32_t ax, bool wrap, const uint32_t (&ar)[5]) {
+    int32_t nim[NL], xre[NL], xim[NL], nxim[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) { nim[j] = -fim[j]; xre[j] = fre[j] - fim[j]; xim[j] = fre[j] + fim[j]; nxim[j] = -xim[j]; }
+    int32_t Xre[NL], Xim[NL], Xnim[NL], a[NL], b[NL];
+    bperm14(a, fre, ax); bperm14(b, xre, ax);
+#pragma unroll
+    for (int j = 0; j < NL; j++) Xre[j] = wrap ? b[j] : a[j];
+    bperm14(a, fim, ax); bperm14(b, xim, ax);
+#pragma unroll
+    for (int j = 0; j < NL; j++) Xim[j] = wrap ? b[j] : a[j];
+    bperm14(a, nim, ax); bperm14(b, nxim, ax);
+#pragma unroll
+    for (int j = 0; j < NL; j++) Xnim[j] = wrap ? b[j] : a[j];
+    int32_t pre[NL], pim[NL];
+    bls28::fp28_dot2(pre, Xre, yre, Xnim, yim);            // units: 1 + 2 (|xi f| limbs below 2^29): inside 8
+    bls28::fp28_dot2(pim, Xre, yim, Xim, yre);
+    r28::F<0, 6> sr, si;
+#pragma unroll
+    for (int j = 0; j < NL; j++) { sr.v[j] = pre[j]; si.v[j] = pim[j]; }
+#pragma unroll
+    for (int u = 0; u < 5; u++) {
+        bperm14(a, pre, ar[u]); bperm14(b, pim, ar[u]);
+#pragma unroll
+        for (int j = 0; j < NL; j++) { sr.v[j] += a[j]; si.v[j] += b[j]; }
+    }
+    const fe nr = r28::norm(sr), ni = r28::norm(si);       // six values in (-q, 2q): digits back below 2^28
+#pragma unroll
+    for (int j = 0; j < NL; j++) { fre[j] = nr.v[j]; fim[j] = ni.v[j]; }
+}
+__global__ void __launch_bounds__(64) k_ml_horner_wide(const int32_t* __restrict__ prods, uint32_t groups, uint32_t* __restrict__ partials,
+                                                       uint32_t pstride) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t l36 = lane < 36u ? lane : lane - 36u;
+    const uint32_t t = l36 / 6u, k = l36 - t * 6u;
+    const uint32_t g = blockIdx.x;
+    const int32_t* rec = prods + (size_t)g * LINES * DENSE_DW;
+    const uint32_t ax = (t * 6u + (k >= t ? k - t : k + 6u - t)) * 4u;     // own row, coefficient (k - t) mod 6
+    const bool wrap = t > k;
+    const uint32_t ay = (t * 6u + t) * 4u;                                   // own row, coefficient t
+    uint32_t ar[5];
+#pragma unroll
+    for (int u = 0; u < 5; u++) ar[u] = (((t + 1u + u) % 6u) * 6u + k) * 4u;  // the other rows, same coefficient
+    int32_t fre[NL], fim[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) { fre[j] = rec[k * 2 * NL + j]; fim[j] = rec[k * 2 * NL + NL + j]; }
+#pragma unroll 1
+    for (uint32_t L = 1; L < (uint32_t)LINES; L++) {
+        int32_t yre[NL], yim[NL];
+        if (line_is_tangent(L)) {
+            bperm14(yre, fre, ay); bperm14(yim, fim, ay);
+            wide_op(fre, fim, yre, yim, ax, wrap, ar);
+        }
+        const int32_t* m = rec + (size_t)L * DENSE_DW + t * 2 * NL;
+#pragma unroll
+        for (int j = 0; j < NL; j++) { yre[j] = m[j]; yim[j] = m[NL + j]; }
+        wide_op(fre, fim, yre, yim, ax, wrap, ar);
+    }
+    if (lane < 6u && g < groups) {
+        const uint32_t flat = (k & 1u) ? 3u + (k >> 1) : (k >> 1);
+        uint32_t* o = partials + (size_t)g * pstride + flat * 24u;
+        fe a, b;
+#pragma unroll
+        for (int j = 0; j < NL; j++) { a.v[j] = fre[j]; b.v[j] = fim[j]; }
+        uint32_t w[12];
+        r28::to_vm(w, a);
+#pragma unroll
+        for (int j = 0; j < 12; j++) o[j] = w[j];
+        r28::to_vm(w, b);
+#pragma unroll
+        for (int j = 0; j < 12; j++) o[12 + j] = w[j];
+    }
+}
 }  // namespace ml
 
 // The listed pairs through the reference-faithful program: extra[e] = fq_miller_loop of pair dg.blocks[e] (144 words).

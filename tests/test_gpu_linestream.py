@@ -28,12 +28,12 @@ def ls():
 
 def test_default_selection_is_line_stream_for_large_calls(engine, ls, seeded_pairs, golden):
     """the shared engine (default thresholds) and the forced one agree on the reference's 1025-pair vector, and a
-    call of 16 x 1025 pairs -- line-stream by default -- returns it for every group"""
+    call of 32 x 1025 pairs -- line-stream by default -- returns it for every group"""
     g1, g2 = seeded_pairs
     want = golden("pairing.json")["seeded"]["1025"]["out"]
     assert ls.pairing_multi(g1, g2, 1025).hex() == want
-    out = engine.pairing_multi_batch(g1 * 16, g2 * 16, 1025, 16)
-    assert all(out[576 * g:576 * (g + 1)].hex() == want for g in range(16))
+    out = engine.pairing_multi_batch(g1 * 32, g2 * 32, 1025, 32)
+    assert all(out[576 * g:576 * (g + 1)].hex() == want for g in range(32))
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 64, 65])
