@@ -600,10 +600,10 @@ def run_c4(env, args):
             "n_gpus": env.world, "steps": reps, "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: %d groups per GPU, G2 multi-scalar combine of 67 shares + 2-pair verify; "
-                                   "bucket method with signed 4-bit digits, one (group, window) per lane, 8 buckets in HBM, complete mixed additions" % groups, "name": "c4",
+                                   "bucket method with signed 4-bit digits, one (group, window) per lane PAIR (Fq2 split over two lanes), 8 buckets in HBM, complete mixed additions; verifies: point chains on lane pairs + one accumulator per group (k_ml_lines2, k_ml_small)" % groups, "name": "c4",
                        "check": "combine == c_g x reference golden, every verify == 1"},
             "combine_s": dt_c, "verify_s": dt_v,
-            "roofline": {"bound": "valu-int32-mac", "kernel": "k_msm_lane<2> (+ k_lane_prep, windows, horner)", "peak": PEAK_TMACS, "unit": "TMAC/s",
+            "roofline": {"bound": "valu-int32-mac", "kernel": "k_msm_lane2x (+ k_lane_prep, windows, horner)", "peak": PEAK_TMACS, "unit": "TMAC/s",
                          "achieved": mac_combine * groups / dt_c / 1e12, "frac": mac_combine * groups / dt_c / 1e12 / PEAK_TMACS,
                          "verify_achieved": mac_verify * groups / dt_v / 1e12, "traffic": None,
                          "algorithmic_bytes": groups * k * (192 + 32)}}

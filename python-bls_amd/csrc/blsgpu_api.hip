@@ -59,6 +59,7 @@ struct blsgpu_ctx {
     size_t msm_sort_threshold = 16384;  // points from which one G1 sum with scalars uses sorted buckets (k_srt_*)
     size_t horner_np_threshold = 1024; // G2 sums per call from which the window Horner runs several sums per team
     size_t msm_lane_threshold = 65536; // points from which the bucket sums run one (group, chunk, window) per lane
+    bool msm_lane_pairs = true;        // G2: every (group, chunk, window) on a lane PAIR (k_msm_lane2x) instead of one lane
     uint32_t* d_buckets = nullptr;     // their buckets (HBM)
     size_t bucket_cap = 0;
     uint32_t* d_msm_part = nullptr;    // MSM partials
@@ -361,9 +362,14 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
             const size_t lanes = groups * chunks * blsgpu::PIP_W;
             const size_t bneed = lanes * (blsgpu::PIP_NB - 1) * PJ28 + fold_n * groups * blsgpu::PIP_W * 36 * DEG;
             if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, bneed)) return rc_;
-            hipLaunchKernelGGL(blsgpu::k_msm_lane<DEG>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, d_prep, d_live,
-                               (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, (uint32_t)chunks, (uint32_t)lanes, c->d_buckets,
-                               c->d_msm_part, fold_n ? 0u : 1u);
+            if (DEG == 2 && c->msm_lane_pairs)
+                hipLaunchKernelGGL(blsgpu::k_msm_lane2x, dim3((unsigned)((2 * lanes + 63) / 64)), dim3(64), 0, st, d_prep, d_live,
+                                   (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, (uint32_t)chunks, (uint32_t)lanes, c->d_buckets,
+                                   c->d_msm_part, fold_n ? 0u : 1u);
+            else
+                hipLaunchKernelGGL(blsgpu::k_msm_lane<DEG>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, d_prep, d_live,
+                                   (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, (uint32_t)chunks, (uint32_t)lanes, c->d_buckets,
+                                   c->d_msm_part, fold_n ? 0u : 1u);
             HIP_TRY(hipGetLastError());
             const uint32_t* winsrc = c->d_msm_part;
             size_t wchunks = chunks;
@@ -485,6 +491,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_NP_THRESHOLD")) c->horner_np_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_LANE_THRESHOLD")) c->msm_lane_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_MSM_LANE_PAIRS")) c->msm_lane_pairs = atoi(e) != 0;
     // pack all tables into one device allocation (16-byte aligned pieces)
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     size_t o_m = 0;
@@ -761,7 +768,7 @@ static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, cons
 // The line-stream form of launch_miller (blsgpu_ml.hip): ONE partial per group comes out (bpg = 1).
 constexpr size_t LS_MAX_PAIRS = (size_t)1 << 20;       // pairs per launch sequence: 24 GB of line records
 static bool use_ls(const blsgpu_ctx* c, size_t gsz, size_t groups) {
-    return gsz >= c->ls_min_group && gsz * groups >= c->ls_threshold && gsz * groups <= 0x3FFFFFF0ull;
+    return gsz >= 1 && gsz * groups >= c->ls_threshold && gsz * groups <= 0x3FFFFFF0ull;
 }
 static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups,
                             uint32_t* d_partials, hipStream_t st) {
@@ -777,9 +784,10 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     const size_t chunk = (gsz + cpg - 1) / cpg;
     cpg = (gsz + chunk - 1) / chunk;
     constexpr size_t FAN = 8;
+    const bool small = gsz < c->ls_min_group;              // one accumulator per group runs the whole loop (k_ml_small)
     if (grow_buffer(c, &c->d_lines, &c->lines_cap, n * ml::LINES * ml::LINE_DW * 4) ||
-        grow_buffer(c, &c->d_lsp[0], &c->lsp_cap[0], groups * cpg * ml::LINES * ml::DENSE_DW * 4) ||
-        grow_buffer(c, &c->d_lsp[1], &c->lsp_cap[1], groups * ((cpg + FAN - 1) / FAN) * ml::LINES * ml::DENSE_DW * 4) ||
+        (!small && grow_buffer(c, &c->d_lsp[0], &c->lsp_cap[0], groups * cpg * ml::LINES * ml::DENSE_DW * 4)) ||
+        (!small && grow_buffer(c, &c->d_lsp[1], &c->lsp_cap[1], groups * ((cpg + FAN - 1) / FAN) * ml::LINES * ml::DENSE_DW * 4)) ||
         grow_buffer(c, &c->d_bad, &c->bad_cap, n) || grow_buffer(c, &c->d_extra, &c->extra_cap, n * 576) ||
         grow_elems(c, &c->d_degen, &c->degen_cap, n + 2)) {
         (void)hipGetLastError();
@@ -803,6 +811,20 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
                            (const uint32_t*)d_g2, dg, (uint32_t*)c->d_extra);
     }
     HIP_TRY(hipGetLastError());
+    if (small) {
+        {
+            KernelTimer kt(c, st, 5);
+            hipLaunchKernelGGL(ml::k_ml_small, dim3((unsigned)((groups + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st, (const int32_t*)c->d_lines,
+                               (const uint8_t*)c->d_bad, (uint32_t)n, (uint32_t)gsz, (uint32_t)groups, d_partials, 144u);
+        }
+        HIP_TRY(hipGetLastError());
+        if (c->bulk_event) HIP_TRY(hipEventRecord(c->bulk_event, st));
+        KernelTimer kt(c, st, 3);
+        hipLaunchKernelGGL(k_ml_fold_extras, dim3((unsigned)groups), dim3(64), (size_t)TEAM_BYTES, st, c->tabs, dg, (const uint32_t*)c->d_extra,
+                           (uint32_t)gsz, d_partials, 144u);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     size_t teams = groups * cpg * ml::LINES;
     {
         KernelTimer kt(c, st, 5);
@@ -1115,6 +1137,20 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1
     if (gsz >= BATCH_TREE_MIN_GROUP) return grouped_pairing(c, d_g1, d_g2, d_inf, gsz, groups, nullptr, d_out, st);
     int rc = ensure_workspace(c, (n + 1) * MILLER_WAVES);      // one partial per PAIR here
     if (rc) return rc;
+    if (gsz >= 1 && use_ls(c, gsz, groups) && n <= LS_MAX_PAIRS) {
+        // a large batch of small groups: point chains on lane pairs, then one accumulator per group (blsgpu_ml.hip)
+        rc = launch_miller_ls(c, d_g1, d_g2, d_inf, gsz, groups, c->d_part[0], st);
+        if (rc == 0) {
+            size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
+            unsigned blocks = (unsigned)((groups + REDUCE_WAVES - 1) / REDUCE_WAVES);
+            KernelTimer kt(c, st, 2);
+            hipLaunchKernelGGL(blsgpu::k_final_groups, dim3(blocks), dim3(REDUCE_WAVES * 64), lds, st, c->tabs, c->d_part[0], 1u,
+                               (uint32_t)groups, (uint32_t*)d_out);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+        if (rc != -ENOMEM) return rc;
+    }
     // groups of two or three pairs in a batch large enough for the team kernels: the group IS the team (one
     // accumulator, its squarings shared), one partial per group; otherwise one partial per pair
     const bool team_groups = (gsz == 2 || gsz == (size_t)BLSVM_MP_G) && use_mp(c, n) && groups <= 0x7FFFFFFFull;

@@ -604,6 +604,72 @@ __global__ void __launch_bounds__(64, 2) k_ml_horner(const int32_t* __restrict__
     }
 }
 
+// Small groups (a batch of verifications of a few pairs each: threshold verifies, single signatures): the classic loop
+// f <- f^2 prod_i l_{i,L} with ONE GROUP PER TEAM of six lanes, lines from k_ml_lines2 -- the per-line products of a
+// group of two are not worth an accumulator each, and the group count already fills the chip.
+struct TeamRec {                                   // the team's own f as the dense operand (squaring)
+    const int32_t* re; const int32_t* im; uint32_t base4;
+    __device__ __forceinline__ void operator()(int32_t* __restrict__ d, int k) const {
+        bperm14(d, (k & 1) ? im : re, base4 + (uint32_t)(k >> 1) * 4u);
+    }
+};
+__global__ void __launch_bounds__(64, 2) k_ml_small(const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad, uint32_t n, uint32_t gsz,
+                                                    uint32_t groups, uint32_t* __restrict__ partials, uint32_t pstride) {
+    const Team t = team_of_lane();
+    const uint32_t g = blockIdx.x * TEAMS + t.slot;
+    const bool valid = t.slot < (uint32_t)TEAMS && g < groups;
+    const size_t first = (size_t)(valid ? g : 0u) * gsz;
+    int32_t fre[NL], fim[NL];
+    set_one(fre, fim, t);
+#pragma unroll 1
+    for (uint32_t L = 0; L < (uint32_t)LINES; L++) {
+        if (L > 0 && line_is_tangent(L)) {
+            int32_t cre[NL], cim[NL];
+#pragma unroll
+            for (int k = 0; k < NL; k++) { cre[k] = fre[k]; cim[k] = fim[k]; }
+            mul_dense(fre, fim, t, TeamRec{cre, cim, t.base4});
+        }
+        const int32_t* base = lines + ((size_t)L * n + first) * LINE_DW;
+#pragma unroll 1
+        for (uint32_t i = 0; i < gsz; i++) {
+            const bool use = bad[first + i] == 0;
+            const int4* rec = reinterpret_cast<const int4*>(base + (size_t)i * LINE_DW);
+            int32_t y[6][NL];
+            {
+                int4 q[LINE_DW / 4];
+#pragma unroll
+                for (int k = 0; k < LINE_DW / 4; k++) q[k] = rec[k];
+#pragma unroll
+                for (int k = 0; k < LINE_DW / 4; k++) {
+                    const int e = 4 * k;
+                    y[e / NL][e % NL] = q[k].x; y[(e + 1) / NL][(e + 1) % NL] = q[k].y;
+                    y[(e + 2) / NL][(e + 2) % NL] = q[k].z; y[(e + 3) / NL][(e + 3) % NL] = q[k].w;
+                }
+            }
+            Pub P;
+            publish<true>(P, fre, fim);                    // f may be a dense product's sum: normalised xi forms
+            int32_t re[NL], im[NL];
+            mul3<0, 2, 3>(re, im, P, t, y[0], y[1], y[2], y[3], y[4], y[5]);
+#pragma unroll
+            for (int k = 0; k < NL; k++) { fre[k] = use ? re[k] : fre[k]; fim[k] = use ? im[k] : fim[k]; }
+        }
+    }
+    if (valid) {
+        const uint32_t flat = (t.c & 1u) ? 3u + (t.c >> 1) : (t.c >> 1);
+        uint32_t* o = partials + (size_t)g * pstride + flat * 24u;
+        fe a, b;
+#pragma unroll
+        for (int k = 0; k < NL; k++) { a.v[k] = fre[k]; b.v[k] = fim[k]; }
+        uint32_t w[12];
+        r28::to_vm(w, a);
+#pragma unroll
+        for (int k = 0; k < 12; k++) o[k] = w[k];
+        r28::to_vm(w, b);
+#pragma unroll
+        for (int k = 0; k < 12; k++) o[12 + k] = w[k];
+    }
+}
+
 // The same chain with ONE GROUP PER WAVEFRONT and the six terms of every coefficient on six different lanes: lane
 // (t, k) = 6 t + k computes the one Fq2 product F_{k-t} g_t (two sums of two products), the six products of a coefficient
 // are added across the lanes (ds_bpermute) and every lane ends up with f_k.  A dense product is then ~1.6 k

@@ -550,6 +550,161 @@ __global__ void __launch_bounds__(64) k_msm_lane(const uint32_t* __restrict__ pr
     else r28::pt_st(tot, partials + o * PJ_DW);
 }
 
+// ---- the same bucket sums for G2 on LANE PAIRS (round 3) ------------------------------------------------------------
+// k_msm_lane<2> needs 511 registers and 1.7 KB of scratch per lane for a twist addition (one wavefront per SIMD, 55 % of
+// the issue rate).  With every Fq2 value split over two adjacent lanes (blsgpu_ml.hip, namespace sp: even lane real
+// part, odd lane imaginary part, partner's part one DPP move away) a lane holds half of every coordinate: no scratch,
+// two wavefronts per SIMD, and the mixed addition (7 k instructions per lane) stays in the instruction cache.  Same
+// complete formulas (RCB 2015 algorithms 7 and 8), same bucket and partial layouts as k_msm_lane<2>.
+namespace sp2 {
+using namespace ml::sp;
+struct pt { h X, Y, Z; };
+__device__ __forceinline__ pt pt_inf() {
+    const int32_t one[r28::NL] = BLS28_ONE;
+    pt r;
+#pragma unroll
+    for (int j = 0; j < r28::NL; j++) { r.X.v[j] = 0; r.Y.v[j] = odd() ? 0 : one[j]; r.Z.v[j] = 0; }
+    return r;
+}
+__device__ __forceinline__ h ldh(const uint32_t* __restrict__ p) {                  // the lane's half of an fe2 at p
+    h r;
+    const uint32_t* q = p + (odd() ? r28::NL : 0);
+#pragma unroll
+    for (int j = 0; j < r28::NL; j++) r.v[j] = (int32_t)q[j];
+    return r;
+}
+__device__ __forceinline__ void sth(const h& x, uint32_t* __restrict__ p) {
+    uint32_t* q = p + (odd() ? r28::NL : 0);
+#pragma unroll
+    for (int j = 0; j < r28::NL; j++) q[j] = (uint32_t)x.v[j];
+}
+__device__ __forceinline__ pt pt_ld(const uint32_t* __restrict__ p) { return {ldh(p), ldh(p + 2 * r28::NL), ldh(p + 4 * r28::NL)}; }
+__device__ __forceinline__ void pt_st(const pt& P, uint32_t* __restrict__ p) { sth(P.X, p); sth(P.Y, p + 2 * r28::NL); sth(P.Z, p + 4 * r28::NL); }
+// P += (x2 : y2 : 1), RCB algorithm 8
+__device__ __forceinline__ void pmadd(pt& P, const h& x2, const h& y2) {
+    const Lop<1> lx2 = left(x2), ly2 = left(y2);
+    const Rop<1> rX = right(P.X), rY = right(P.Y), rZ = right(P.Z);
+    const h t0 = mul(lx2, rX), t1 = mul(ly2, rY);
+    const h t3 = norm(sub(sub(mul(left(add(x2, y2)), right(add(P.X, P.Y))), t0), t1));
+    const h t4 = norm(add(mul(ly2, rZ), P.Y));
+    const h y3 = b3(add(mul(lx2, rZ), P.X));
+    const h x3 = mulc_norm<3>(t0);
+    const h bz = b3(P.Z);
+    const h z3 = norm(add(t1, bz)), t1m = norm(sub(t1, bz));
+    const Lop<1> lz3 = left(z3), lx3 = left(x3), ly3 = left(y3), lt1m = left(t1m);
+    const Rop<1> rt3 = right(t3), rt4 = right(t4);
+    P.X = dot2(left(t3), right(t1m), left(neg(t4)), right(y3));
+    P.Y = dot2(ly3, right(x3), lt1m, right(z3));
+    P.Z = dot2(lz3, rt4, lx3, rt3);
+}
+// P + Q, RCB algorithm 7
+__device__ __forceinline__ pt padd(const pt& P, const pt& Q) {
+    const Rop<1> rQX = right(Q.X), rQY = right(Q.Y), rQZ = right(Q.Z);
+    const h t0 = mul(left(P.X), rQX), t1 = mul(left(P.Y), rQY), t2 = mul(left(P.Z), rQZ);
+    const h t3 = norm(sub(sub(mul(left(add(P.X, P.Y)), right(add(Q.X, Q.Y))), t0), t1));
+    const h t4 = norm(sub(sub(mul(left(add(P.Y, P.Z)), right(add(Q.Y, Q.Z))), t1), t2));
+    const S<3> t5 = sub(sub(mul(left(add(P.X, P.Z)), right(add(Q.X, Q.Z))), t0), t2);
+    const h x3 = mulc_norm<3>(t0);
+    const h bz = b3(t2);
+    const h z3 = norm(add(t1, bz)), t1m = norm(sub(t1, bz));
+    const h y3 = b3(t5);
+    pt R;
+    R.X = dot2(left(t3), right(t1m), left(neg(t4)), right(y3));
+    R.Y = dot2(left(t1m), right(z3), left(y3), right(x3));
+    R.Z = dot2(left(z3), right(t4), left(x3), right(t3));
+    return R;
+}
+__device__ __forceinline__ void st_vm(const pt& r, uint32_t* __restrict__ p) {     // the VM's projective form: 72 dwords
+    const h* c[3] = {&r.X, &r.Y, &r.Z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        r28::fe t;
+#pragma unroll
+        for (int j = 0; j < r28::NL; j++) t.v[j] = c[k]->v[j];
+        uint32_t w[12];
+        r28::to_vm(w, t);
+        uint32_t* o = p + k * 24 + (odd() ? 12 : 0);
+#pragma unroll
+        for (int j = 0; j < 12; j++) o[j] = w[j];
+    }
+}
+}  // namespace sp2
+
+#ifndef BLSGPU_MSM_LANE2X_WAVES
+#define BLSGPU_MSM_LANE2X_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, BLSGPU_MSM_LANE2X_WAVES) k_msm_lane2x(const uint32_t* __restrict__ prep, const uint8_t* __restrict__ live,
+                                                  const uint32_t* __restrict__ scalars, uint32_t k,
+                                                  uint32_t chunk, uint32_t chunks, uint32_t total, uint32_t* __restrict__ buckets,
+                                                  uint32_t* __restrict__ partials, uint32_t vm_out) {
+    constexpr uint32_t PJ_DW = L28_PJ * 2, AF_DW = L28_AFF * 2;
+    const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t L = min(T >> 1, total - 1u);                                  // spare lanes of the last wavefront repeat the last item
+    const bool store = (T >> 1) < total;
+    const uint32_t win = L & 63u, cidx = (L >> 6) % chunks, grp = (L >> 6) / chunks;
+    const uint32_t lo = grp * k + cidx * chunk, hi = min(grp * k + k, lo + chunk);
+    uint32_t* B = buckets + (size_t)L * (PIP_NB - 1) * PJ_DW;                   // buckets 1 .. 15
+    {
+        const sp2::pt inf = sp2::pt_inf();
+        for (int j = 0; j < PIP_NB - 1; j++) sp2::pt_st(inf, B + j * PJ_DW);
+    }
+    bool wide = false;                                                          // (digits as in k_msm_lane)
+#pragma unroll 1
+    for (uint32_t i = lo; i < hi; i++) {
+        if (!live[i]) continue;
+        uint32_t word;
+        bool big = false;
+        if (scalars) {
+            const uint32_t* sc = scalars + (size_t)i * 8;
+            big = bswap32(sc[0]) > 0x77777776u;
+            if (!big) {
+                uint32_t c = 0;
+                word = 0;
+                for (uint32_t j = 0; j <= win / 8; j++) word = bls::addc(bswap32(sc[7u - j]), 0x88888888u, c);
+            } else {
+                word = bswap32(sc[7 - win / 8]);
+            }
+        } else {
+            word = (win < 8) ? 0x88888889u : 0x88888888u;
+        }
+        const int nib = (int)((word >> (4 * (win % 8))) & 15u);
+        const int d = big ? nib : nib - 8;
+        wide = wide || big;
+        if (d != 0) {
+            uint32_t* b = B + ((d < 0 ? -d : d) - 1) * PJ_DW;
+            const uint32_t* pt = prep + (size_t)i * AF_DW;
+            const sp2::h x2 = sp2::ldh(pt);
+            sp2::h y2 = sp2::ldh(pt + 2 * r28::NL);
+            if (d < 0) y2 = sp2::norm(sp2::neg(y2));
+            sp2::pt r = sp2::pt_ld(b);
+            sp2::pmadd(r, x2, y2);
+            sp2::pt_st(r, b);
+        }
+    }
+    // sum_j j B_j by running sums: acc += B_j, tot += acc -- ONE inlined addition, its operands chosen by the step's parity
+    sp2::pt acc = sp2::pt_inf(), tot = sp2::pt_inf();
+    const int nb = wide ? PIP_NB - 1 : PIP_NB / 2;
+#pragma unroll 1
+    for (int it = 0; it < 2 * nb; it++) {
+        const bool first = (it & 1) == 0;
+        const int j = nb - 1 - (it >> 1);
+        const sp2::pt Bj = sp2::pt_ld(B + j * PJ_DW);
+        sp2::pt P, Q;
+#pragma unroll
+        for (int e = 0; e < r28::NL; e++) {
+            P.X.v[e] = first ? acc.X.v[e] : tot.X.v[e]; P.Y.v[e] = first ? acc.Y.v[e] : tot.Y.v[e]; P.Z.v[e] = first ? acc.Z.v[e] : tot.Z.v[e];
+            Q.X.v[e] = first ? Bj.X.v[e] : acc.X.v[e]; Q.Y.v[e] = first ? Bj.Y.v[e] : acc.Y.v[e]; Q.Z.v[e] = first ? Bj.Z.v[e] : acc.Z.v[e];
+        }
+        const sp2::pt R = sp2::padd(P, Q);
+        if (first) acc = R; else tot = R;
+    }
+    if (store) {
+        const size_t o = ((size_t)grp * PIP_W + win) * chunks + cidx;
+        if (vm_out) sp2::st_vm(tot, partials + o * 72);
+        else sp2::pt_st(tot, partials + o * PJ_DW);
+    }
+}
+
 // out[w * nfold + f] = sum of partials[w * chunks + f * per .. + per): one run per lane; L28 in, L28 or the VM's form out
 template <int DEG>
 __global__ void __launch_bounds__(64) k_msm_lane_fold(const uint32_t* __restrict__ partials, uint32_t chunks, uint32_t per, uint32_t nfold,

@@ -158,3 +158,40 @@ def test_miller_product_partials_compose(ls, seeded_pairs, golden):
     ls.final_exp_product_batch_dev(parts.data_ptr(), 2, 1, out.data_ptr())
     torch.cuda.synchronize()
     assert bytes(out.cpu().numpy()).hex() == golden("pairing.json")["seeded"]["1025"]["out"]
+
+
+def test_small_groups_one_accumulator_per_group(golden, seeded_pairs, oracle):
+    """k_ml_small: batches of groups of 1, 2, 3, 7 and 27 pairs (threshold verifies, single signatures), with degenerate
+    pairs spliced in, against the oracle group by group"""
+    from bls_py import _native
+    e = _native.Engine(0)
+    e.set_ls_threshold(1, 1 << 30)                     # every group is "small"
+    a, b, inf = _spliced(golden, seeded_pairs, count=220, every=13)
+    n = len(a) // 96
+    for gsz in (1, 2, 3, 7, 27):
+        groups = min(n // gsz, 40)
+        m = gsz * groups
+        out = e.pairing_multi_batch(a[:96 * m], b[:192 * m], gsz, groups, inf[:2 * m])
+        for g in range(groups):
+            lo, hi = gsz * g, gsz * (g + 1)
+            want = oracle.pairing_multi(a[96 * lo:96 * hi], b[192 * lo:192 * hi], gsz, inf=inf[2 * lo:2 * hi])
+            assert out[576 * g:576 * (g + 1)] == want, (gsz, g)
+    # one long "small" group: the whole loop on one team
+    g1, g2 = seeded_pairs
+    assert e.pairing_multi(g1[:96 * 65], g2[:192 * 65], 65).hex() == golden("pairing.json")["seeded"]["65"]["out"]
+
+
+def test_default_selection_for_a_batch_of_two_pair_verifications(engine, seeded_pairs, oracle):
+    """10 000 groups of 2 pairs (BASELINE configs[3]'s verifies) take the small-group line-stream kernels by default:
+    every 97th group against the oracle, and the whole output against the VM kernels"""
+    from bls_py import _native
+    g1, g2 = seeded_pairs
+    groups = 10000
+    a = (g1 * 20)[:96 * 2 * groups]
+    b = (g2 * 20)[:192 * 2 * groups]
+    out = engine.pairing_multi_batch(a, b, 2, groups)
+    for g in range(0, groups, 97):
+        assert out[576 * g:576 * (g + 1)] == oracle.pairing_multi(a[96 * 2 * g:96 * 2 * (g + 1)], b[192 * 2 * g:192 * 2 * (g + 1)], 2), g
+    vm = _native.Engine(0)
+    vm.set_ls_threshold(None)
+    assert vm.pairing_multi_batch(a, b, 2, groups) == out
