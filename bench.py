@@ -9,12 +9,13 @@ exits with the child's code; under an external torchrun it just reads RANK / WOR
 
 A "step" is one pass of the hot path over one batch already resident in HBM.
 
-  c2 (default, headline; BASELINE.json configs[1] shape x 256, weak scaling)
-      B = 256 independent aggregate verifications per step (round 3; 32 before: a step of 32 800 pairs lasted 6 ms, so the
-      driver's 20 steps were a 0.13 s timed region, and 10 934 teams left the last third of the launch at 2/3 occupancy),
-      each fq_ate_pairing_multi over 1025
+  c2 (default, headline; BASELINE.json configs[1] shape x 512, weak scaling)
+      B = 512 independent aggregate verifications per step (round 3; 32 in rounds 1-2: a step of 32 800 pairs lasted 6 ms, so
+      the driver's 20 steps were a 0.13 s timed region.  The line-stream kernels run 16 400 + 33 000 wavefronts per
+      step at B = 512: the last, partly filled round of wavefronts costs 6 % of a step, 12 % at B = 256 -- measured
+      12.65 against 11.84 M pairings/s), each fq_ate_pairing_multi over 1025
       (pk, H(m)) pairs per GPU (1024 signatures + the (-G1, aggregate) pair): Miller loops,
-      Fq12 products, B final exponentiations.  The 256 x 1025 pairs of a rank are 262 400 DIFFERENT
+      Fq12 products, B final exponentiations.  The 512 x 1025 pairs of a rank are 524 800 DIFFERENT
       PRF-seeded points; verification 0 on rank 0 is the batch whose result the
       reference produced (tests/golden/pairing.json).  N ranks: Miller products per rank, ONE RCCL
       all-gather of B x 576 bytes per rank, the B final exponentiations on every rank.
@@ -45,7 +46,7 @@ sys.path.insert(0, os.path.join(ROOT, "python-bls_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PAIRS_PER_GPU = 1025
-VERIFICATIONS_PER_STEP = 256
+VERIFICATIONS_PER_STEP = 512
 C3_PAIRS = 65536
 # algorithmic work, SURVEY.md section 8(d): 6754 Fq-mults per pairing at 300 32-bit MACs each,
 # ~9.5k Fq-mults per final exponentiation; G2 / G1 mixed additions at 36 / 11 Fq-mults

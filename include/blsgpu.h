@@ -94,6 +94,15 @@ int blsgpu_ctx_set_ls_teams(blsgpu_ctx *ctx, size_t teams);
  * exponentiation) occupies a few dozen wavefronts.  A caller that pipelines calls over several contexts lets the
  * next call's stream wait for this event instead of the end of the call (bench.py does). */
 int blsgpu_ctx_set_bulk_event(blsgpu_ctx *ctx, void *event);
+/* Calls that end in at least `results` final exponentiations (fq12_final_exp, fields_t.py:1124-1128) run them six
+ * lanes per result, ten results per wavefront, on the register arithmetic (csrc/blsgpu_fexp.hip: ~4x fewer
+ * instructions per result than the one-wavefront-per-result VM program, which keeps the lower latency for a few
+ * results).  Default 256; (size_t)-1: never.  Results are identical either way. */
+int blsgpu_ctx_set_fexp_team_threshold(blsgpu_ctx *ctx, size_t results);
+/* Diagnostic: a device buffer of (script length) x 576 bytes that receives the accumulator of result 0 after every
+ * operation of the batched final exponentiation's script (tools/fexp_trace.py compares it with the integer model), or
+ * NULL (default). */
+int blsgpu_ctx_set_fexp_trace(blsgpu_ctx *ctx, void *d_buf);
 
 /* fq_ate_pairing_multi(Ps, Qs) -- fields_t.py:1114-1121 / fields_t_c.pyx:2333-2391.
  * Host buffers in, 576 result bytes out; synchronous.  n == 0 returns one. */

@@ -23,7 +23,7 @@ SYMBOLS = (
     "blsgpu_g1_decompress", "blsgpu_g2_decompress", "blsgpu_g1_decompress_dev", "blsgpu_g2_decompress_dev",
     "blsgpu_hash_to_g2", "blsgpu_hash_to_g2_dev",
     "blsgpu_miller_loop_batch", "blsgpu_miller_loop_batch_dev", "blsgpu_line_eval_batch", "blsgpu_ctx_trim",
-    "blsgpu_fq12_op_batch", "blsgpu_fq12_pow_batch", "blsgpu_ctx_set_mp3_threshold", "blsgpu_ctx_set_ls_threshold", "blsgpu_ctx_set_ls_teams", "blsgpu_ctx_set_bulk_event",
+    "blsgpu_fq12_op_batch", "blsgpu_fq12_pow_batch", "blsgpu_ctx_set_mp3_threshold", "blsgpu_ctx_set_ls_threshold", "blsgpu_ctx_set_ls_teams", "blsgpu_ctx_set_bulk_event", "blsgpu_ctx_set_fexp_team_threshold", "blsgpu_ctx_set_fexp_trace",
 )
 
 _lib = None
@@ -66,6 +66,8 @@ def load_library(path=None):
         L.blsgpu_ctx_set_ls_threshold.argtypes = [vp, sz, sz]
         L.blsgpu_ctx_set_ls_teams.argtypes = [vp, sz]
         L.blsgpu_ctx_set_bulk_event.argtypes = [vp, vp]
+        L.blsgpu_ctx_set_fexp_team_threshold.argtypes = [vp, sz]
+        L.blsgpu_ctx_set_fexp_trace.argtypes = [vp, vp]
         L.blsgpu_ctx_trim.argtypes = [vp]
         L.blsgpu_pairing_multi.argtypes = [vp, cp, cp, cp, sz, cp]
         L.blsgpu_pairing_multi_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
@@ -147,6 +149,11 @@ class Engine:
 
     def set_ls_teams(self, teams):
         self._check(self.lib.blsgpu_ctx_set_ls_teams(self.h, teams), "blsgpu_ctx_set_ls_teams")
+
+    def set_fexp_team_threshold(self, results):
+        """calls with >= results final exponentiations run them six lanes each; None: never"""
+        self._check(self.lib.blsgpu_ctx_set_fexp_team_threshold(self.h, (1 << 64) - 1 if results is None else results),
+                    "blsgpu_ctx_set_fexp_team_threshold")
 
     def set_bulk_event(self, event_handle):
         """hipEvent_t handle (int; torch: event.cuda_event after a first record) recorded after the chip-filling

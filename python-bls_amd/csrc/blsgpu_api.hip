@@ -15,6 +15,7 @@
 #include "blsgpu_kernels.hip"
 #include "fp28.h"
 #include "blsgpu_ml.hip"
+#include "blsgpu_fexp.hip"
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
 
@@ -78,6 +79,10 @@ struct blsgpu_ctx {
     size_t extra_cap = 0;
     int ls_horner_form = 2;            // 2: one group per wavefront, a product spread over 36 lanes; 1: ten groups per wavefront
     int ls_lines_form = 2;             // 2: the point chains on lane pairs (k_ml_lines2); 1: one pair per lane (k_ml_lines)
+    size_t fexp_team_threshold = 256;  // results per call from which the final exponentiations run six lanes each (blsgpu_fexp.hip)
+    void* d_fexp_dbg = nullptr;        // tools/fexp_trace.py: the accumulator of result 0 after every operation of the script
+    void* d_fexp_ws = nullptr;         // their slots
+    size_t fexp_ws_cap = 0;
     hipEvent_t bulk_event = nullptr;   // caller's event, recorded after the last chip-filling kernel of a Miller stage
     size_t msm_part_cap = 0;           // in u32
     // optional per-kernel timing (blsgpu_timing_enable): HIP events recorded on
@@ -483,6 +488,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_LS_THRESHOLD")) c->ls_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_MIN_GROUP")) c->ls_min_group = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_TEAMS")) c->ls_teams = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_FEXP_TEAM_THRESHOLD")) c->fexp_team_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_LINES_FORM")) c->ls_lines_form = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("BLSGPU_LS_HORNER_FORM")) c->ls_horner_form = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -603,6 +609,7 @@ BLSGPU_EXPORT void blsgpu_ctx_destroy(blsgpu_ctx* c) {
         if (c->d_lsp[i]) (void)hipFree(c->d_lsp[i]);
     if (c->d_bad) (void)hipFree(c->d_bad);
     if (c->d_extra) (void)hipFree(c->d_extra);
+    if (c->d_fexp_ws) (void)hipFree(c->d_fexp_ws);
     for (void* q : c->retired) (void)hipFree(q);
     if (c->last_event) (void)hipEventDestroy(c->last_event);
     if (c->ev0) {
@@ -657,6 +664,20 @@ BLSGPU_EXPORT int blsgpu_ctx_set_ls_threshold(blsgpu_ctx* c, size_t pairs, size_
 // fills the chip; what follows (Horner, the product of the partials, the final exponentiation) occupies a few dozen
 // wavefronts.  A server that pipelines calls over several contexts lets the next call's stream wait for this event
 // instead of the end of the call.
+// Calls with at least `results` final exponentiations run them six lanes per result on the register arithmetic
+// (blsgpu_fexp.hip); fewer keep one wavefront each on the VM (lower latency).  (size_t)-1: never.
+BLSGPU_EXPORT int blsgpu_ctx_set_fexp_team_threshold(blsgpu_ctx* c, size_t results) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    c->fexp_team_threshold = results;
+    return 0;
+}
+// Diagnostic (tools/fexp_trace.py): device buffer of BLS28_FEXP_NOPS x 576 bytes that receives the accumulator of
+// result 0 after every operation of the batched final exponentiation's script, or NULL.
+BLSGPU_EXPORT int blsgpu_ctx_set_fexp_trace(blsgpu_ctx* c, void* d_buf) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    c->d_fexp_dbg = d_buf;
+    return 0;
+}
 BLSGPU_EXPORT int blsgpu_ctx_set_bulk_event(blsgpu_ctx* c, void* event) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
     c->bulk_event = (hipEvent_t)event;
@@ -690,6 +711,21 @@ BLSGPU_EXPORT int blsgpu_ctx_trim(blsgpu_ctx* c) {
     return 0;
 }
 
+// `groups` results at once: product of the m partials of each group (partial i of group g at
+// d_in[(i * istride + g * gstride) * 144]) and its final exponentiation, six lanes per result (blsgpu_fexp.hip).
+static bool use_fexp_team(const blsgpu_ctx* c, size_t m, size_t groups) { return groups >= c->fexp_team_threshold && m <= 64; }
+static int launch_fexp_team(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_t istride, size_t gstride, size_t groups, void* d_out_bytes,
+                            hipStream_t st) {
+    using namespace blsgpu;
+    const size_t blocks = (groups + ml::TEAMS - 1) / ml::TEAMS;
+    if (int rc = grow_buffer(c, &c->d_fexp_ws, &c->fexp_ws_cap, blocks * (ml::TEAMS + 1) * BLS28_FEXP_NSLOTS * ml::DENSE_DW * 4)) return rc;
+    KernelTimer kt(c, st, 2);
+    hipLaunchKernelGGL(fx::k_fexp_team, dim3((unsigned)blocks), dim3(64), 0, st, d_in, (uint32_t)m, (uint32_t)istride, (uint32_t)gstride,
+                       (uint32_t)groups, (int32_t*)c->d_fexp_ws, (uint32_t*)d_out_bytes, (uint32_t*)c->d_fexp_dbg);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // For each of `groups` groups fold its m partials down to one; the last launch
 // optionally applies the final exponentiation and writes 576 bytes per group to
 // d_out_bytes, otherwise one partial per group to d_out_partial.  Partial i of
@@ -700,6 +736,7 @@ static int reduce_chain(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_t gr
     int pp = (d_in == c->d_part[0]) ? 1 : 0;
     size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
     if (groups > 65535) return fail(-EINVAL, "too many groups");
+    if (do_final && use_fexp_team(c, m, groups)) return launch_fexp_team(c, d_in, m, istride, gstride, groups, d_out_bytes, st);
     while (true) {
         size_t blocks = (m + REDUCE_PER_BLOCK - 1) / REDUCE_PER_BLOCK;
         if (blocks == 0) blocks = 1;
@@ -1110,9 +1147,13 @@ BLSGPU_EXPORT int blsgpu_final_exp_batch(blsgpu_ctx* c, const uint8_t* in, size_
     hipLaunchKernelGGL(blsgpu::k_bytes_to_partials, dim3(blocks), dim3(REDUCE_WAVES * 64), lds, 0, c->tabs,
                        (const uint32_t*)din, (uint32_t)m, c->d_part[1]);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(blsgpu::k_final_groups, dim3(blocks), dim3(REDUCE_WAVES * 64), lds, 0, c->tabs, c->d_part[1],
-                       1u, (uint32_t)m, (uint32_t*)dout);
-    HIP_TRY(hipGetLastError());
+    if (use_fexp_team(c, 1, m)) {
+        if (int rc2 = launch_fexp_team(c, c->d_part[1], 1, 1, 1, m, dout, 0)) return rc2;
+    } else {
+        hipLaunchKernelGGL(blsgpu::k_final_groups, dim3(blocks), dim3(REDUCE_WAVES * 64), lds, 0, c->tabs, c->d_part[1],
+                           1u, (uint32_t)m, (uint32_t*)dout);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMemcpy(out, dout, m * 576, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1141,6 +1182,7 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1
         // a large batch of small groups: point chains on lane pairs, then one accumulator per group (blsgpu_ml.hip)
         rc = launch_miller_ls(c, d_g1, d_g2, d_inf, gsz, groups, c->d_part[0], st);
         if (rc == 0) {
+            if (use_fexp_team(c, 1, groups)) return launch_fexp_team(c, c->d_part[0], 1, 1, 1, groups, d_out, st);
             size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
             unsigned blocks = (unsigned)((groups + REDUCE_WAVES - 1) / REDUCE_WAVES);
             KernelTimer kt(c, st, 2);
@@ -1160,6 +1202,8 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1
                          : launch_miller(c, d_g1, d_g2, d_inf, n, 1, true, c->d_part[0], st, &bpg);
         if (rc) return rc;
     }
+    if (use_fexp_team(c, team_groups ? 1 : gsz, groups))
+        return launch_fexp_team(c, c->d_part[0], team_groups ? 1 : gsz, 1, team_groups ? 1 : gsz, groups, d_out, st);
     size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
     unsigned blocks = (unsigned)((groups + REDUCE_WAVES - 1) / REDUCE_WAVES);
     {
