@@ -56,7 +56,10 @@ struct blsgpu_ctx {
     size_t mp3_threshold = (size_t)-1; // ... with three pairs per wavefront from here on, two below; -1: the measured schedule
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
-    size_t h2c_reg_threshold = 65536;  // messages from which cofactor clearing runs one message per lane in registers (measured: DESIGN.md 2c)
+    size_t h2c_reg_threshold = 8192;   // messages from which cofactor clearing runs in registers (one message per lane PAIR; measured: DESIGN.md 2c)
+    bool h2c_reg_pairs = true;         // ... on lane pairs (k_h2c_clear_pairs); false: one message per lane (k_h2c_clear_reg)
+    void* d_h2c_ws = nullptr;          // the lane-private point slots of k_h2c_clear_pairs
+    size_t h2c_ws_cap = 0;
     size_t msm_sort_threshold = 16384;  // points from which one G1 sum with scalars uses sorted buckets (k_srt_*)
     size_t horner_np_threshold = 1024; // G2 sums per call from which the window Horner runs several sums per team
     size_t msm_lane_threshold = 65536; // points from which the bucket sums run one (group, chunk, window) per lane
@@ -494,6 +497,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_H2C_REG_PAIRS")) c->h2c_reg_pairs = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_NP_THRESHOLD")) c->horner_np_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_LANE_THRESHOLD")) c->msm_lane_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -610,6 +614,7 @@ BLSGPU_EXPORT void blsgpu_ctx_destroy(blsgpu_ctx* c) {
     if (c->d_bad) (void)hipFree(c->d_bad);
     if (c->d_extra) (void)hipFree(c->d_extra);
     if (c->d_fexp_ws) (void)hipFree(c->d_fexp_ws);
+    if (c->d_h2c_ws) (void)hipFree(c->d_h2c_ws);
     for (void* q : c->retired) (void)hipFree(q);
     if (c->last_event) (void)hipEventDestroy(c->last_event);
     if (c->ev0) {
@@ -1300,6 +1305,10 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
         unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);
         hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)d_out);
+    } else if (c->h2c_reg_pairs) {         // one message per lane pair, the point operations as a script
+        if (int rc2 = grow_buffer(c, &c->d_h2c_ws, &c->h2c_ws_cap, (2 * n + 64) * BLS28_H2C_NSLOTS * 3 * blsgpu::r28::NL * 4)) return rc2;
+        hipLaunchKernelGGL(blsgpu::k_h2c_clear_pairs, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, c->tabs, img, (uint32_t)n,
+                           (uint32_t*)c->d_h2c_ws, (uint32_t*)d_out);
     } else {
         hipLaunchKernelGGL(blsgpu::k_h2c_clear_reg, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)d_out);

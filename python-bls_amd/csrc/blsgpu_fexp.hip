@@ -13,8 +13,8 @@
 //   CSQ   acc <- acc^(2^n)     Granger-Scott squaring of the cyclotomic subgroup: every lane ONE pair of sums of three
 //                              products (operands chosen by the lane's role: x^2 + xi y^2, 2xy, xi 2xy)
 //   CONJ / FROB                f^(q^6) (odd coefficients change sign) / f^(q^i), i = 1, 2, 4: lane-local products by constants
-//   TINV                       the one inversion: of an Fq2 value (coefficient 0), its norm to the fixed power q - 2
-//                              (0 -> 0 as fields_t.py:47-55); the Fq12 inverse itself is products and Frobenius maps:
+//   TINV                       the one inversion: of an Fq2 value (coefficient 0) through its norm and the VM's safegcd
+//                              inversion (0 -> 0 as fields_t.py:47-55); the Fq12 inverse itself is products and Frobenius maps:
 //                              N = f conj(f) in Fq6, t = N N^(q^2) N^(q^4) in Fq2, f^-1 = conj(f) N^(q^2) N^(q^4) t^-1.
 // Used for batches of at least fexp_team_threshold results (blsgpu_api.hip); a single result keeps the VM's latency.
 #pragma once
@@ -126,7 +126,16 @@ __device__ __forceinline__ void tinv(int32_t* __restrict__ fre, int32_t* __restr
 #pragma unroll
     for (int j = 0; j < NL; j++) { re.v[j] = fre[j]; im.v[j] = fim[j]; nim.v[j] = -fim[j]; }
     bls28::fp28_dot2(n.v, re.v, re.v, im.v, im.v);
+    // 1/n by the VM's branch-free safegcd inversion (fq32.h fq_inv, 0 -> 0): ~20 k instructions against ~220 k for
+    // the fixed power n^(q-2) (fq_inverse above, kept for BLSGPU_FEXP_FERMAT builds); the forms differ by 2^8
+#ifdef BLSGPU_FEXP_FERMAT
     const fe ni = fq_inverse(n);
+#else
+    uint32_t w[12], v[12];
+    r28::to_vm(w, n);
+    bls::fq_inv(v, w);
+    const fe ni = r28::from_vm(v);
+#endif
     const fe a = r28::mul(re, ni), b = r28::mul(nim, ni);
 #pragma unroll
     for (int j = 0; j < NL; j++) { fre[j] = t.c == 0u ? a.v[j] : 0; fim[j] = t.c == 0u ? b.v[j] : 0; }

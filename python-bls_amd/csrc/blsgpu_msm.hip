@@ -614,6 +614,20 @@ __device__ __forceinline__ pt padd(const pt& P, const pt& Q) {
     R.Z = dot2(left(z3), right(t4), left(x3), right(t3));
     return R;
 }
+// 2 P, RCB algorithm 9
+__device__ __forceinline__ pt pdbl(const pt& P) {
+    const Lop<1> ly = left(P.Y);
+    const h t0 = sqr(P.Y), t1 = mul(ly, right(P.Z)), t2 = b3(sqr(P.Z)), txy = mul(left(P.X), right(P.Y));
+    const h z8 = mulc_norm<8>(t0);
+    const h d = norm(sub(t0, mulc<3>(t2)));
+    const Lop<1> ld = left(d);
+    pt R;
+    R.X = mul(ld, right(add(txy, txy)));
+    R.Y = dot2(left(t2), right(z8), ld, right(add(t0, t2)));
+    R.Z = mul(left(t1), right(z8));
+    return R;
+}
+__device__ __forceinline__ pt pneg(const pt& P) { return {P.X, norm(neg(P.Y)), P.Z}; }
 __device__ __forceinline__ void st_vm(const pt& r, uint32_t* __restrict__ p) {     // the VM's projective form: 72 dwords
     const h* c[3] = {&r.X, &r.Y, &r.Z};
 #pragma unroll

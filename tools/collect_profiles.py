@@ -64,4 +64,16 @@ for name, dirs in ((RN + "_bench_pmc_summary.csv", ("pmc_fetch", "pmc_write", "p
         f.write("kernel,counter,dispatches,average_per_dispatch\n")
         for k, c, d, x in pmc_rows(dirs):
             f.write("%s,%s,%d,%.6g\n" % (k, c, d, x))
-print(open(os.path.join(P, RN + "_bench_pmc_summary.csv")).read())
+# the line-stream stage's rows once more, stamped with the build and the launch size they were measured on: bench.py
+# reports roofline.traffic only when both match what it runs (never a stale figure)
+import sys
+sys.path.insert(0, ROOT)
+import bench
+pairs = json.loads(json_line(os.path.join(R, "pmc_fetch.json")))["config"]["pairs_per_step_per_gpu"]
+with open(os.path.join(P, RN + "_ls_pmc_summary.csv"), "w") as f:
+    f.write("# build %s pairs %d  (rocprofv3 --pmc, separate passes; KB per dispatch for FETCH_SIZE / WRITE_SIZE)\n" % (bench.source_hash(), pairs))
+    f.write("kernel,counter,dispatches,average_per_dispatch\n")
+    for k, c, d, x in pmc_rows(("pmc_fetch", "pmc_write", "pmc_sq")):
+        if "k_ml_" in k:
+            f.write("%s,%s,%d,%.6g\n" % (k.replace("void ", ""), c, d, x))
+print(open(os.path.join(P, RN + "_ls_pmc_summary.csv")).read())

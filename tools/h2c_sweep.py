@@ -19,7 +19,7 @@ def main():
     uniq = b"".join(H.g2_hash_field_elements(hashlib.sha256(b"cfg-h2c-%d" % i).digest(), util.hash512) for i in range(256))
     want0 = H.g2_affine_bytes(H.hash_to_g2_prehashed(hashlib.sha256(b"cfg-h2c-0").digest(), util.hash512))
     ref = None
-    for n in [int(a) for a in sys.argv[1:]] or [256, 1024, 4096, 16384, 32768, 65536, 262144]:
+    for n in [int(a) for a in sys.argv[1:]] or [256, 1024, 4096, 8192, 16384, 32768, 65536, 262144]:
         tin = torch.frombuffer(bytearray(uniq * (n // 256)), dtype=torch.uint8).to(dev)
         tout = torch.zeros(n * 192, dtype=torch.uint8, device=dev)
         fn = lambda: eng.lib.blsgpu_map_to_g2_dev(eng.h, tin.data_ptr(), n, tout.data_ptr(), 0)

@@ -1,7 +1,7 @@
 # Runs on the GPU box (gpurun): the round's bench lines, rocprofv3 kernel stats and PMC passes.
-# ROUND=r02 bash tools/profile_round.sh ; then python tools/collect_profiles.py here copies the summaries into profiles/.
+# ROUND=r03 bash tools/profile_round.sh ; then ROUND=r03 python tools/collect_profiles.py here copies the summaries into profiles/.
 set -e
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
