@@ -103,6 +103,9 @@ int blsgpu_ctx_set_fexp_team_threshold(blsgpu_ctx *ctx, size_t results);
  * operation of the batched final exponentiation's script (tools/fexp_trace.py compares it with the integer model), or
  * NULL (default). */
 int blsgpu_ctx_set_fexp_trace(blsgpu_ctx *ctx, void *d_buf);
+/* Diagnostic: the first `bytes` bytes of the line records the last line-stream call left in the workspace
+ * (lines[(L * n + pair) * 84] int32, csrc/blsgpu_ml.hip); tools/exact_trace.py compares them with the integer model. */
+int blsgpu_debug_read_lines(blsgpu_ctx *ctx, void *host_buf, size_t bytes);
 
 /* fq_ate_pairing_multi(Ps, Qs) -- fields_t.py:1114-1121 / fields_t_c.pyx:2333-2391.
  * Host buffers in, 576 result bytes out; synchronous.  n == 0 returns one. */

@@ -78,8 +78,6 @@ struct blsgpu_ctx {
     size_t lsp_cap[2] = {0, 0};        // bytes
     void* d_bad = nullptr;             // one byte per pair: left to the slow program
     size_t bad_cap = 0;
-    void* d_extra = nullptr;           // Miller values of the listed pairs (VM form)
-    size_t extra_cap = 0;
     int ls_horner_form = 2;            // 2: one group per wavefront, a product spread over 36 lanes; 1: ten groups per wavefront
     int ls_lines_form = 2;             // 2: the point chains on lane pairs (k_ml_lines2); 1: one pair per lane (k_ml_lines)
     size_t fexp_team_threshold = 256;  // results per call from which the final exponentiations run six lanes each (blsgpu_fexp.hip)
@@ -612,7 +610,6 @@ BLSGPU_EXPORT void blsgpu_ctx_destroy(blsgpu_ctx* c) {
     for (int i = 0; i < 2; i++)
         if (c->d_lsp[i]) (void)hipFree(c->d_lsp[i]);
     if (c->d_bad) (void)hipFree(c->d_bad);
-    if (c->d_extra) (void)hipFree(c->d_extra);
     if (c->d_fexp_ws) (void)hipFree(c->d_fexp_ws);
     if (c->d_h2c_ws) (void)hipFree(c->d_h2c_ws);
     for (void* q : c->retired) (void)hipFree(q);
@@ -674,6 +671,15 @@ BLSGPU_EXPORT int blsgpu_ctx_set_ls_threshold(blsgpu_ctx* c, size_t pairs, size_
 BLSGPU_EXPORT int blsgpu_ctx_set_fexp_team_threshold(blsgpu_ctx* c, size_t results) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
     c->fexp_team_threshold = results;
+    return 0;
+}
+// Diagnostic (tools/exact_trace.py): copies the first `bytes` bytes of the line records of the last line-stream call.
+BLSGPU_EXPORT int blsgpu_debug_read_lines(blsgpu_ctx* c, void* host_buf, size_t bytes) {
+    if (!c || !host_buf) return fail(-EINVAL, "NULL argument");
+    if (bytes > c->lines_cap) return fail(-EINVAL, "more than the buffer holds");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_buf, c->d_lines, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 // Diagnostic (tools/fexp_trace.py): device buffer of BLS28_FEXP_NOPS x 576 bytes that receives the accumulator of
@@ -768,7 +774,7 @@ static int reduce_chain(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_t gr
 // Miller loops of `groups` runs of gsz pairs; returns the partials per group (bpg).
 // Then k_miller_slow: it rewrites the partials of the blocks that met a degenerate pair with the
 // reference-faithful program (normally none: every wavefront leaves at once).
-constexpr unsigned SLOW_GRID = 1024;
+constexpr unsigned SLOW_GRID = 3072;           // three wavefronts per SIMD (166 VGPRs, 10 KB of LDS each)
 // team: 0 = choose by batch size; 2 / 3 = k_miller_mp with that many pairs per wavefront (groups of two or three pairs: one team
 // per group, the group's product comes out of the Miller kernel)
 static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups, bool one_per_block,
@@ -830,7 +836,7 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     if (grow_buffer(c, &c->d_lines, &c->lines_cap, n * ml::LINES * ml::LINE_DW * 4) ||
         (!small && grow_buffer(c, &c->d_lsp[0], &c->lsp_cap[0], groups * cpg * ml::LINES * ml::DENSE_DW * 4)) ||
         (!small && grow_buffer(c, &c->d_lsp[1], &c->lsp_cap[1], groups * ((cpg + FAN - 1) / FAN) * ml::LINES * ml::DENSE_DW * 4)) ||
-        grow_buffer(c, &c->d_bad, &c->bad_cap, n) || grow_buffer(c, &c->d_extra, &c->extra_cap, n * 576) ||
+        grow_buffer(c, &c->d_bad, &c->bad_cap, n) ||
         grow_elems(c, &c->d_degen, &c->degen_cap, n + 2)) {
         (void)hipGetLastError();
         return -ENOMEM;                                    // the caller falls back to the wavefront-VM kernels
@@ -847,10 +853,11 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
                                (const uint32_t*)d_g2, (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
     }
     HIP_TRY(hipGetLastError());
-    {
+    {   // the listed pairs once more with the reference's own formulas: their line records are rewritten (leaves at once
+        // when the list is empty)
         KernelTimer kt(c, st, 3);
-        hipLaunchKernelGGL(k_ml_slow_pairs, dim3(SLOW_GRID), dim3(64), (size_t)SLOW_TEAM_BYTES, st, c->tabs, (const uint32_t*)d_g1,
-                           (const uint32_t*)d_g2, dg, (uint32_t*)c->d_extra);
+        hipLaunchKernelGGL(ml::k_ml_lines_exact, dim3(2048), dim3(64), 0, st, (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n,
+                           (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
     }
     HIP_TRY(hipGetLastError());
     if (small) {
@@ -861,10 +868,6 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
         }
         HIP_TRY(hipGetLastError());
         if (c->bulk_event) HIP_TRY(hipEventRecord(c->bulk_event, st));
-        KernelTimer kt(c, st, 3);
-        hipLaunchKernelGGL(k_ml_fold_extras, dim3((unsigned)groups), dim3(64), (size_t)TEAM_BYTES, st, c->tabs, dg, (const uint32_t*)c->d_extra,
-                           (uint32_t)gsz, d_partials, 144u);
-        HIP_TRY(hipGetLastError());
         return 0;
     }
     size_t teams = groups * cpg * ml::LINES;
@@ -895,12 +898,6 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
         else
             hipLaunchKernelGGL(ml::k_ml_horner_wide, dim3((unsigned)groups), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur],
                                (uint32_t)groups, d_partials, 144u);
-    }
-    HIP_TRY(hipGetLastError());
-    {
-        KernelTimer kt(c, st, 3);
-        hipLaunchKernelGGL(k_ml_fold_extras, dim3((unsigned)groups), dim3(64), (size_t)TEAM_BYTES, st, c->tabs, dg, (const uint32_t*)c->d_extra,
-                           (uint32_t)gsz, d_partials, 144u);
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -21,8 +21,9 @@
 //
 // The value differs from the reference's Miller product by the line scalings (Fq2 factors and w^3 per line) that
 // the final exponentiation removes iff they are non-zero: a pair whose Q is off the twist, flagged,
-// or whose chain ends with Z = 0 is marked in bad[] and listed; k_ml_accum leaves it out, k_ml_slow_pairs computes
-// the reference's own Miller value for it (the VM's slow program) and k_ml_fold_extras multiplies those in.
+// or whose chain ends with Z = 0 is marked in bad[] and listed; k_ml_lines_exact rewrites its line records with the
+// reference's own line values (affine formulas, 0^-1 := 0, the chord step's branches), which k_ml_accum multiplies in
+// like any other line -- their product is the reference's Miller value of that pair itself.
 #pragma once
 
 namespace blsgpu {
@@ -363,6 +364,141 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines2(const 
     }
 }
 
+// ---- the reference's own lines for the listed pairs ---------------------------------------------------------------
+// fq_miller_loop is a total function of the coordinates (fields_t.py:1035-1078, 641-686): affine formulas with
+// 0^-1 := 0 and three branches in the chord step; vmgen/slow_programs.py spells them out and
+// vmgen/linestream_model.exact_pair_lines is this kernel's integer model (it reproduces the reference's Miller value
+// of every pair of tests/golden/pairing_degenerate.json).  The line values are sparse in the w-power basis as well --
+// tangent  py + c3 w^3 + c5 w^5,  chord the same or, on the "vertical" branch,  px + c4 w^4  -- so they are written
+// into the pair's ordinary line records ([c0 | zeros | cA | cB]) and k_ml_accum multiplies them in with the positions
+// (3, 5) / (4, 5) instead of (2, 3): the group's product is then the reference's Miller value of these pairs times
+// the scaled lines of the others.  One pair per lane pair; every inversion is the safegcd routine of fq32.h run by
+// all lanes at once, so a batch made of nothing but such pairs runs at a third of the ordinary rate, not a fiftieth.
+namespace sp {
+__device__ __attribute__((noinline)) fe fq_inv_lane(fe n) {           // 1/n, 0 -> 0 (fields_t.py:47-55)
+    uint32_t w[12], v[12];
+    r28::to_vm(w, n);
+    bls::fq_inv(v, w);
+    return r28::from_vm(v);
+}
+template <int M> __device__ __forceinline__ bool zero2(const S<M>& x) { return is_zero2(mulf(x, r28::fe_one())); }
+// 1/z for z = re + im u: conj(z) / (re^2 + im^2); z with digits below 2^29
+template <int M> __device__ __forceinline__ h inv2(const S<M>& z) {
+    static_assert(2 * M * M <= 8, "");
+    const S<M> p = swp(z);
+    fe n;
+    bls28::fp28_dot2(n.v, z.v, z.v, p.v, p.v);
+    const fe ni = fq_inv_lane(n);
+    S<M> zc;
+#pragma unroll
+    for (int j = 0; j < NL; j++) zc.v[j] = odd() ? -z.v[j] : z.v[j];
+    return mulf(zc, ni);
+}
+// (a0 + a1, a1 - a0): xi^-1 a = this / 2
+template <int M> __device__ __forceinline__ S<2 * M> xisum(const S<M>& a) {
+    const S<M> p = swp(a);
+    S<2 * M> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = odd() ? a.v[j] - p.v[j] : a.v[j] + p.v[j];
+    return r;
+}
+struct Aff { h x, y; };
+// fq2_double_point (fields_t.py:641-646) with the slope; i2y = 1 / (2 ry)
+__device__ __forceinline__ Aff exact_double(const h& rx, const h& ry, const h& i2y, h& lam) {
+    lam = mul(left(mulc_norm<3>(sqr(rx))), right(i2y));
+    // (the differences go through a product by one: x' = lam^2 - 2x is a linear recurrence, digit normalisation alone
+    // would let the VALUE double with every step of the chain)
+    Aff r;
+    r.x = mulf(sub(sqr(lam), add(rx, rx)), r28::fe_one());
+    r.y = mulf(sub(mul(left(lam), right(norm(sub(rx, r.x)))), ry), r28::fe_one());
+    return r;
+}
+}  // namespace sp
+
+__global__ void __launch_bounds__(64) k_ml_lines_exact(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
+                                                       int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg) {
+    using namespace sp;
+    const uint32_t total = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
+    if (blockIdx.x * 32u >= total) return;
+    const uint32_t part = threadIdx.x & 1u;
+    const int32_t one[NL] = BLS28_ONE;
+    const int32_t halfc[NL] = BLS28_HALF;
+    fe half;
+#pragma unroll
+    for (int j = 0; j < NL; j++) half.v[j] = halfc[j];
+#pragma unroll 1
+    for (uint32_t e0 = blockIdx.x * 32u; e0 < total; e0 += gridDim.x * 32u) {
+        const uint32_t er = e0 + (threadIdx.x >> 1);
+        const uint32_t e = er < total ? er : total - 1u;              // spare lane pairs repeat the last entry
+        const uint32_t p = dg.blocks[e];
+        const uint32_t* s1 = g1 + (size_t)p * 24;
+        const uint32_t* s2 = g2 + (size_t)p * 48 + part * 12;
+        const bool qinf = q_flagged(dg, p);
+        const fe px = load_coord(s1), py = load_coord(s1 + 12);
+        const fe hnpx = r28::mul(r28::neg(px), half);                 // -px / 2
+        const h qx = load_part(s2), qy = load_part(s2 + 24);
+        h rx = qx, ry = qy;
+        int32_t* rec = lines + (size_t)p * LINE_DW;
+        const size_t lstride = (size_t)n * LINE_DW;
+        uint32_t flag = 1u, chord = 0u;
+        h c0;
+#pragma unroll 1
+        for (int bit = 62; bit >= 0; bit--) {
+            {   // tangent: line py - lam px / w - (ry - lam rx) / w^3  (fq2_double_line_eval, fields_t.py:1035-1049)
+                h lam;
+                const Aff d = exact_double(rx, ry, inv2(add(ry, ry)), lam);
+                const h l0 = norm(sub(mul(left(lam), right(rx)), ry));
+#pragma unroll
+                for (int j = 0; j < NL; j++) c0.v[j] = part ? 0 : py.v[j];
+                store_part(rec, 0, c0);
+                store_part(rec, 1, mulf(xisum(l0), half));            // w^3:  xi^-1 (lam rx - ry)
+                store_part(rec, 2, mulf(xisum(lam), hnpx));           // w^5:  xi^-1 (-lam px)
+                rx = d.x; ry = d.y;
+                rec += lstride;
+            }
+            if ((ML_NX >> bit) & 1ull) {
+                // chord: fq2_add_line_eval (fields_t.py:1052-1078) and fq2_add_points (:673-686)
+                const h dd = norm(sub(qx, rx)), u = norm(sub(ry, qy));
+                const bool n1 = !zero2(dd), same = !n1 && zero2(u);
+                const bool vert = zero2(add(rx, qx)) && zero2(add(ry, qy));
+                const h D = inv2(dd);
+                const h mu = mul(left(norm(neg(u))), right(D));
+                const h tt = dot2(left(qy), right(rx), left(norm(neg(ry))), right(qx));
+                const h nu = mul(left(norm(neg(tt))), right(D));
+                const h av = mulf(xisum(neg(rx)), half);              // vertical: px - rx / w^2 -> w^4: xi^-1 (-rx)
+                const h an = mulf(xisum(neg(nu)), half);              // else w^3: xi^-1 (-nu)
+                const h bn = mulf(xisum(mu), hnpx);                   //      w^5: xi^-1 (-mu px)
+                h a, b;
+#pragma unroll
+                for (int j = 0; j < NL; j++) {
+                    c0.v[j] = part ? 0 : (vert ? px.v[j] : py.v[j]);
+                    a.v[j] = vert ? av.v[j] : an.v[j];
+                    b.v[j] = vert ? 0 : bn.v[j];
+                }
+                store_part(rec, 0, c0);
+                store_part(rec, 1, a);
+                store_part(rec, 2, b);
+                if (vert) flag |= 2u << chord;
+                chord++;
+                rec += lstride;
+                // R + Q: the chord point unless rx = qx; then the double if also ry = qy, else (0, 0); a flagged Q leaves R
+                const h xc = mulf(sub(sub(sqr(mu), rx), qx), r28::fe_one());
+                const h yc = mulf(sub(mul(left(mu), right(norm(sub(rx, xc)))), ry), r28::fe_one());
+                h lam;
+                const Aff d = exact_double(rx, ry, inv2(add(ry, ry)), lam);
+                if (!qinf) {
+#pragma unroll
+                    for (int j = 0; j < NL; j++) {
+                        rx.v[j] = n1 ? xc.v[j] : (same ? d.x.v[j] : 0);
+                        ry.v[j] = n1 ? yc.v[j] : (same ? d.y.v[j] : 0);
+                    }
+                }
+            }
+        }
+        if (part == 0u && er < total) bad[p] = (uint8_t)flag;
+    }
+}
+
 // ---- stages B / merge / Horner: six lanes per accumulator -----------------------------------------------------------
 struct Team {
     uint32_t c;            // the lane's coefficient: power of w
@@ -437,6 +573,42 @@ __device__ __forceinline__ void mul3(int32_t* __restrict__ re, int32_t* __restri
     bls28::fp28_dot6(re, X0.re, y0r, X0.nim, y0i, X1.re, y1r, X1.nim, y1i, X2.re, y2r, X2.nim, y2i);
     bls28::fp28_dot6(im, X0.re, y0i, X0.im, y0r, X1.re, y1i, X1.im, y1r, X2.re, y2i, X2.im, y2r);
 }
+// the same with the positions of the second and third term at run time: a LINE is f_0-term + w^jA + w^jB with
+// (jA, jB) = (2, 3) for the scaled lines of k_ml_lines2 and (3, 5) / (4, 5) for the reference's own line values
+// (k_ml_lines_exact: coefficient 0 in Fq, its imaginary part stored as zeros).  Column bound as mul3<0, 2, 3>: 2 + 3 + 3.
+__device__ __forceinline__ void fetch_rt(Xop& X, const Pub& P, const Team& t, uint32_t J) {
+    const uint32_t src = t.c >= J ? t.c - J : t.c + 6u - J;
+    const uint32_t addr = t.base4 + src * 4u;
+    const bool wrap = t.c < J;
+    int32_t a[NL], b[NL];
+    bperm14(a, P.re, addr); bperm14(b, P.xre, addr);
+#pragma unroll
+    for (int j = 0; j < NL; j++) X.re[j] = wrap ? b[j] : a[j];
+    bperm14(a, P.im, addr); bperm14(b, P.xim, addr);
+#pragma unroll
+    for (int j = 0; j < NL; j++) X.im[j] = wrap ? b[j] : a[j];
+    bperm14(a, P.nim, addr); bperm14(b, P.nxim, addr);
+#pragma unroll
+    for (int j = 0; j < NL; j++) X.nim[j] = wrap ? b[j] : a[j];
+}
+__device__ __forceinline__ void mul_line(int32_t* __restrict__ re, int32_t* __restrict__ im, const Pub& P, const Team& t, uint32_t jA, uint32_t jB,
+                                         const int32_t* y0r, const int32_t* y0i, const int32_t* y1r, const int32_t* y1i,
+                                         const int32_t* y2r, const int32_t* y2i) {
+    Xop X0, X1, X2;
+    fetch<0>(X0, P, t);
+    fetch_rt(X1, P, t, jA);
+    fetch_rt(X2, P, t, jB);
+    bls28::fp28_dot6(re, X0.re, y0r, X0.nim, y0i, X1.re, y1r, X1.nim, y1i, X2.re, y2r, X2.nim, y2i);
+    bls28::fp28_dot6(im, X0.re, y0i, X0.im, y0r, X1.re, y1i, X1.im, y1r, X2.re, y2i, X2.im, y2r);
+}
+// positions of line L of a pair whose flag byte is `flag` (0: scaled lines; else bit 0 set and bit 1 + c = chord c took the
+// reference's "vertical" branch)
+__device__ __forceinline__ void line_positions(uint32_t L, uint32_t flag, uint32_t& jA, uint32_t& jB) {
+    const int ci = L == 1u ? 0 : (L == 4u ? 1 : (L == 8u ? 2 : (L == 18u ? 3 : (L == 51u ? 4 : -1))));
+    const bool vert = ci >= 0 && ((flag >> (1 + ci)) & 1u) != 0u;
+    jA = flag ? (vert ? 4u : 3u) : 2u;
+    jB = flag ? 5u : 3u;
+}
 // f <- f g for a dense g given as 12 x 14 dwords (w-power order) behind `ld` (global or LDS): two half sums, added
 // and normalised (value in (-2q, 4q), digits below 2^28: a valid operand)
 template <class LD>
@@ -498,9 +670,10 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const in
     const int32_t* base = lines + ((size_t)L * n + first) * LINE_DW;
 #pragma unroll 1
     for (uint32_t i = 0; __any(i < cnt); i++) {
-        const bool act = i < cnt;
-        const uint32_t ii = act ? i : 0u;
-        const bool use = act && bad[first + ii] == 0;
+        const bool use = i < cnt;
+        const uint32_t ii = use ? i : 0u;
+        uint32_t jA, jB;
+        line_positions(L, bad[first + ii], jA, jB);
         const int4* rec = reinterpret_cast<const int4*>(base + (size_t)ii * LINE_DW);
         int32_t y[6][NL];
         {
@@ -517,7 +690,7 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const in
         Pub P;
         publish<false>(P, fre, fim);
         int32_t re[NL], im[NL];
-        mul3<0, 2, 3>(re, im, P, t, y[0], y[1], y[2], y[3], y[4], y[5]);
+        mul_line(re, im, P, t, jA, jB, y[0], y[1], y[2], y[3], y[4], y[5]);
 #pragma unroll
         for (int k = 0; k < NL; k++) { fre[k] = use ? re[k] : fre[k]; fim[k] = use ? im[k] : fim[k]; }
     }
@@ -632,7 +805,8 @@ __global__ void __launch_bounds__(64, 2) k_ml_small(const int32_t* __restrict__ 
         const int32_t* base = lines + ((size_t)L * n + first) * LINE_DW;
 #pragma unroll 1
         for (uint32_t i = 0; i < gsz; i++) {
-            const bool use = bad[first + i] == 0;
+            uint32_t jA, jB;
+            line_positions(L, bad[first + i], jA, jB);
             const int4* rec = reinterpret_cast<const int4*>(base + (size_t)i * LINE_DW);
             int32_t y[6][NL];
             {
@@ -649,9 +823,9 @@ __global__ void __launch_bounds__(64, 2) k_ml_small(const int32_t* __restrict__ 
             Pub P;
             publish<true>(P, fre, fim);                    // f may be a dense product's sum: normalised xi forms
             int32_t re[NL], im[NL];
-            mul3<0, 2, 3>(re, im, P, t, y[0], y[1], y[2], y[3], y[4], y[5]);
+            mul_line(re, im, P, t, jA, jB, y[0], y[1], y[2], y[3], y[4], y[5]);
 #pragma unroll
-            for (int k = 0; k < NL; k++) { fre[k] = use ? re[k] : fre[k]; fim[k] = use ? im[k] : fim[k]; }
+            for (int k = 0; k < NL; k++) { fre[k] = re[k]; fim[k] = im[k]; }
         }
     }
     if (valid) {
@@ -751,45 +925,4 @@ __global__ void __launch_bounds__(64) k_ml_horner_wide(const int32_t* __restrict
 }
 }  // namespace ml
 
-// The listed pairs through the reference-faithful program: extra[e] = fq_miller_loop of pair dg.blocks[e] (144 words).
-__global__ void __launch_bounds__(64) k_ml_slow_pairs(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
-                                                      DegenList dg, uint32_t* __restrict__ extra) {
-    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
-    if (blockIdx.x >= total) return;
-    team_init_consts(T, team, lane);
-    for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
-        const uint32_t pair = __builtin_amdgcn_readfirstlane(dg.blocks[e]);
-        wave_fence();
-        miller_exact_one(T, team, lane, g1, g2, dg.inf, pair);
-        for (uint32_t i = lane; i < 144; i += 64) extra[(size_t)e * 144 + i] = team[F_DW + i];
-    }
-}
-// Team g multiplies the extras of its group's pairs into the group's partial (pstride words apart).
-__global__ void __launch_bounds__(64) k_ml_fold_extras(VmTables T, DegenList dg, const uint32_t* __restrict__ extra, uint32_t gsz,
-                                                       uint32_t* __restrict__ partials, uint32_t pstride) {
-    uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
-    if (total == 0) return;
-    const uint32_t g = blockIdx.x;
-    team_init_consts(T, team, lane);
-    uint32_t* part = partials + (size_t)g * pstride;
-    for (uint32_t i = lane; i < 144; i += 64) team[F_DW + i] = part[i];
-    bool touched = false;
-    for (uint32_t e = 0; e < total; e++) {
-        const uint32_t pair = __builtin_amdgcn_readfirstlane(dg.blocks[e]);
-        if (pair / gsz != g) continue;
-        wave_fence();
-        for (uint32_t i = lane; i < 144; i += 64) team[R1_DW + i] = extra[(size_t)e * 144 + i];
-        wave_fence();
-        run_rounds<true>(T, T.segflat + BLSVM_SEGF_MUL_0_1_OFF, BLSVM_SEGF_MUL_0_1_LEN, 0, lane);
-        touched = true;
-    }
-    if (touched) {
-        wave_fence();
-        for (uint32_t i = lane; i < 144; i += 64) part[i] = team[F_DW + i];
-    }
-}
 }  // namespace blsgpu

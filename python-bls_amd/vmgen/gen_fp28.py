@@ -134,6 +134,7 @@ def generate(path=None):
     out.append(arr("BLS28_Q", Q, "q"))
     out.append(arr("BLS28_ONE", R % Q, "R mod q: the Montgomery form of 1"))
     out.append(arr("BLS28_R2", R * R % Q, "R^2 mod q: content c (an integer < 2^391) times this is c R"))
+    out.append(arr("BLS28_HALF", (Q + 1) // 2 * R % Q, "R / 2 mod q: the Montgomery form of 1/2"))
     out.append(arr("BLS28_FROM_VM", (1 << 400) % Q, "2^400 mod q: a value of the wavefront VM (x 2^384, 12 x 32 bits) times this is x R"))
     out.append(arr("BLS28_TO_VM", (1 << 384) % Q, "2^384 mod q: x R times this is x 2^384, the VM's Montgomery form"))
     out.append("// 2^384 mod q as 12 x 32-bit words: the VM's Montgomery form of 1\n#define BLS28_VM_ONE_WORDS {%s}\n" % ", ".join("0x%08xu" % ((((1 << 384) % Q) >> (32 * i)) & 0xFFFFFFFF) for i in range(12)))

@@ -201,3 +201,85 @@ def miller_product(pairs, chunk=4):
         assert ok, "degenerate pair: the slow program's business"
         all_lines.append(lines)
     return to_flat12(horner(group_line_products(all_lines, chunk)))
+
+
+# ---- the reference-faithful lines (degenerate pairs) ---------------------------------------------------------------------
+# The reference (fields_t.py:1035-1078, 641-686) is a total function of the coordinates: affine formulas with 0^-1 := 0
+# and three branches in the chord step (vmgen/slow_programs.py spells them out).  Its line values are sparse in the
+# w-power basis too: a tangent line is  py + c3 w^3 + c5 w^5  (c0 = py in Fq; 1/w^3 = xi^-1 w^3, 1/w = xi^-1 w^5), a
+# chord line the same or, on the "vertical" branch,  px + c4 w^4  (1/w^2 = xi^-1 w^4).  k_ml_lines_exact writes them
+# into the pair's line records, k_ml_accum multiplies them in like any other line, and the product over a group is the
+# reference's own Miller value times the scaled lines of the ordinary pairs.
+def inv_fq(a):
+    return pow(a % Q, Q - 2, Q)                    # 0 -> 0
+
+
+def inv2(z):
+    ni = inv_fq(z[0] * z[0] + z[1] * z[1])
+    return (z[0] * ni % Q, (-z[1]) * ni % Q)
+
+
+def xi_inv2(a):
+    """a / (1 + u) = a (1 - u) / 2"""
+    half = (Q + 1) // 2
+    return ((a[0] + a[1]) * half % Q, (a[1] - a[0]) * half % Q)
+
+
+def neg2(a):
+    return ((-a[0]) % Q, (-a[1]) % Q)
+
+
+def exact_double(rx, ry):
+    lam = mul2(scl2(mul2(rx, rx), 3), inv2(scl2(ry, 2)))
+    xr = sub2(mul2(lam, lam), scl2(rx, 2))
+    return lam, (xr, sub2(mul2(lam, sub2(rx, xr)), ry))
+
+
+def exact_pair_lines(P, Qa, qinf=False):
+    """[(positions, coefficients)] for the 68 lines of fq_miller_loop(P, Q): coefficient 0 is (c, 0) with c in Fq"""
+    px, py = P
+    qx, qy = Qa
+    rx, ry = qx, qy
+    out = []
+    for s, kind in line_schedule():
+        if kind == "t":
+            lam, Rn = exact_double(rx, ry)
+            l0 = sub2(mul2(lam, rx), ry)
+            l1 = neg2(scl2(lam, px))
+            out.append(((0, 3, 5), ((py % Q, 0), xi_inv2(l0), xi_inv2(l1))))
+            rx, ry = Rn
+        else:
+            d, u = sub2(qx, rx), sub2(ry, qy)
+            D = inv2(d)
+            n1 = d != (0, 0)
+            same = (not n1) and u == (0, 0)
+            vert = add2(rx, qx) == (0, 0) and add2(ry, qy) == (0, 0)
+            mu = mul2(neg2(u), D)
+            nu = neg2(mul2(sub2(mul2(qy, rx), mul2(ry, qx)), D))
+            if vert:
+                out.append(((0, 4, 5), ((px % Q, 0), xi_inv2(neg2(rx)), (0, 0))))
+            else:
+                out.append(((0, 3, 5), ((py % Q, 0), xi_inv2(neg2(nu)), xi_inv2(neg2(scl2(mu, px))))))
+            xc = sub2(sub2(mul2(mu, mu), rx), qx)
+            yc = sub2(mul2(mu, sub2(rx, xc)), ry)
+            _, (xd, yd) = exact_double(rx, ry)
+            new = (xc, yc) if n1 else ((xd, yd) if same else ((0, 0), (0, 0)))
+            if not qinf:
+                rx, ry = new
+    return out
+
+
+def exact_miller(P, Qa, qinf=False):
+    """fq_miller_loop(P, Q) itself (w-power order) as Horner over the exact lines"""
+    f = None
+    for (s, kind), (pos, cf) in zip(line_schedule(), exact_pair_lines(P, Qa, qinf)):
+        m = [(0, 0)] * 6
+        for p, c in zip(pos, cf):
+            m[p] = c
+        if f is None:
+            f = m
+            continue
+        if kind == "t":
+            f = mul_dense(f, f)
+        f = mul_dense(f, m)
+    return f

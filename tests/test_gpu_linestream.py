@@ -1,5 +1,5 @@
-"""Parity of the LINE-STREAM multi-pairing (csrc/blsgpu_ml.hip: k_ml_lines -> k_ml_accum -> k_ml_merge ->
-k_ml_horner, degenerate pairs through k_ml_slow_pairs / k_ml_fold_extras) through the C ABI, with the path FORCED
+"""Parity of the LINE-STREAM multi-pairing (csrc/blsgpu_ml.hip: k_ml_lines2 -> k_ml_accum -> k_ml_merge ->
+k_ml_horner_wide, degenerate pairs' lines rewritten by k_ml_lines_exact) through the C ABI, with the path FORCED
 for every size (blsgpu_ctx_set_ls_threshold), against the reference's golden vectors and the CPU oracle.  Bit-exact
 (576-byte canonical Fq12 serialisations).  Needs an MI355X."""
 import hashlib
@@ -65,8 +65,7 @@ def test_edge_cases(ls, golden, name):
 
 def test_degenerate_pairs(ls, golden):
     """every reference-generated case on which the reference's special cases decide: the lines kernel must flag the
-    pair (Q flagged / off the twist / final Z = 0), the product kernel must leave it out and the slow program's value
-    must be folded in"""
+    pair (Q flagged / off the twist / final Z = 0) and k_ml_lines_exact must write the reference's own line values"""
     for name, v in golden("pairing_degenerate.json")["cases"].items():
         n = len(v["g1"])
         assert ls.pairing_multi(cat(v["g1"]), cat(v["g2"]), n, flags(v)).hex() == v["out"], name
@@ -109,6 +108,17 @@ def test_all_degenerate_batch(ls, golden, oracle):
     assert ls.pairing_multi(a, b, n) == oracle.pairing_multi(a, b, n, threads=8)
     out = ls.pairing_multi_batch(a, b, 6, 8)
     assert out == oracle.pairing_multi(a[:96 * 6], b[:192 * 6], 6) * 8
+
+
+def test_4096_low_order_pairs_against_the_oracle(ls, golden, oracle):
+    """a batch of nothing but low-order / off-curve pairs: every pair's line records are rewritten by
+    k_ml_lines_exact with the reference's own line values; one 4096-pair call and 32 groups of 128"""
+    d = golden("pairing_degenerate.json")["cases"]
+    names = ["ord13", "ord11_embedded", "off_curve", "qy_zero", "ord3_embedded", "ord13_neg", "qx_zero", "ord13_px_zero"]
+    a = b"".join(bytes.fromhex(d[k]["g1"][0]) for k in names) * 512
+    b = b"".join(bytes.fromhex(d[k]["g2"][0]) for k in names) * 512
+    assert ls.pairing_multi(a, b, 4096) == oracle.pairing_multi(a, b, 4096, threads=8)
+    assert ls.pairing_multi_batch(a, b, 128, 32) == oracle.pairing_multi(a[:96 * 128], b[:192 * 128], 128, threads=8) * 32
 
 
 @pytest.mark.parametrize("teams", [1, 700, 4000, 10 ** 9])

@@ -55,3 +55,18 @@ def test_degenerate_pairs_are_flagged():
         c = cases[name]
         p = _pairs(cat(c["g1"]), cat(c["g2"]), 1)[0]
         assert M.pair_lines(*p)[1] is False, name
+
+
+def test_exact_lines_reproduce_the_reference_miller_values():
+    """exact_pair_lines / exact_miller (the model of k_ml_lines_exact): fq_miller_loop itself, bit for bit, for the
+    generators and for EVERY pair of the reference-generated degenerate cases (flags included)"""
+    with open(os.path.join(GOLDEN, "pairing.json")) as f:
+        g = json.load(f)["gen"]
+    p = _pairs(bytes.fromhex(g["g1"]), bytes.fromhex(g["g2"]), 1)[0]
+    assert _bytes(M.to_flat12(M.exact_miller(*p))).hex() == g["miller"]
+    with open(os.path.join(GOLDEN, "pairing_degenerate.json")) as f:
+        cases = json.load(f)["cases"]
+    for name, c in cases.items():
+        for i in range(len(c["g1"])):
+            p = _pairs(bytes.fromhex(c["g1"][i]), bytes.fromhex(c["g2"][i]), 1)[0]
+            assert _bytes(M.to_flat12(M.exact_miller(*p, bool(c["inf"][i][1])))).hex() == c["miller"][i], (name, i)
