@@ -18,9 +18,9 @@ for c in c4 c5 h2c; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt_$c -o kt --output-format csv -- python3 bench.py --config $c --steps 2 > $O/kt_$c.json 2> $O/kt_$c.err
 done
 echo "kernel traces done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency > $O/pmc_write.json 2> $O/pmc_write.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS -d $O/pmc_sq -o s --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency > $O/pmc_sq.json 2> $O/pmc_sq.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency --no-secondary > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency --no-secondary > $O/pmc_write.json 2> $O/pmc_write.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS -d $O/pmc_sq -o s --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency --no-secondary > $O/pmc_sq.json 2> $O/pmc_sq.err
 for c in c4 c5 h2c; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS -d $O/pmc_$c -o p --output-format csv -- python3 bench.py --config $c --steps 1 > $O/pmc_$c.json 2> $O/pmc_$c.err || echo "pmc $c failed"
 done
