@@ -740,6 +740,122 @@ EXPORT int oracle_pairing_multi(const uint8_t *g1, const uint8_t *g2, const uint
     return oracle_pairing_multi_mt(g1, g2, inf, n, 1, out);
 }
 
+/* ------------------------------------------------ the FAST-ALGORITHM flavour ------
+ * The second CPU baseline bench.py reports (`cpu_baseline.fast`): the same multi-pairing with the algorithm the GPU
+ * path uses instead of the reference's -- the twist point in homogeneous projective coordinates (no inversions),
+ * lines scaled by factors the final exponentiation removes and kept sparse (l0 + l1 v + l4 v w; formulas of
+ * python-bls_amd/vmgen/programs.t_double / t_add), ONE accumulator per thread whose squaring is shared by all the
+ * thread's pairs, sparse products (13 Fq2 products).  Valid for ordinary pairs (Q on the twist in the prime-order
+ * subgroup, nothing flagged): a timing baseline, checked against the reference-algorithm flavour on its sample. */
+typedef struct { fq2 X, Y, Z; } g2proj;
+typedef struct { fq2 l0, l1, l4; } sline;
+static void fq2_sqr(fq2 *r, const fq2 *a) { fq2_mul(r, a, a); }
+static void fq2_mul_fq(fq2 *r, const fq2 *a, const fq *k) { fq_mul(&r->c0, &a->c0, k); fq_mul(&r->c1, &a->c1, k); }
+static void fast_tangent(g2proj *T, sline *l, const fq *px3n, const fq *py) {
+    fq2 A, B, C, XX, YZ, E, F3, H, G, t, u;
+    fq2_mul(&A, &T->X, &T->Y); fq2_sqr(&B, &T->Y); fq2_sqr(&C, &T->Z); fq2_sqr(&XX, &T->X); fq2_mul(&YZ, &T->Y, &T->Z);
+    fq2_mul_xi(&E, &C); fq2_mul_small(&E, &E, 12);           /* 3 b' Z^2, b' = 4 xi */
+    fq2_mul_small(&F3, &E, 3);
+    fq2_add(&H, &YZ, &YZ);
+    fq2_sub(&l->l0, &B, &E); fq2_mul_fq(&l->l1, &XX, px3n); fq2_mul_fq(&l->l4, &H, py);
+    fq2_sub(&t, &B, &F3); fq2_mul(&t, &A, &t); fq2_add(&T->X, &t, &t);
+    fq2_add(&G, &B, &F3); fq2_sqr(&t, &G); fq2_sqr(&u, &E); fq2_mul_small(&u, &u, 12); fq2_sub(&T->Y, &t, &u);
+    fq2_mul(&t, &B, &H); fq2_mul_small(&T->Z, &t, 4);
+}
+static void fast_chord(g2proj *T, sline *l, const g2aff *Q, const fq *px, const fq *py) {
+    fq2 th, la, C, D, E, Fz, G, H, t, u;
+    fq2_mul(&t, &Q->y, &T->Z); fq2_sub(&th, &T->Y, &t);
+    fq2_mul(&t, &Q->x, &T->Z); fq2_sub(&la, &T->X, &t);
+    fq2_sqr(&C, &th); fq2_sqr(&D, &la); fq2_mul(&E, &la, &D); fq2_mul(&Fz, &T->Z, &C); fq2_mul(&G, &T->X, &D);
+    fq2_add(&H, &E, &Fz); fq2_sub(&H, &H, &G); fq2_sub(&H, &H, &G);
+    fq2_mul(&t, &th, &Q->x); fq2_mul(&u, &la, &Q->y); fq2_sub(&l->l0, &t, &u);
+    fq2_mul_fq(&t, &th, px); fq2_neg(&l->l1, &t); fq2_mul_fq(&l->l4, &la, py);
+    fq2_sub(&t, &G, &H); fq2_mul(&t, &th, &t); fq2_mul(&u, &E, &T->Y); fq2_sub(&u, &t, &u);
+    fq2_mul(&T->X, &la, &H); fq2_mul(&T->Z, &T->Z, &E); T->Y = u;
+}
+/* x (c0 + c1 v), 5 Fq2 products; x (c1 v), 3 */
+static void fq6_mul_by_01(fq6 *r, const fq6 *x, const fq2 *c0, const fq2 *c1) {
+    fq2 v0, v1, m12, m01, m02, t, s;
+    fq2_mul(&v0, &x->c0, c0); fq2_mul(&v1, &x->c1, c1);
+    fq2_add(&t, &x->c1, &x->c2); fq2_mul(&m12, &t, c1);
+    fq2_add(&t, &x->c0, &x->c1); fq2_add(&s, c0, c1); fq2_mul(&m01, &t, &s);
+    fq2_add(&t, &x->c0, &x->c2); fq2_mul(&m02, &t, c0);
+    fq2_sub(&t, &m12, &v1); fq2_mul_xi(&t, &t); fq2_add(&r->c0, &t, &v0);
+    fq2_sub(&t, &m01, &v0); fq2_sub(&r->c1, &t, &v1);
+    fq2_sub(&t, &m02, &v0); fq2_add(&r->c2, &t, &v1);
+}
+static void fq6_mul_by_1(fq6 *r, const fq6 *x, const fq2 *c1) {
+    fq2 a, b, c;
+    fq2_mul(&a, &x->c2, c1); fq2_mul_xi(&a, &a); fq2_mul(&b, &x->c0, c1); fq2_mul(&c, &x->c1, c1);
+    r->c0 = a; r->c1 = b; r->c2 = c;
+}
+/* f (l0 + l1 v + l4 v w): 13 Fq2 products */
+static void fq12_mul_by_014(fq12 *f, const sline *l) {
+    fq6 t0, t1, m, s;
+    fq2 c;
+    fq6_mul_by_01(&t0, &f->c0, &l->l0, &l->l1);
+    fq6_mul_by_1(&t1, &f->c1, &l->l4);
+    fq6_add(&s, &f->c0, &f->c1); fq2_add(&c, &l->l1, &l->l4);
+    fq6_mul_by_01(&m, &s, &l->l0, &c);
+    fq6_mul_v(&s, &t1); fq6_add(&f->c0, &t0, &s);
+    fq6_sub(&m, &m, &t0); fq6_sub(&f->c1, &m, &t1);
+}
+typedef struct { const uint8_t *g1, *g2; size_t lo, hi; fq12 prod; } fast_job;
+static void *fast_worker(void *arg) {
+    fast_job *j = (fast_job *)arg;
+    size_t n = j->hi - j->lo;
+    fq12 f = FQ12_ONE;
+    if (n) {
+        g2proj *T = (g2proj *)malloc(n * sizeof(g2proj));
+        g2aff *Q = (g2aff *)malloc(n * sizeof(g2aff));
+        fq *px = (fq *)malloc(4 * n * sizeof(fq));               /* px, py, -3 px per pair */
+        for (size_t i = 0; i < n; i++) {
+            g1aff P;
+            g1_from_bytes(&P, j->g1 + 96 * (j->lo + i));
+            g2_from_bytes(&Q[i], j->g2 + 192 * (j->lo + i));
+            T[i].X = Q[i].x; T[i].Y = Q[i].y; T[i].Z = FQ2_ONE;
+            px[4 * i] = P.x; px[4 * i + 1] = P.y;
+            fq_mul_small(&px[4 * i + 2], &P.x, 3); fq_neg(&px[4 * i + 2], &px[4 * i + 2]);
+        }
+        int nbits = 64;
+        while (!((ORC_NX >> (nbits - 1)) & 1)) nbits--;
+        sline l;
+        for (int b = nbits - 2; b >= 0; b--) {
+            fq12_mul(&f, &f, &f);                                /* one squaring for all the thread's pairs */
+            for (size_t i = 0; i < n; i++) { fast_tangent(&T[i], &l, &px[4 * i + 2], &px[4 * i + 1]); fq12_mul_by_014(&f, &l); }
+            if ((ORC_NX >> b) & 1)
+                for (size_t i = 0; i < n; i++) { fast_chord(&T[i], &l, &Q[i], &px[4 * i], &px[4 * i + 1]); fq12_mul_by_014(&f, &l); }
+        }
+        free(T); free(Q); free(px);
+    }
+    j->prod = f;
+    return NULL;
+}
+EXPORT int oracle_pairing_multi_fast(const uint8_t *g1, const uint8_t *g2, size_t n, int threads, uint8_t out[576]) {
+    ensure_init();
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+    fast_job *jobs = (fast_job *)calloc((size_t)threads, sizeof(fast_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -12; }
+    for (int t = 0; t < threads; t++) {
+        jobs[t].g1 = g1; jobs[t].g2 = g2;
+        jobs[t].lo = n * (size_t)t / (size_t)threads;
+        jobs[t].hi = n * (size_t)(t + 1) / (size_t)threads;
+    }
+    if (threads == 1) fast_worker(&jobs[0]);
+    else {
+        for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, fast_worker, &jobs[t]);
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    }
+    fq12 prod = FQ12_ONE, r;
+    for (int t = 0; t < threads; t++) fq12_mul(&prod, &prod, &jobs[t].prod);
+    final_exp(&r, &prod);
+    fq12_to_bytes(out, &r);
+    free(jobs); free(th);
+    return 0;
+}
+
 /* field operations for the KAT tests: degree in {1,2,6,12}; op: 0 add, 1 sub,
  * 2 mul, 3 neg, 4 inv.  b is ignored for unary ops. */
 EXPORT int oracle_field_op(int degree, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {

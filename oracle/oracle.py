@@ -27,6 +27,7 @@ def lib():
         L.oracle_line_eval.argtypes = [c_p, c_p, c_p, c_p]
         L.oracle_pairing_multi.argtypes = [c_p, c_p, c_p, ctypes.c_size_t, c_p]
         L.oracle_pairing_multi_mt.argtypes = [c_p, c_p, c_p, ctypes.c_size_t, ctypes.c_int, c_p]
+        L.oracle_pairing_multi_fast.argtypes = [c_p, c_p, ctypes.c_size_t, ctypes.c_int, c_p]
         L.oracle_field_op.argtypes = [ctypes.c_int, ctypes.c_int, c_p, c_p, c_p]
         L.oracle_qi_pow.argtypes = [ctypes.c_int, c_p, ctypes.c_int, c_p]
         L.oracle_fq12_pow.argtypes = [c_p, c_p, ctypes.c_size_t, c_p]
@@ -66,6 +67,15 @@ def pairing_multi(g1: bytes, g2: bytes, n: int, threads: int = 1, inf: bytes = N
     assert inf is None or len(inf) == 2 * n
     o = _out(576)
     assert lib().oracle_pairing_multi_mt(g1, g2, inf, n, threads, o) == 0
+    return o.raw
+
+
+def pairing_multi_fast(g1: bytes, g2: bytes, n: int, threads: int = 1) -> bytes:
+    """the fast-algorithm CPU flavour (projective twist point, sparse lines, one shared squaring per thread): ordinary
+    pairs only -- a timing baseline, same result as pairing_multi for them"""
+    assert len(g1) == 96 * n and len(g2) == 192 * n
+    o = _out(576)
+    assert lib().oracle_pairing_multi_fast(g1, g2, n, threads, o) == 0
     return o.raw
 
 

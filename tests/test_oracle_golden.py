@@ -139,3 +139,16 @@ def test_threshold_vectors(golden, oracle):
         lam = [int(x, 16) for x in rec["lambdas"]]
         got, inf = oracle.g2_msm(pts, lam, len(lam))
         assert got.hex() == rec["combined_affine"] and not inf, key
+
+
+def test_fast_algorithm_flavour_equals_the_reference_flavour(oracle, seeded_pairs, golden):
+    """oracle.pairing_multi_fast (bench.py's second CPU baseline: projective twist point, sparse lines, shared
+    squaring) gives the reference's bytes on ordinary pairs, for every thread split"""
+    g1, g2 = seeded_pairs
+    for n, th in ((1, 1), (2, 2), (7, 3), (65, 8)):
+        a, b = g1[:96 * n], g2[:192 * n]
+        want = bytes.fromhex(golden("pairing.json")["seeded"]["65"]["out"]) if n == 65 else oracle.pairing_multi(a, b, n, threads=4)
+        assert oracle.pairing_multi_fast(a, b, n, th) == want
+    v = golden("pairing.json")["small4"]
+    from conftest import cat
+    assert oracle.pairing_multi_fast(cat(v["g1"]), cat(v["g2"]), 4, 2).hex() == v["out"]
