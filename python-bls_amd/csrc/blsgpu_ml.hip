@@ -271,20 +271,22 @@ template <int M> __device__ __forceinline__ void store_part(int32_t* __restrict_
 }
 
 __device__ __forceinline__ void tangent_step(h& X, h& Y, h& Z, const fe& px3n, const fe& py2, int32_t* __restrict__ rec) {
-    const Lop<1> lx = left(X), ly = left(Y);
-    const Rop<1> ry = right(Y), rz = right(Z);
-    const h A = mul(lx, ry), YZ = mul(ly, rz);
-    const h B = sqr(Y), C = sqr(Z), XX = sqr(X);
-    const h E = b3(C);
+    // (the statements are asm volatile underneath, so this order IS the execution order: every value is consumed as
+    // early as the data flow allows, which keeps the step inside 256 registers)
+    store_part(rec, 1, mulf(sqr(X), px3n));                           // X^2 (-3 px)
+    const h YZ = mul(left(Y), right(Z));
+    store_part(rec, 2, mulf(YZ, py2));                                // 2YZ py
+    const h z8 = mulc_norm<8>(YZ);
+    const h E = b3(sqr(Z));
+    const h B = sqr(Y);
+    const h A = mul(left(X), right(Y));
+    store_part(rec, 0, sub(B, E));
     const S<3> F3 = mulc<3>(E);
     const h BmF = norm(sub(B, F3)), G = norm(add(B, F3));
     const h nE12 = mulc_norm<12>(neg(E));
-    store_part(rec, 0, sub(B, E));
-    store_part(rec, 1, mulf(XX, px3n));
-    store_part(rec, 2, mulf(YZ, py2));
     X = mul(left(add(A, A)), right(BmF));
     Y = dot2(left(G), right(G), left(nE12), right(E));
-    Z = mul(left(B), right(mulc_norm<8>(YZ)));
+    Z = mul(left(B), right(z8));
 }
 __device__ __forceinline__ void chord_step(h& X, h& Y, h& Z, const h& xq, const h& yq, const fe& px3n, const fe& py3,
                                            int32_t* __restrict__ rec) {
