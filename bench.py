@@ -413,7 +413,7 @@ def run_pairing(env, args):
           ((4, "k_ml_lines"), (5, "k_ml_accum"), (6, "k_ml_merge"), (7, "k_ml_horner"))}
     line_stream = bool(ls["k_ml_lines"])
     if line_stream:
-        launches = len(ls["k_ml_lines"])
+        launches = args.steps                        # per STEP (a step of more than 2^20 pairs is several launch sequences)
         ls_avg = {name: sum(v) / launches for name, v in ls.items()}
         miller_avg = sum(ls_avg.values())
     else:
