@@ -423,7 +423,6 @@ __global__ void __launch_bounds__(64) k_ml_lines_exact(const uint32_t* __restric
     const uint32_t total = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
     if (blockIdx.x * 32u >= total) return;
     const uint32_t part = threadIdx.x & 1u;
-    const int32_t one[NL] = BLS28_ONE;
     const int32_t halfc[NL] = BLS28_HALF;
     fe half;
 #pragma unroll
