@@ -205,3 +205,30 @@ def test_default_selection_for_a_batch_of_two_pair_verifications(engine, seeded_
     vm = _native.Engine(0)
     vm.set_ls_threshold(None)
     assert vm.pairing_multi_batch(a, b, 2, groups) == out
+
+
+def test_single_call_beyond_one_slice_of_line_records(engine, seeded_pairs, golden, oracle):
+    """one multi-pairing of 1100 x 1025 = 1 127 500 pairs: more than the 2^20 pairs whose line records (24 GB) one launch
+    sequence keeps -- the call is cut into runs that each leave a partial; the result is the reference's 1025-pair
+    value to the 1100th power"""
+    g1, g2 = seeded_pairs
+    k = 1100
+    want = oracle.fq12_pow(bytes.fromhex(golden("pairing.json")["seeded"]["1025"]["out"]), k)
+    assert engine.pairing_multi(g1 * k, g2 * k, 1025 * k) == want
+
+
+def test_many_single_pair_groups_by_default(engine, seeded_pairs, oracle):
+    """40 000 groups of ONE pair each (single pairings in bulk): line-stream small-group form + batched final
+    exponentiation by default; against the VM kernels, and a sample against the oracle"""
+    from bls_py import _native
+    g1, g2 = seeded_pairs
+    groups = 40000
+    a, b = (g1 * 40)[:96 * groups], (g2 * 40)[:192 * groups]
+    out = engine.pairing_multi_batch(a, b, 1, groups)
+    for g in (0, 1, 1024, 1025, 39999):
+        assert out[576 * g:576 * (g + 1)] == oracle.pairing_multi(a[96 * g:96 * (g + 1)], b[192 * g:192 * (g + 1)], 1), g
+    assert out[:576 * 1025] == out[576 * 1025:576 * 2050]           # the inputs repeat with period 1025
+    vm = _native.Engine(0)
+    vm.set_ls_threshold(None)
+    vm.set_fexp_team_threshold(None)
+    assert vm.pairing_multi_batch(a[:96 * 3000], b[:192 * 3000], 1, 3000) == out[:576 * 3000]
