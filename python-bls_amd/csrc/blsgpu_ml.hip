@@ -5,19 +5,23 @@
 // that fill the chip.  vmgen/linestream_model.py is the integer model of exactly this data flow (CPU-tested against
 // the oracle and the reference's vectors):
 //
-//   k_ml_lines   one PAIR PER LANE, 28-bit-limb register arithmetic (fp28.h).  The twist-point chain T <- 2T (+ Q)
-//                does not depend on the Miller accumulator, so it runs alone; every step stores its line
-//                l = l0 + l2 w^2 + l3 w^3 (three Fq2 values, P already multiplied in) as an 84-dword record:
-//                lines[(L * n + pair) * 84], L = 0 .. 67 in execution order (63 tangents, 5 chords).
-//                22.8 KB per pair: the 8 TB/s of HBM3E are what makes cutting the loop here affordable.
+//   k_ml_lines2  one PAIR PER LANE PAIR, 28-bit-limb register arithmetic (fp28.h) with every Fq2 value split over two
+//                adjacent lanes (namespace sp).  The twist-point chain T <- 2T (+ Q) does not depend on the Miller
+//                accumulator, so it runs alone; every step stores its line l = l0 + l2 w^2 + l3 w^3 (three Fq2 values,
+//                P already multiplied in) as an 84-dword record: lines[(L * n + pair) * 84], L = 0 .. 67 in execution
+//                order (63 tangents, 5 chords).  22.8 KB per pair: the 8 TB/s of HBM3E are what makes cutting the
+//                loop here affordable.  (k_ml_lines: the same with one pair per lane, kept for comparison.)
+//   k_ml_lines_exact  the pairs the fast formulas are not valid for: the reference's own line values into the same records.
 //   k_ml_accum   SIX LANES PER ACCUMULATOR (ten accumulators per wavefront): lane k holds the coefficient f_k of
 //                f = sum f_k w^k (Fq12 = Fq2[w]/(w^6 - xi)).  A team multiplies the line L of the pairs of its chunk
 //                into its accumulator: c_k = f_k l0 + F_{k-2} l2 + F_{k-3} l3 with F_i = f_i (i >= 0), xi f_{i+6}
 //                (i < 0) fetched from the team's lanes with ds_bpermute; each part of c_k is ONE sum of six products
 //                with one Montgomery reduction (fp28_dot6).  No squarings, no dependency between line indices.
+//   k_ml_small   groups of a few pairs: one team per group runs the whole loop f <- f^2 prod l on the same lines.
 //   k_ml_merge   dense products of the chunks' partial products (same lane layout).
-//   k_ml_horner  f <- f^2 (before a tangent) ; f <- f M_L over the 68 per-line products of a group; hands the
-//                result to the wavefront VM's form (one partial per group for k_reduce / the final exponentiation).
+//   k_ml_horner_wide  f <- f^2 (before a tangent) ; f <- f M_L over the 68 per-line products of a group, a dense product
+//                spread over 36 lanes; hands the result to the wavefront VM's form (one partial per group for
+//                k_reduce / the final exponentiation).  (k_ml_horner: ten groups per wavefront, kept for comparison.)
 //
 // The value differs from the reference's Miller product by the line scalings (Fq2 factors and w^3 per line) that
 // the final exponentiation removes iff they are non-zero: a pair whose Q is off the twist, flagged,
