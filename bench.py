@@ -726,7 +726,7 @@ def run_h2c(env, args):
             "metric": "hash-to-G2 messages/sec", "value": n * env.world / dtm, "unit": "messages/s", "n_gpus": env.world, "steps": reps,
             "warmup": 1, "ms_per_step": dtm * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "hash_to_point_prehashed_Fq2 of %d message hashes per GPU (SHA-256 chain, two SW encodings on the wavefront VM with the powers in registers, cofactor clearing one message per lane pair)" % n,
+            "config": {"workload": "hash_to_point_prehashed_Fq2 of %d message hashes per GPU (SHA-256 chain, two SW encodings one per lane with the powers in registers, cofactor clearing one message per lane pair)" % n,
                        "name": "h2c", "check": "3 messages against the host integer code (itself pinned to the reference's vectors)"},
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_pow + k_h2c_stage + k_h2c_clear", "peak": PEAK_TMACS, "unit": "TMAC/s",
                          "achieved": mac * n / dt / 1e12, "frac": mac * n / dt / 1e12 / PEAK_TMACS, "traffic": None}}

@@ -57,6 +57,7 @@ struct blsgpu_ctx {
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
     size_t h2c_reg_threshold = 8192;   // messages from which cofactor clearing runs in registers (one message per lane PAIR; measured: DESIGN.md 2c)
+    size_t h2c_lane_threshold = 2048;  // messages from which the three encoding stages run one encoding per lane (k_h2c_sw0/1/2)
     bool h2c_reg_pairs = true;         // ... on lane pairs (k_h2c_clear_pairs); false: one message per lane (k_h2c_clear_reg)
     void* d_h2c_ws = nullptr;          // the lane-private point slots of k_h2c_clear_pairs
     size_t h2c_ws_cap = 0;
@@ -496,6 +497,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_PAIRS")) c->h2c_reg_pairs = atoi(e) != 0;
+    if (const char* e = getenv("BLSGPU_H2C_LANE_THRESHOLD")) c->h2c_lane_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_NP_THRESHOLD")) c->horner_np_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_LANE_THRESHOLD")) c->msm_lane_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -1276,13 +1278,21 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
     uint32_t* img = c->d_msm_part;
     const size_t lds = (size_t)blsgpu::H1_TEAM_DW * 4;
     constexpr uint32_t BASE = BLSVM_H1_BASE - BLSVM_H1_STATE0, ACC = BLSVM_H1_ACC - BLSVM_H1_STATE0;
+    const bool lanes = n >= c->h2c_lane_threshold;         // the three encoding stages one encoding per lane (k_h2c_sw*)
+    const uint32_t total = (uint32_t)(teams * BLSVM_H1_NE);
+    const unsigned lgrid = (unsigned)((total + 63) / 64);
     if (from_hashes) {
         uint32_t* d_dig = img + teams * blsgpu::H1_IMG * 12;
         hipLaunchKernelGGL(blsgpu::k_h2c_hash, dim3((unsigned)((8 * n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_in,
                            (uint32_t)n, d_dig);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((blsgpu::k_h2c_stage<0, 1>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)d_dig,
-                           (uint32_t)(2 * n), img);
+        if (lanes)
+            hipLaunchKernelGGL(blsgpu::k_h2c_sw0<1>, dim3(lgrid), dim3(64), 0, st, (const uint32_t*)d_dig, (uint32_t)(2 * n), total, img);
+        else
+            hipLaunchKernelGGL((blsgpu::k_h2c_stage<0, 1>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)d_dig,
+                               (uint32_t)(2 * n), img);
+    } else if (lanes) {
+        hipLaunchKernelGGL(blsgpu::k_h2c_sw0<0>, dim3(lgrid), dim3(64), 0, st, (const uint32_t*)d_in, (uint32_t)(2 * n), total, img);
     } else {
         hipLaunchKernelGGL((blsgpu::k_h2c_stage<0, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)d_in,
                            (uint32_t)(2 * n), img);
@@ -1290,13 +1300,19 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
     HIP_TRY(hipGetLastError());
     int rc = launch_pow(c, img, blsgpu::H1_IMG, BASE, ACC, teams, 3 * BLSVM_H1_NE, st);
     if (rc) return rc;
-    hipLaunchKernelGGL((blsgpu::k_h2c_stage<1, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,
-                       (uint32_t)(2 * n), img);
+    if (lanes)
+        hipLaunchKernelGGL(blsgpu::k_h2c_sw1, dim3(lgrid), dim3(64), 0, st, total, img);
+    else
+        hipLaunchKernelGGL((blsgpu::k_h2c_stage<1, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,
+                           (uint32_t)(2 * n), img);
     HIP_TRY(hipGetLastError());
     rc = launch_pow(c, img, blsgpu::H1_IMG, BASE, ACC, teams, 2 * BLSVM_H1_NE, st);
     if (rc) return rc;
-    hipLaunchKernelGGL((blsgpu::k_h2c_stage<2, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,
-                       (uint32_t)(2 * n), img);
+    if (lanes)
+        hipLaunchKernelGGL(blsgpu::k_h2c_sw2, dim3(lgrid), dim3(64), 0, st, total, img);
+    else
+        hipLaunchKernelGGL((blsgpu::k_h2c_stage<2, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,
+                           (uint32_t)(2 * n), img);
     HIP_TRY(hipGetLastError());
     if (n < c->h2c_reg_threshold) {        // the VM form (BLSVM_H2_NM messages per wavefront)
         unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);

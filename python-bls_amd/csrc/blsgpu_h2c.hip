@@ -204,6 +204,194 @@ __global__ void __launch_bounds__(64, 2) k_h2c_stage(VmTables T, const uint32_t*
     img_store(team, my, BLSVM_H1_STATE0, H1_IMG, lane);
 }
 
+// ---------------------------------------------------------------------------
+// The three stages once more with ONE ENCODING PER LANE on the register arithmetic (round 3).  On the VM a team of 64
+// lanes serves 12 encodings and an inversion round serves 12 of its 64 lanes; at 262 144 messages the three stages
+// cost 10 ms.  Here every lane carries an encoding through the same formulas (vmgen/h2c_programs.py h1_a / h1_b /
+// h1_c, i.e. sw_encode of ec.py:449-507 with its control flow as arithmetic selects: the selectors stay FIELD values
+// (chi^2 + chi)/2, (1 + chi)/2 exactly as there, so every input gives the VM's values), reads and writes the SAME image
+// in the VM's form -- k_pow between the stages and the clearing kernels after them are unchanged -- and the one
+// inversion per stage is the safegcd routine run by all 64 lanes at once.
+namespace swl {
+using r28::fe;
+using r28::fe2;
+constexpr uint32_t NE = BLSVM_H1_NE;
+constexpr uint32_t S_PAR = BLSVM_H1_TH + 2 * NE, S_X = S_PAR + NE, S_A1 = BLSVM_H1_BASE + 3 * NE, S_FT = S_A1 + NE;
+__device__ __forceinline__ fe ldv(const uint32_t* __restrict__ team, uint32_t slot) {
+    uint32_t x[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) x[j] = team[(slot - BLSVM_H1_STATE0) * 12 + j];
+    return r28::from_vm(x);
+}
+template <int A, int B> __device__ __forceinline__ void stv(uint32_t* __restrict__ team, uint32_t slot, const r28::F<A, B>& v) {
+    uint32_t y[12];
+    r28::to_vm(y, r28::norm(v));
+#pragma unroll
+    for (int j = 0; j < 12; j++) team[(slot - BLSVM_H1_STATE0) * 12 + j] = y[j];
+}
+__device__ __forceinline__ void st_zero(uint32_t* __restrict__ team, uint32_t slot) {
+#pragma unroll
+    for (int j = 0; j < 12; j++) team[(slot - BLSVM_H1_STATE0) * 12 + j] = 0u;
+}
+__device__ __forceinline__ fe cst(const int32_t (&c)[r28::NL]) { return r28::fe_const(c); }
+// canonical(v) > (q - 1) / 2: the "lexicographically larger than its negation" test of ec.py:94-100 (the VM's SGN round)
+template <int A, int B> __device__ __forceinline__ bool sgn(const r28::F<A, B>& v) {
+    const uint32_t half[12] = BLS_HALF_LIMBS;
+    uint32_t x[12];
+    r28::to_raw(x, r28::norm(v));
+    uint32_t br = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) (void)bls::subc(half[j], x[j], br);
+    return br != 0;
+}
+__device__ __forceinline__ fe inv(const fe& n) {                     // 1/n, 0 -> 0
+    uint32_t w[12], v[12];
+    r28::to_vm(w, n);
+    bls::fq_inv(v, w);
+    return r28::from_vm(v);
+}
+template <int A, int B> __device__ __forceinline__ fe red(const r28::F<A, B>& x) { return r28::mul(x, r28::fe_one()); }   // value into (-q, 2q)
+__device__ __forceinline__ fe2 scale(const fe2& x, const fe& k) { return {r28::mul(x.a, k), r28::mul(x.b, k)}; }
+}  // namespace swl
+
+template <int WIDE>
+__global__ void __launch_bounds__(64) k_h2c_sw0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img) {
+    using namespace swl;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    uint32_t* team = img + (size_t)(e / NE) * H1_IMG * 12;
+    const uint32_t i = e % NE;
+    const int32_t onec[r28::NL] = BLS28_ONE, s3c[r28::NL] = BLS28_SW_S3, hhc[r28::NL] = BLS28_SW_HH, sic[r28::NL] = BLS28_SW_SINV;
+    const fe one = cst(onec);
+    fe2 tv;
+    if (e < n_enc) {
+        fe part[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            uint32_t lo[12];
+            if (WIDE) {
+                const uint32_t* src = t + (size_t)e * 32 + c * 16;             // 64 bytes, most significant dword first
+                uint32_t hi[12];
+#pragma unroll
+                for (int j = 0; j < 12; j++) { lo[j] = bswap32(src[15 - j]); hi[j] = j < 4 ? bswap32(src[3 - j]) : 0u; }
+                const int32_t c2[r28::NL] = BLS28_WIDE_C2;
+                part[c] = r28::norm(r28::add(r28::from_raw(lo), r28::mul(r28::unpack32(hi), cst(c2))));
+            } else {
+                const uint32_t* src = t + (size_t)e * 24 + c * 12;
+#pragma unroll
+                for (int j = 0; j < 12; j++) lo[j] = bswap32(src[11 - j]);
+                part[c] = r28::from_raw(lo);
+            }
+        }
+        tv = {part[0], part[1]};
+    } else {
+        tv = {one, r28::fe_zero()};                                            // encodings past the end run on t = (1, 0)
+    }
+    stv(team, BLSVM_H1_T + 2 * i, tv.a); stv(team, BLSVM_H1_T + 2 * i + 1, tv.b);
+    if (sgn(tv.b)) stv(team, S_PAR + i, one); else st_zero(team, S_PAR + i);     // parity: t.c1 > (-t).c1
+    const fe2 tt = r28::sqr(tv);
+    const fe2 w = {r28::norm(r28::add(tt.a, r28::mulc<5>(one))), r28::norm(r28::add(tt.b, r28::mulc<4>(one)))};   // t^2 + b' + 1
+    const fe2 wt = r28::mul(w, tv);
+    const fe ni = inv(r28::dot2(wt.a, wt.a, wt.b, wt.b));
+    const fe2 iwt = {r28::mul(wt.a, ni), r28::mul(r28::neg(wt.b), ni)};
+    const fe2 wi = r28::mul(tv, iwt), ti = r28::mul(w, iwt);                     // 1/w, 1/t
+    stv(team, S_FT + i, r28::mul(tv, ti).a);                                     // 1, or 0 when t = 0
+    const fe2 wp = scale(r28::mul(wi, tv), cst(s3c));                            // w' = sqrt(-3) t / w
+    const fe2 wpt = r28::mul(wp, tv);
+    const fe2 x1 = {r28::norm(r28::sub(cst(hhc), wpt.a)), r28::norm(r28::neg(wpt.b))};
+    const fe2 x2 = {r28::norm(r28::sub(r28::neg(one), x1.a)), r28::norm(r28::neg(x1.b))};
+    const fe2 wpi = scale(r28::mul(w, ti), cst(sic));                            // 1/w'
+    const fe2 q3 = r28::sqr(wpi);
+    const fe2 x3 = {r28::norm(r28::add(q3.a, one)), q3.b};
+    const fe2 xs[3] = {x1, x2, x3};
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) {
+        const fe2 x = xs[j];
+        const fe2 x3p = r28::mul(r28::sqr(x), x);
+        const fe four = r28::norm(r28::mulc<4>(one));
+        const fe2 u = {red(r28::add(x3p.a, four)), red(r28::add(x3p.b, four))};
+        const fe n = r28::dot2(u.a, u.a, u.b, u.b);                             // N(u)
+        const uint32_t k = 3 * i + j;
+        stv(team, S_X + 2 * k, x.a); stv(team, S_X + 2 * k + 1, x.b);
+        stv(team, BLSVM_H1_U + 2 * k, u.a); stv(team, BLSVM_H1_U + 2 * k + 1, u.b);
+        // a candidate whose u has zero imaginary part has no y in the reference: n' = 0 keeps h1_b from choosing it
+        if (r28::is_zero(u.b)) st_zero(team, BLSVM_H1_N + k); else stv(team, BLSVM_H1_N + k, n);
+        stv(team, BLSVM_H1_ACC + k, n); stv(team, BLSVM_H1_BASE + k, n);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_h2c_sw1(uint32_t total, uint32_t* __restrict__ img) {
+    using namespace swl;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    uint32_t* team = img + (size_t)(e / NE) * H1_IMG * 12;
+    const uint32_t i = e % NE;
+    const int32_t halfc[r28::NL] = BLS28_HALF;
+    const fe inv2 = cst(halfc);
+    fe c[2], r[3];
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) {
+        const uint32_t k = 3 * i + j;
+        const fe z = ldv(team, BLSVM_H1_ACC + k), n = ldv(team, BLSVM_H1_N + k);
+        r[j] = r28::mul(z, n);
+        const fe chi = r28::mul(r[j], z);
+        if (j < 2) c[j] = r28::mul(r28::add(r28::sqr(chi), chi), inv2);           // 1 iff chi = 1 (0 for chi = -1 and for n' = 0)
+    }
+    // x1 if c1 else (x2 if c2 else x3) (index rule of ec.py:489-500), as arithmetic selects v = B + c (A - B)
+    fe ch[5];
+#pragma unroll
+    for (uint32_t m = 0; m < 5; m++) {
+        fe p[3];
+#pragma unroll
+        for (uint32_t j = 0; j < 3; j++) {
+            const uint32_t k = 3 * i + j;
+            p[j] = m < 2 ? ldv(team, S_X + 2 * k + m) : (m < 4 ? ldv(team, BLSVM_H1_U + 2 * k + (m - 2)) : r[j]);
+        }
+        const fe inner = red(r28::add(p[2], r28::mul(c[1], red(r28::sub(p[1], p[2])))));
+        ch[m] = red(r28::add(inner, r28::mul(c[0], red(r28::sub(p[0], inner)))));
+    }
+    stv(team, S_X + 6 * i, ch[0]); stv(team, S_X + 6 * i + 1, ch[1]);
+    stv(team, S_A1 + i, ch[3]);
+    const fe dp = r28::mul(r28::add(ch[2], ch[4]), inv2), dm = r28::mul(r28::sub(ch[2], ch[4]), inv2);
+    stv(team, BLSVM_H1_ACC + 2 * i, dp); stv(team, BLSVM_H1_BASE + 2 * i, dp);
+    stv(team, BLSVM_H1_ACC + 2 * i + 1, dm); stv(team, BLSVM_H1_BASE + 2 * i + 1, dm);
+}
+
+__global__ void __launch_bounds__(64) k_h2c_sw2(uint32_t total, uint32_t* __restrict__ img) {
+    using namespace swl;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    uint32_t* team = img + (size_t)(e / NE) * H1_IMG * 12;
+    const uint32_t i = e % NE;
+    const int32_t halfc[r28::NL] = BLS28_HALF, onec[r28::NL] = BLS28_ONE;
+    const fe inv2 = cst(halfc), one = cst(onec);
+    fe sq[2], chi0;
+#pragma unroll
+    for (uint32_t j = 0; j < 2; j++) {
+        const fe z = ldv(team, BLSVM_H1_ACC + 2 * i + j), d = ldv(team, BLSVM_H1_BASE + 2 * i + j);
+        sq[j] = r28::mul(z, d);
+        if (j == 0) chi0 = r28::mul(sq[0], z);
+    }
+    const fe c = r28::mul(r28::add(one, chi0), inv2);
+    const fe x0 = red(r28::add(sq[1], r28::mul(c, red(r28::sub(sq[0], sq[1])))));
+    const fe a1 = ldv(team, S_A1 + i);
+    const fe x1c = r28::mul(a1, inv(red(r28::add(x0, x0))));
+    const bool g = sgn(x1c);
+    uint32_t pw = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) pw |= team[(S_PAR + i - BLSVM_H1_STATE0) * 12 + j];
+    const bool flip = g != (pw != 0u);                                          // g xor p
+    const fe y0 = flip ? r28::norm(r28::neg(x0)) : x0, y1 = flip ? r28::norm(r28::neg(x1c)) : x1c;
+    const fe ft = ldv(team, S_FT + i);
+    // t = 0: the projective point at infinity (0, 1, 0)  (ec.py:450-452)
+    stv(team, BLSVM_H1_S + 5 * i, r28::mul(ft, ldv(team, S_X + 6 * i)));
+    stv(team, BLSVM_H1_S + 5 * i + 1, r28::mul(ft, ldv(team, S_X + 6 * i + 1)));
+    stv(team, BLSVM_H1_S + 5 * i + 2, r28::add(one, r28::mul(ft, red(r28::sub(y0, one)))));
+    stv(team, BLSVM_H1_S + 5 * i + 3, r28::mul(ft, y1));
+    stv(team, BLSVM_H1_S + 5 * i + 4, ft);
+}
+
+// ---------------------------------------------------------------------------
 // Kernel H2: one team = BLSVM_H2_NM messages: P = S0 + S1, cofactor clearing,
 // canonical affine bytes (x.c0 || x.c1 || y.c0 || y.c1, 192 B per message).
 // enc = the stage image: encoding e sits in team e / NE, slots S + 5 (e % NE) .. + 5.

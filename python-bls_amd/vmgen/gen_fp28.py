@@ -134,6 +134,13 @@ def generate(path=None):
     out.append(arr("BLS28_Q", Q, "q"))
     out.append(arr("BLS28_ONE", R % Q, "R mod q: the Montgomery form of 1"))
     out.append(arr("BLS28_R2", R * R % Q, "R^2 mod q: content c (an integer < 2^391) times this is c R"))
+    # the Shallue-van de Woestijne encoding's constants (vmgen/h2c_programs.py; ec.py:449-507), Montgomery form
+    S3 = 1586958781458431025242759403266842894121773480562120986020912974854563298150952611241517463240701
+    assert (S3 * S3 + 3) % Q == 0
+    out.append(arr("BLS28_SW_S3", S3 * R % Q, "sqrt(-3) R"))
+    out.append(arr("BLS28_SW_HH", (S3 - 1) * pow(2, -1, Q) % Q * R % Q, "(sqrt(-3) - 1) / 2 R"))
+    out.append(arr("BLS28_SW_SINV", pow(S3, -1, Q) * R % Q, "1 / sqrt(-3) R"))
+    out.append(arr("BLS28_WIDE_C2", (1 << 384) * R * R % Q, "2^384 R^2 mod q: the digits of hi (a plain integer) times this is hi 2^384 R"))
     out.append(arr("BLS28_HALF", (Q + 1) // 2 * R % Q, "R / 2 mod q: the Montgomery form of 1/2"))
     out.append(arr("BLS28_FROM_VM", (1 << 400) % Q, "2^400 mod q: a value of the wavefront VM (x 2^384, 12 x 32 bits) times this is x R"))
     out.append(arr("BLS28_TO_VM", (1 << 384) % Q, "2^384 mod q: x R times this is x 2^384, the VM's Montgomery form"))
