@@ -58,6 +58,8 @@ struct blsgpu_ctx {
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
     size_t h2c_reg_threshold = 8192;   // messages from which cofactor clearing runs in registers (one message per lane PAIR; measured: DESIGN.md 2c)
     size_t h2c_lane_threshold = 2048;  // messages from which the three encoding stages run one encoding per lane (k_h2c_sw0/1/2)
+    bool h2c_jacobi = true;            // ... with the quadratic characters decided by a Jacobi-symbol routine: two powers per encoding, not five
+    size_t h2c_jacobi_threshold = 16384;   // ... from this many messages (below, five parallel powers finish sooner than three serial symbol loops)
     bool h2c_reg_pairs = true;         // ... on lane pairs (k_h2c_clear_pairs); false: one message per lane (k_h2c_clear_reg)
     void* d_h2c_ws = nullptr;          // the lane-private point slots of k_h2c_clear_pairs
     size_t h2c_ws_cap = 0;
@@ -497,6 +499,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_PAIRS")) c->h2c_reg_pairs = atoi(e) != 0;
+    if (const char* e = getenv("BLSGPU_H2C_JACOBI")) c->h2c_jacobi = atoi(e) != 0;
+    if (const char* e = getenv("BLSGPU_H2C_JACOBI_THRESHOLD")) c->h2c_jacobi_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_LANE_THRESHOLD")) c->h2c_lane_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_NP_THRESHOLD")) c->horner_np_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -1286,11 +1290,15 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
         hipLaunchKernelGGL(blsgpu::k_h2c_hash, dim3((unsigned)((8 * n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_in,
                            (uint32_t)n, d_dig);
         HIP_TRY(hipGetLastError());
-        if (lanes)
+        if (lanes && c->h2c_jacobi && n >= c->h2c_jacobi_threshold)
+            hipLaunchKernelGGL(blsgpu::k_h2c_swj0<1>, dim3(lgrid), dim3(64), 0, st, (const uint32_t*)d_dig, (uint32_t)(2 * n), total, img);
+        else if (lanes)
             hipLaunchKernelGGL(blsgpu::k_h2c_sw0<1>, dim3(lgrid), dim3(64), 0, st, (const uint32_t*)d_dig, (uint32_t)(2 * n), total, img);
         else
             hipLaunchKernelGGL((blsgpu::k_h2c_stage<0, 1>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)d_dig,
                                (uint32_t)(2 * n), img);
+    } else if (lanes && c->h2c_jacobi && n >= c->h2c_jacobi_threshold) {
+        hipLaunchKernelGGL(blsgpu::k_h2c_swj0<0>, dim3(lgrid), dim3(64), 0, st, (const uint32_t*)d_in, (uint32_t)(2 * n), total, img);
     } else if (lanes) {
         hipLaunchKernelGGL(blsgpu::k_h2c_sw0<0>, dim3(lgrid), dim3(64), 0, st, (const uint32_t*)d_in, (uint32_t)(2 * n), total, img);
     } else {
@@ -1298,17 +1306,22 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
                            (uint32_t)(2 * n), img);
     }
     HIP_TRY(hipGetLastError());
-    int rc = launch_pow(c, img, blsgpu::H1_IMG, BASE, ACC, teams, 3 * BLSVM_H1_NE, st);
+    const bool jac = lanes && c->h2c_jacobi && n >= c->h2c_jacobi_threshold;   // two powers per encoding instead of five (swl::jacobi)
+    int rc = launch_pow(c, img, blsgpu::H1_IMG, BASE, ACC, teams, (jac ? 1 : 3) * BLSVM_H1_NE, st);
     if (rc) return rc;
-    if (lanes)
+    if (jac)
+        hipLaunchKernelGGL(blsgpu::k_h2c_swj1, dim3(lgrid), dim3(64), 0, st, total, img);
+    else if (lanes)
         hipLaunchKernelGGL(blsgpu::k_h2c_sw1, dim3(lgrid), dim3(64), 0, st, total, img);
     else
         hipLaunchKernelGGL((blsgpu::k_h2c_stage<1, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,
                            (uint32_t)(2 * n), img);
     HIP_TRY(hipGetLastError());
-    rc = launch_pow(c, img, blsgpu::H1_IMG, BASE, ACC, teams, 2 * BLSVM_H1_NE, st);
+    rc = launch_pow(c, img, blsgpu::H1_IMG, BASE, ACC, teams, (jac ? 1 : 2) * BLSVM_H1_NE, st);
     if (rc) return rc;
-    if (lanes)
+    if (jac)
+        hipLaunchKernelGGL(blsgpu::k_h2c_swj2, dim3(lgrid), dim3(64), 0, st, total, img);
+    else if (lanes)
         hipLaunchKernelGGL(blsgpu::k_h2c_sw2, dim3(lgrid), dim3(64), 0, st, total, img);
     else
         hipLaunchKernelGGL((blsgpu::k_h2c_stage<2, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,

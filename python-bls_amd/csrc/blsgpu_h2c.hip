@@ -254,6 +254,184 @@ template <int A, int B> __device__ __forceinline__ fe red(const r28::F<A, B>& x)
 __device__ __forceinline__ fe2 scale(const fe2& x, const fe& k) { return {r28::mul(x.a, k), r28::mul(x.b, k)}; }
 }  // namespace swl
 
+// ---- quadratic characters without a power -------------------------------------------------------------------------
+// Of the five fixed-exponent powers per encoding (377 squarings + 110 products each) three only decide a quadratic
+// character: which of x1, x2 has a square norm (the third candidate is taken unseen, ec.py:489-500), and which of
+// delta+- is the square (fields.py:463-482).  swl::jacobi decides it with the binary algorithm on the canonical value:
+// 768 fixed iterations of compare / conditional swap (reciprocity: the sign flips when both are 3 mod 4) / subtract /
+// halve (the sign flips when n is 3 or 5 mod 8), ~100 instructions each and the same for every lane -- 0.4 of a power.
+// The k_h2c_swj* kernels are the encoding stages built on it: TWO powers per encoding instead of five.  Results are the
+// VM's and the k_h2c_sw* kernels' field elements in every case (chi in {1, -1, 0} drives the same selections).
+namespace swl {
+__device__ __forceinline__ int jacobi(uint32_t (&a)[12]) {
+    uint32_t n[12] = BLS_Q_LIMBS;
+    uint32_t sg = 0;
+#pragma unroll 1
+    for (int it = 0; it < 768; it++) {
+        const bool odd = (a[0] & 1u) != 0u;
+        uint32_t d[12], nd[12], br = 0, cy = 1;
+#pragma unroll
+        for (int j = 0; j < 12; j++) d[j] = bls::subc(a[j], n[j], br);            // a - n, borrow <=> a < n
+#pragma unroll
+        for (int j = 0; j < 12; j++) nd[j] = bls::addc(~d[j], 0u, cy);             // n - a
+        const bool lt = br != 0u;
+        sg ^= (odd && lt) ? ((a[0] & n[0] & 2u) >> 1) : 0u;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const uint32_t na = lt ? nd[j] : d[j], nn = lt ? a[j] : n[j];
+            n[j] = odd ? nn : n[j];
+            a[j] = odd ? na : a[j];
+        }
+        uint32_t any = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) any |= a[j];
+        const bool nz = any != 0u;
+        sg ^= nz ? (((n[0] >> 1) ^ (n[0] >> 2)) & 1u) : 0u;
+#pragma unroll
+        for (int j = 0; j < 11; j++) a[j] = nz ? __builtin_amdgcn_alignbit(a[j + 1], a[j], 1) : a[j];
+        a[11] = nz ? a[11] >> 1 : a[11];
+    }
+    uint32_t rest = n[0] ^ 1u;
+#pragma unroll
+    for (int j = 1; j < 12; j++) rest |= n[j];
+    return rest ? 0 : (sg ? -1 : 1);
+}
+template <int A, int B> __device__ __forceinline__ int chi(const r28::F<A, B>& v) {    // the quadratic character of v
+    uint32_t x[12];
+    r28::to_raw(x, r28::norm(v));
+    return jacobi(x);
+}
+}  // namespace swl
+
+// stage 0 with the choice of the candidate inside: X[6i..] = x, U[6i] = u0, A1 = u1, N[3i] = n' (0 for a real u),
+// BASE[i] = ACC[i] = N(u) of the chosen candidate -> ONE power per encoding
+template <int WIDE>
+__global__ void __launch_bounds__(64) k_h2c_swj0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img) {
+    using namespace swl;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    uint32_t* team = img + (size_t)(e / NE) * H1_IMG * 12;
+    const uint32_t i = e % NE;
+    const int32_t onec[r28::NL] = BLS28_ONE, s3c[r28::NL] = BLS28_SW_S3, hhc[r28::NL] = BLS28_SW_HH, sic[r28::NL] = BLS28_SW_SINV;
+    const fe one = cst(onec);
+    fe2 tv;
+    if (e < n_enc) {
+        fe part[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            uint32_t lo[12];
+            if (WIDE) {
+                const uint32_t* src = t + (size_t)e * 32 + c * 16;
+                uint32_t hi[12];
+#pragma unroll
+                for (int j = 0; j < 12; j++) { lo[j] = bswap32(src[15 - j]); hi[j] = j < 4 ? bswap32(src[3 - j]) : 0u; }
+                const int32_t c2[r28::NL] = BLS28_WIDE_C2;
+                part[c] = r28::norm(r28::add(r28::from_raw(lo), r28::mul(r28::unpack32(hi), cst(c2))));
+            } else {
+                const uint32_t* src = t + (size_t)e * 24 + c * 12;
+#pragma unroll
+                for (int j = 0; j < 12; j++) lo[j] = bswap32(src[11 - j]);
+                part[c] = r28::from_raw(lo);
+            }
+        }
+        tv = {part[0], part[1]};
+    } else {
+        tv = {one, r28::fe_zero()};
+    }
+    if (sgn(tv.b)) stv(team, S_PAR + i, one); else st_zero(team, S_PAR + i);
+    const fe2 tt = r28::sqr(tv);
+    const fe2 w = {r28::norm(r28::add(tt.a, r28::mulc<5>(one))), r28::norm(r28::add(tt.b, r28::mulc<4>(one)))};
+    const fe2 wt = r28::mul(w, tv);
+    const fe ni = inv(r28::dot2(wt.a, wt.a, wt.b, wt.b));
+    const fe2 iwt = {r28::mul(wt.a, ni), r28::mul(r28::neg(wt.b), ni)};
+    const fe2 wi = r28::mul(tv, iwt), ti = r28::mul(w, iwt);
+    stv(team, S_FT + i, r28::mul(tv, ti).a);
+    const fe2 wp = scale(r28::mul(wi, tv), cst(s3c));
+    const fe2 wpt = r28::mul(wp, tv);
+    const fe2 x1 = {r28::norm(r28::sub(cst(hhc), wpt.a)), r28::norm(r28::neg(wpt.b))};
+    const fe2 x2 = {r28::norm(r28::sub(r28::neg(one), x1.a)), r28::norm(r28::neg(x1.b))};
+    const fe2 wpi = scale(r28::mul(w, ti), cst(sic));
+    const fe2 q3 = r28::sqr(wpi);
+    const fe2 x3 = {r28::norm(r28::add(q3.a, one)), q3.b};
+    const fe four = r28::norm(r28::mulc<4>(one));
+    // candidates in the reference's order; the first of x1, x2 whose n' is a square, else x3 (ec.py:489-500)
+    fe2 x = x3, u;
+    fe n;
+    bool realu, taken = false;
+#pragma unroll 1
+    for (int j = 0; j < 3; j++) {
+        const fe2 xc = j == 0 ? x1 : (j == 1 ? x2 : x3);
+        const fe2 x3p = r28::mul(r28::sqr(xc), xc);
+        const fe2 uc = {red(r28::add(x3p.a, four)), red(r28::add(x3p.b, four))};
+        const fe nc = r28::dot2(uc.a, uc.a, uc.b, uc.b);
+        const bool ru = r28::is_zero(uc.b);                   // u with zero imaginary part: n' = 0, never a square here
+        const bool sq = j == 2 || (!ru && chi(nc) == 1);
+        const bool take = sq && !taken;
+#pragma unroll
+        for (int l = 0; l < r28::NL; l++) {
+            x.a.v[l] = take ? xc.a.v[l] : x.a.v[l]; x.b.v[l] = take ? xc.b.v[l] : x.b.v[l];
+            u.a.v[l] = take ? uc.a.v[l] : u.a.v[l]; u.b.v[l] = take ? uc.b.v[l] : u.b.v[l];
+            n.v[l] = take ? nc.v[l] : n.v[l];
+        }
+        realu = take ? ru : realu;
+        taken = taken || take;
+    }
+    stv(team, S_X + 6 * i, x.a); stv(team, S_X + 6 * i + 1, x.b);
+    stv(team, BLSVM_H1_U + 6 * i, u.a);
+    stv(team, S_A1 + i, u.b);
+    if (realu) st_zero(team, BLSVM_H1_N + 3 * i); else stv(team, BLSVM_H1_N + 3 * i, n);
+    stv(team, BLSVM_H1_ACC + i, n); stv(team, BLSVM_H1_BASE + i, n);
+}
+// after z = n^E: r = z n', delta+- = (u0 +- r)/2, the square one of them -> BASE[i] = ACC[i]; its character -> N[3i + 1]
+__global__ void __launch_bounds__(64) k_h2c_swj1(uint32_t total, uint32_t* __restrict__ img) {
+    using namespace swl;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    uint32_t* team = img + (size_t)(e / NE) * H1_IMG * 12;
+    const uint32_t i = e % NE;
+    const int32_t halfc[r28::NL] = BLS28_HALF;
+    const fe inv2 = cst(halfc);
+    const fe r = r28::mul(ldv(team, BLSVM_H1_ACC + i), ldv(team, BLSVM_H1_N + 3 * i));
+    const fe u0 = ldv(team, BLSVM_H1_U + 6 * i);
+    const fe dp = r28::mul(r28::add(u0, r), inv2), dm = r28::mul(r28::sub(u0, r), inv2);
+    const int J = chi(dp);
+    fe d;
+#pragma unroll
+    for (int l = 0; l < r28::NL; l++) d.v[l] = J == 1 ? dp.v[l] : dm.v[l];
+    stv(team, BLSVM_H1_ACC + i, d); stv(team, BLSVM_H1_BASE + i, d);
+    team[(BLSVM_H1_N + 3 * i + 1 - BLSVM_H1_STATE0) * 12] = (uint32_t)(J + 1);
+}
+// after z = d^E: x0 = z d (halved when delta+ was zero: the VM's (1 + chi)/2 selection with chi = 0), then h1_c as k_h2c_sw2
+__global__ void __launch_bounds__(64) k_h2c_swj2(uint32_t total, uint32_t* __restrict__ img) {
+    using namespace swl;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    uint32_t* team = img + (size_t)(e / NE) * H1_IMG * 12;
+    const uint32_t i = e % NE;
+    const int32_t halfc[r28::NL] = BLS28_HALF, onec[r28::NL] = BLS28_ONE;
+    const fe inv2 = cst(halfc), one = cst(onec);
+    const fe sq = r28::mul(ldv(team, BLSVM_H1_ACC + i), ldv(team, BLSVM_H1_BASE + i));
+    const bool zeroplus = team[(BLSVM_H1_N + 3 * i + 1 - BLSVM_H1_STATE0) * 12] == 1u;
+    const fe hsq = r28::mul(sq, inv2);
+    fe x0;
+#pragma unroll
+    for (int l = 0; l < r28::NL; l++) x0.v[l] = zeroplus ? hsq.v[l] : sq.v[l];
+    const fe a1 = ldv(team, S_A1 + i);
+    const fe x1c = r28::mul(a1, inv(red(r28::add(x0, x0))));
+    const bool g = sgn(x1c);
+    uint32_t pw = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) pw |= team[(S_PAR + i - BLSVM_H1_STATE0) * 12 + j];
+    const bool flip = g != (pw != 0u);
+    const fe y0 = flip ? r28::norm(r28::neg(x0)) : x0, y1 = flip ? r28::norm(r28::neg(x1c)) : x1c;
+    const fe ft = ldv(team, S_FT + i);
+    stv(team, BLSVM_H1_S + 5 * i, r28::mul(ft, ldv(team, S_X + 6 * i)));
+    stv(team, BLSVM_H1_S + 5 * i + 1, r28::mul(ft, ldv(team, S_X + 6 * i + 1)));
+    stv(team, BLSVM_H1_S + 5 * i + 2, r28::add(one, r28::mul(ft, red(r28::sub(y0, one)))));
+    stv(team, BLSVM_H1_S + 5 * i + 3, r28::mul(ft, y1));
+    stv(team, BLSVM_H1_S + 5 * i + 4, ft);
+}
+
 template <int WIDE>
 __global__ void __launch_bounds__(64) k_h2c_sw0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img) {
     using namespace swl;
