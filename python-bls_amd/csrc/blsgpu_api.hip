@@ -81,6 +81,7 @@ struct blsgpu_ctx {
     size_t lsp_cap[2] = {0, 0};        // bytes
     void* d_bad = nullptr;             // one byte per pair: left to the slow program
     size_t bad_cap = 0;
+    bool vm_exact_lanes = true;        // degenerate blocks of the VM kernels through the lane kernels (k_ml_lines_exact / k_ml_small) instead of k_miller_slow
     int ls_horner_form = 2;            // 2: one group per wavefront, a product spread over 36 lanes; 1: ten groups per wavefront
     int ls_lines_form = 2;             // 2: the point chains on lane pairs (k_ml_lines2); 1: one pair per lane (k_ml_lines)
     size_t fexp_team_threshold = 256;  // results per call from which the final exponentiations run six lanes each (blsgpu_fexp.hip)
@@ -493,6 +494,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_LS_MIN_GROUP")) c->ls_min_group = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_TEAMS")) c->ls_teams = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_FEXP_TEAM_THRESHOLD")) c->fexp_team_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_VM_EXACT_LANES")) c->vm_exact_lanes = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_LS_LINES_FORM")) c->ls_lines_form = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("BLSGPU_LS_HORNER_FORM")) c->ls_horner_form = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -810,7 +812,21 @@ static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, cons
     }
     HIP_TRY(hipGetLastError());
     if (c->bulk_event) HIP_TRY(hipEventRecord(c->bulk_event, st));
-    {
+    // The listed blocks once more, exactly: the reference's own line values of their pairs on lane pairs
+    // (k_ml_lines_exact, block mode) and one six-lane accumulator per block over them (k_ml_small, list mode) -- 1.5 ms
+    // where the VM's slow program (k_miller_slow: one pair at a time per wavefront, 68 lane-serial inversions each)
+    // takes 6 ms per PAIR.  Both kernels leave at once when the list is empty.
+    const size_t nv = bpg * groups * per_block;            // virtual pairs: every block could be listed
+    if (c->vm_exact_lanes && nv <= ((size_t)1 << 16) &&
+        !grow_buffer(c, &c->d_lines, &c->lines_cap, nv * blsgpu::ml::LINES * blsgpu::ml::LINE_DW * 4) && !grow_buffer(c, &c->d_bad, &c->bad_cap, nv)) {
+        KernelTimer kt(c, st, 3);
+        hipLaunchKernelGGL(blsgpu::ml::k_ml_lines_exact, dim3(1024), dim3(64), 0, st, (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)nv,
+                           (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg, (uint32_t)gsz, (uint32_t)bpg, (uint32_t)per_block);
+        hipLaunchKernelGGL(blsgpu::ml::k_ml_small, dim3((unsigned)((bpg * groups + blsgpu::ml::TEAMS - 1) / blsgpu::ml::TEAMS)), dim3(64), 0, st,
+                           (const int32_t*)c->d_lines, (const uint8_t*)c->d_bad, (uint32_t)nv, (uint32_t)per_block, (uint32_t)(bpg * groups),
+                           d_partials, 144u, (const uint32_t*)dg.count, (const uint32_t*)dg.blocks);
+    } else {
+        (void)hipGetLastError();
         KernelTimer kt(c, st, 3);
         hipLaunchKernelGGL(blsgpu::k_miller_slow, dim3(SLOW_GRID), dim3(64), (size_t)blsgpu::SLOW_TEAM_BYTES, st, c->tabs,
                            (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, (uint32_t)per_block, d_partials, dg);
@@ -863,14 +879,15 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
         // when the list is empty)
         KernelTimer kt(c, st, 3);
         hipLaunchKernelGGL(ml::k_ml_lines_exact, dim3(2048), dim3(64), 0, st, (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)n,
-                           (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
+                           (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg, 0u, 0u, 0u);
     }
     HIP_TRY(hipGetLastError());
     if (small) {
         {
             KernelTimer kt(c, st, 5);
             hipLaunchKernelGGL(ml::k_ml_small, dim3((unsigned)((groups + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st, (const int32_t*)c->d_lines,
-                               (const uint8_t*)c->d_bad, (uint32_t)n, (uint32_t)gsz, (uint32_t)groups, d_partials, 144u);
+                               (const uint8_t*)c->d_bad, (uint32_t)n, (uint32_t)gsz, (uint32_t)groups, d_partials, 144u,
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         }
         HIP_TRY(hipGetLastError());
         if (c->bulk_event) HIP_TRY(hipEventRecord(c->bulk_event, st));

@@ -421,10 +421,16 @@ __device__ __forceinline__ Aff exact_double(const h& rx, const h& ry, const h& i
 }
 }  // namespace sp
 
+// Block mode (per_block > 0; the wavefront-VM kernels' work list): an entry is a BLOCK of up to per_block consecutive
+// pairs of one group (block b: group b / bpg, pairs from (b - group * bpg) * per_block on); item v = entry * per_block + j
+// is a "virtual pair" whose records go to lines[(L * n + v) * 84] and whose flag to bad[v] (255: past the end of the
+// block's group).  per_block == 0: an entry is a pair and the records are that pair's own.
 __global__ void __launch_bounds__(64) k_ml_lines_exact(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
-                                                       int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg) {
+                                                       int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg,
+                                                       uint32_t gsz, uint32_t bpg, uint32_t per_block) {
     using namespace sp;
-    const uint32_t total = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
+    const uint32_t entries = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
+    const uint32_t total = per_block ? entries * per_block : entries;
     if (blockIdx.x * 32u >= total) return;
     const uint32_t part = threadIdx.x & 1u;
     const int32_t halfc[NL] = BLS28_HALF;
@@ -434,8 +440,17 @@ __global__ void __launch_bounds__(64) k_ml_lines_exact(const uint32_t* __restric
 #pragma unroll 1
     for (uint32_t e0 = blockIdx.x * 32u; e0 < total; e0 += gridDim.x * 32u) {
         const uint32_t er = e0 + (threadIdx.x >> 1);
-        const uint32_t e = er < total ? er : total - 1u;              // spare lane pairs repeat the last entry
-        const uint32_t p = dg.blocks[e];
+        const uint32_t e = er < total ? er : total - 1u;              // spare lane pairs repeat the last item
+        uint32_t p = dg.blocks[per_block ? e / per_block : e], v = p;
+        if (per_block) {
+            const uint32_t b = p, grp = b / bpg, in_grp = (b - grp * bpg) * per_block + (e % per_block);
+            v = e;
+            if (in_grp >= gsz) {                                      // past the end of the group: nothing to multiply
+                if (part == 0u && er < total) bad[v] = 255;
+                continue;
+            }
+            p = grp * gsz + in_grp;
+        }
         const uint32_t* s1 = g1 + (size_t)p * 24;
         const uint32_t* s2 = g2 + (size_t)p * 48 + part * 12;
         const bool qinf = q_flagged(dg, p);
@@ -443,7 +458,7 @@ __global__ void __launch_bounds__(64) k_ml_lines_exact(const uint32_t* __restric
         const fe hnpx = r28::mul(r28::neg(px), half);                 // -px / 2
         const h qx = load_part(s2), qy = load_part(s2 + 24);
         h rx = qx, ry = qy;
-        int32_t* rec = lines + (size_t)p * LINE_DW;
+        int32_t* rec = lines + (size_t)v * LINE_DW;
         const size_t lstride = (size_t)n * LINE_DW;
         uint32_t flag = 1u, chord = 0u;
         h c0;
@@ -500,7 +515,7 @@ __global__ void __launch_bounds__(64) k_ml_lines_exact(const uint32_t* __restric
                 }
             }
         }
-        if (part == 0u && er < total) bad[p] = (uint8_t)flag;
+        if (part == 0u && er < total) bad[v] = (uint8_t)flag;
     }
 }
 
@@ -791,9 +806,17 @@ struct TeamRec {                                   // the team's own f as the de
         bperm14(d, (k & 1) ? im : re, base4 + (uint32_t)(k >> 1) * 4u);
     }
 };
+// List mode (count != nullptr; the wavefront-VM kernels' degenerate blocks): group g is entry g of the work list, its
+// pairs the virtual pairs [g * gsz, (g + 1) * gsz) of k_ml_lines_exact's block mode (flag 255: no pair), and its partial
+// goes to partials[index[g] * pstride].
 __global__ void __launch_bounds__(64, 2) k_ml_small(const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad, uint32_t n, uint32_t gsz,
-                                                    uint32_t groups, uint32_t* __restrict__ partials, uint32_t pstride) {
+                                                    uint32_t groups, uint32_t* __restrict__ partials, uint32_t pstride,
+                                                    const uint32_t* __restrict__ count, const uint32_t* __restrict__ index) {
     const Team t = team_of_lane();
+    if (count != nullptr) {
+        groups = min(groups, __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)count));
+        if (blockIdx.x * TEAMS >= groups) return;
+    }
     const uint32_t g = blockIdx.x * TEAMS + t.slot;
     const bool valid = t.slot < (uint32_t)TEAMS && g < groups;
     const size_t first = (size_t)(valid ? g : 0u) * gsz;
@@ -811,7 +834,9 @@ __global__ void __launch_bounds__(64, 2) k_ml_small(const int32_t* __restrict__ 
 #pragma unroll 1
         for (uint32_t i = 0; i < gsz; i++) {
             uint32_t jA, jB;
-            line_positions(L, bad[first + i], jA, jB);
+            const uint32_t flag = bad[first + i];
+            const bool use = flag != 255u;
+            line_positions(L, flag, jA, jB);
             const int4* rec = reinterpret_cast<const int4*>(base + (size_t)i * LINE_DW);
             int32_t y[6][NL];
             {
@@ -830,12 +855,12 @@ __global__ void __launch_bounds__(64, 2) k_ml_small(const int32_t* __restrict__ 
             int32_t re[NL], im[NL];
             mul_line(re, im, P, t, jA, jB, y[0], y[1], y[2], y[3], y[4], y[5]);
 #pragma unroll
-            for (int k = 0; k < NL; k++) { fre[k] = re[k]; fim[k] = im[k]; }
+            for (int k = 0; k < NL; k++) { fre[k] = use ? re[k] : fre[k]; fim[k] = use ? im[k] : fim[k]; }
         }
     }
     if (valid) {
         const uint32_t flat = (t.c & 1u) ? 3u + (t.c >> 1) : (t.c >> 1);
-        uint32_t* o = partials + (size_t)g * pstride + flat * 24u;
+        uint32_t* o = partials + (size_t)(index != nullptr ? index[g] : g) * pstride + flat * 24u;
         fe a, b;
 #pragma unroll
         for (int k = 0; k < NL; k++) { a.v[k] = fre[k]; b.v[k] = fim[k]; }
