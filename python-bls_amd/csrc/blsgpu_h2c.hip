@@ -269,27 +269,24 @@ __device__ __forceinline__ int jacobi(uint32_t (&a)[12]) {
 #pragma unroll 1
     for (int it = 0; it < 768; it++) {
         const bool odd = (a[0] & 1u) != 0u;
-        uint32_t d[12], nd[12], br = 0, cy = 1;
+        uint32_t d[12], e[12], br = 0, br2 = 0;
 #pragma unroll
         for (int j = 0; j < 12; j++) d[j] = bls::subc(a[j], n[j], br);            // a - n, borrow <=> a < n
 #pragma unroll
-        for (int j = 0; j < 12; j++) nd[j] = bls::addc(~d[j], 0u, cy);             // n - a
-        const bool lt = br != 0u;
-        sg ^= (odd && lt) ? ((a[0] & n[0] & 2u) >> 1) : 0u;
+        for (int j = 0; j < 12; j++) e[j] = bls::subc(n[j], a[j], br2);           // n - a
+        const bool sw = odd && br != 0u;                                           // a odd and a < n: the two change places
+        sg ^= sw ? ((a[0] & n[0] & 2u) >> 1) : 0u;                                 // reciprocity: both 3 mod 4
 #pragma unroll
         for (int j = 0; j < 12; j++) {
-            const uint32_t na = lt ? nd[j] : d[j], nn = lt ? a[j] : n[j];
-            n[j] = odd ? nn : n[j];
-            a[j] = odd ? na : a[j];
+            const uint32_t keep = odd ? d[j] : a[j];
+            n[j] = sw ? a[j] : n[j];
+            a[j] = sw ? e[j] : keep;
         }
-        uint32_t any = 0;
+        const uint32_t any = (a[0] | a[1] | a[2]) | (a[3] | a[4] | a[5]) | (a[6] | a[7] | a[8]) | (a[9] | a[10] | a[11]);
+        sg ^= any ? (((n[0] >> 1) ^ (n[0] >> 2)) & 1u) : 0u;                       // a halving: n is 3 or 5 mod 8
 #pragma unroll
-        for (int j = 0; j < 12; j++) any |= a[j];
-        const bool nz = any != 0u;
-        sg ^= nz ? (((n[0] >> 1) ^ (n[0] >> 2)) & 1u) : 0u;
-#pragma unroll
-        for (int j = 0; j < 11; j++) a[j] = nz ? __builtin_amdgcn_alignbit(a[j + 1], a[j], 1) : a[j];
-        a[11] = nz ? a[11] >> 1 : a[11];
+        for (int j = 0; j < 11; j++) a[j] = __builtin_amdgcn_alignbit(a[j + 1], a[j], 1);     // (zero stays zero)
+        a[11] >>= 1;
     }
     uint32_t rest = n[0] ^ 1u;
 #pragma unroll
