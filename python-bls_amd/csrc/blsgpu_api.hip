@@ -38,6 +38,7 @@ constexpr int MILLER_WAVES = 4;        // teams (pairings) per workgroup in k_mi
 constexpr int REDUCE_WAVES = 8;        // teams per workgroup in k_reduce
 constexpr size_t BATCH_TREE_MIN_GROUP = 24;   // batches of groups at least this long use the per-group product tree
 constexpr int REDUCE_PER_BLOCK = 64;   // partials folded by one k_reduce block
+constexpr size_t LS_MAX_PAIRS = (size_t)1 << 20;       // pairs per line-stream launch sequence: 24 GB of line records
 
 }  // namespace
 
@@ -717,7 +718,22 @@ BLSGPU_EXPORT int blsgpu_ctx_set_mp3_threshold(blsgpu_ctx* c, size_t pairs) {
 BLSGPU_EXPORT int blsgpu_ctx_reserve(blsgpu_ctx* c, size_t max_pairs) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    return ensure_workspace(c, max_pairs);
+    if (int rc = ensure_workspace(c, max_pairs)) return rc;
+    if (max_pairs >= c->ls_threshold) {
+        // the line-stream stage's buffers as well (a call of that size takes them): line records of one slice, the
+        // flags and the work list, and dense partial products for the usual chunking (ls_teams accumulators plus 68 per
+        // group of at least ls_min_group pairs); a call that needs more grows them itself
+        const size_t n = max_pairs < LS_MAX_PAIRS ? max_pairs : LS_MAX_PAIRS;
+        const size_t teams = c->ls_teams + blsgpu::ml::LINES * (n / (c->ls_min_group ? c->ls_min_group : 1) + 1);
+        if (grow_buffer(c, &c->d_lines, &c->lines_cap, n * blsgpu::ml::LINES * blsgpu::ml::LINE_DW * 4) ||
+            grow_buffer(c, &c->d_bad, &c->bad_cap, n) || grow_elems(c, &c->d_degen, &c->degen_cap, n + 2) ||
+            grow_buffer(c, &c->d_lsp[0], &c->lsp_cap[0], teams * blsgpu::ml::DENSE_DW * 4) ||
+            grow_buffer(c, &c->d_lsp[1], &c->lsp_cap[1], (teams / 8 + blsgpu::ml::LINES) * blsgpu::ml::DENSE_DW * 4)) {
+            (void)hipGetLastError();
+            return fail(-ENOMEM, "no memory for the line-stream workspace (calls of that size will use the wavefront-VM kernels)");
+        }
+    }
+    return 0;
 }
 
 // Waits for the context's enqueued work and releases the buffers that larger ones replaced.
@@ -836,7 +852,6 @@ static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, cons
 }
 
 // The line-stream form of launch_miller (blsgpu_ml.hip): ONE partial per group comes out (bpg = 1).
-constexpr size_t LS_MAX_PAIRS = (size_t)1 << 20;       // pairs per launch sequence: 24 GB of line records
 static bool use_ls(const blsgpu_ctx* c, size_t gsz, size_t groups) {
     return gsz >= 1 && gsz * groups >= c->ls_threshold && gsz * groups <= 0x3FFFFFF0ull;
 }
