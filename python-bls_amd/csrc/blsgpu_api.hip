@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/blsgpu.h"
+#include "blsgpu_tu.h"
 #include "blsgpu_kernels.hip"
 #include "fp28.h"
 #include "blsgpu_ml.hip"
@@ -19,6 +20,7 @@
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
 
+#if BLSGPU_EMIT(BLSGPU_TU_HOST)
 namespace {
 
 thread_local std::string g_err;
@@ -1467,3 +1469,4 @@ BLSGPU_EXPORT int blsgpu_debug_run(blsgpu_ctx* c, int which, unsigned nrounds, u
 #endif
 
 }  // extern "C"
+#endif  // BLSGPU_TU_HOST

@@ -145,7 +145,9 @@ __device__ __forceinline__ void tinv(int32_t* __restrict__ fre, int32_t* __restr
 // exponentiation; 576 canonical big-endian bytes to out_bytes[g].  ws: NSLOTS x 168 dwords per team.
 __global__ void __launch_bounds__(64, 2) k_fexp_team(const uint32_t* __restrict__ in, uint32_t m, uint32_t istride, uint32_t gstride,
                                                      uint32_t groups, int32_t* __restrict__ ws, uint32_t* __restrict__ out_bytes,
-                                                     uint32_t* __restrict__ dbg) {
+                                                     uint32_t* __restrict__ dbg)
+#if BLSGPU_EMIT(BLSGPU_TU_FX)
+{
     const Team t = ml::team_of_lane();
     const uint32_t g = blockIdx.x * ml::TEAMS + t.slot;
     const bool valid = t.slot < (uint32_t)ml::TEAMS && g < groups;
@@ -236,5 +238,8 @@ __global__ void __launch_bounds__(64, 2) k_fexp_team(const uint32_t* __restrict_
         for (int j = 0; j < 12; j++) o[12 + j] = bswap32(w[11 - j]);
     }
 }
+#else
+;
+#endif
 }  // namespace fx
 }  // namespace blsgpu

@@ -59,7 +59,9 @@ __device__ void sha256_block(const uint32_t w_in[16], uint32_t out[8]) {
 // One thread per SHA-256: thread t of message i computes half (t & 1) of hash512 number
 // (t >> 1) in {G2_0_c0, G2_0_c1, G2_1_c0, G2_1_c1}.  msg: n x 32 bytes; digests:
 // n x 4 x 64 bytes, the big-endian 512-bit values of ec.py:531-534 before `% q`.
-__global__ void __launch_bounds__(256) k_h2c_hash(const uint32_t* __restrict__ msg, uint32_t n, uint32_t* __restrict__ digests) {
+__global__ void __launch_bounds__(256) k_h2c_hash(const uint32_t* __restrict__ msg, uint32_t n, uint32_t* __restrict__ digests)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = gid >> 3, t = gid & 7u;
     if (i >= n) return;
@@ -78,6 +80,9 @@ __global__ void __launch_bounds__(256) k_h2c_hash(const uint32_t* __restrict__ m
 #pragma unroll
     for (int k = 0; k < 8; k++) digests[((size_t)i * 4 + (t >> 1)) * 16 + half * 8 + k] = bswap32(d[k]);
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // Fixed-exponent powers x^((q-3)/4) -- the square-root / Legendre-symbol exponent of
@@ -88,7 +93,9 @@ __global__ void __launch_bounds__(256) k_h2c_hash(const uint32_t* __restrict__ m
 // image: per team the slots [STATE0, STATE1) of its scratchpad, 12 u32 each.
 // k_pow: value v = (team v / cnt, index v % cnt): ACC[index] <- BASE[index]^E (Montgomery, < 2q).
 __global__ void __launch_bounds__(256) k_pow(uint32_t* __restrict__ img, uint32_t img_slots, uint32_t base_off, uint32_t acc_off,
-                                             uint32_t cnt, uint32_t total) {
+                                             uint32_t cnt, uint32_t total)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= total) return;
     const uint32_t team = v / cnt, k = v % cnt;
@@ -132,6 +139,9 @@ __global__ void __launch_bounds__(256) k_pow(uint32_t* __restrict__ img, uint32_
         for (int j = 0; j < 12; j++) dst[j] = y[j];
     }
 }
+#else
+;
+#endif
 
 __device__ __forceinline__ void img_load(uint32_t* team, const uint32_t* __restrict__ img, uint32_t state0, uint32_t nslots, uint32_t lane) {
     for (uint32_t d = lane; d < nslots * 12; d += 64) team[state0 * 12 + d] = img[d];
@@ -149,7 +159,9 @@ constexpr uint32_t H1_IMG = BLSVM_H1_STATE1 - BLSVM_H1_STATE0;       // image sl
 // WIDE = 0: t is n_enc x 96 bytes (c0 || c1, big-endian, < 2^384); WIDE = 1: n_enc x 128
 // bytes (two 512-bit big-endian hash values, reduced mod q in h1w_a).
 template <int STAGE, int WIDE>
-__global__ void __launch_bounds__(64, 2) k_h2c_stage(VmTables T, const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t* __restrict__ img) {
+__global__ void __launch_bounds__(64, 2) k_h2c_stage(VmTables T, const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t* __restrict__ img)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t first = blockIdx.x * BLSVM_H1_NE;
@@ -203,6 +215,9 @@ __global__ void __launch_bounds__(64, 2) k_h2c_stage(VmTables T, const uint32_t*
     }
     img_store(team, my, BLSVM_H1_STATE0, H1_IMG, lane);
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // The three stages once more with ONE ENCODING PER LANE on the register arithmetic (round 3).  On the VM a team of 64
@@ -303,7 +318,9 @@ template <int A, int B> __device__ __forceinline__ int chi(const r28::F<A, B>& v
 // stage 0 with the choice of the candidate inside: X[6i..] = x, U[6i] = u0, A1 = u1, N[3i] = n' (0 for a real u),
 // BASE[i] = ACC[i] = N(u) of the chosen candidate -> ONE power per encoding
 template <int WIDE>
-__global__ void __launch_bounds__(64) k_h2c_swj0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img) {
+__global__ void __launch_bounds__(64) k_h2c_swj0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     using namespace swl;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -379,8 +396,13 @@ __global__ void __launch_bounds__(64) k_h2c_swj0(const uint32_t* __restrict__ t,
     if (realu) st_zero(team, BLSVM_H1_N + 3 * i); else stv(team, BLSVM_H1_N + 3 * i, n);
     stv(team, BLSVM_H1_ACC + i, n); stv(team, BLSVM_H1_BASE + i, n);
 }
+#else
+;
+#endif
 // after z = n^E: r = z n', delta+- = (u0 +- r)/2, the square one of them -> BASE[i] = ACC[i]; its character -> N[3i + 1]
-__global__ void __launch_bounds__(64) k_h2c_swj1(uint32_t total, uint32_t* __restrict__ img) {
+__global__ void __launch_bounds__(64) k_h2c_swj1(uint32_t total, uint32_t* __restrict__ img)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     using namespace swl;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -398,8 +420,13 @@ __global__ void __launch_bounds__(64) k_h2c_swj1(uint32_t total, uint32_t* __res
     stv(team, BLSVM_H1_ACC + i, d); stv(team, BLSVM_H1_BASE + i, d);
     team[(BLSVM_H1_N + 3 * i + 1 - BLSVM_H1_STATE0) * 12] = (uint32_t)(J + 1);
 }
+#else
+;
+#endif
 // after z = d^E: x0 = z d (halved when delta+ was zero: the VM's (1 + chi)/2 selection with chi = 0), then h1_c as k_h2c_sw2
-__global__ void __launch_bounds__(64) k_h2c_swj2(uint32_t total, uint32_t* __restrict__ img) {
+__global__ void __launch_bounds__(64) k_h2c_swj2(uint32_t total, uint32_t* __restrict__ img)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     using namespace swl;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -428,9 +455,14 @@ __global__ void __launch_bounds__(64) k_h2c_swj2(uint32_t total, uint32_t* __res
     stv(team, BLSVM_H1_S + 5 * i + 3, r28::mul(ft, y1));
     stv(team, BLSVM_H1_S + 5 * i + 4, ft);
 }
+#else
+;
+#endif
 
 template <int WIDE>
-__global__ void __launch_bounds__(64) k_h2c_sw0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img) {
+__global__ void __launch_bounds__(64) k_h2c_sw0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     using namespace swl;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -494,8 +526,13 @@ __global__ void __launch_bounds__(64) k_h2c_sw0(const uint32_t* __restrict__ t, 
         stv(team, BLSVM_H1_ACC + k, n); stv(team, BLSVM_H1_BASE + k, n);
     }
 }
+#else
+;
+#endif
 
-__global__ void __launch_bounds__(64) k_h2c_sw1(uint32_t total, uint32_t* __restrict__ img) {
+__global__ void __launch_bounds__(64) k_h2c_sw1(uint32_t total, uint32_t* __restrict__ img)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     using namespace swl;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -531,8 +568,13 @@ __global__ void __launch_bounds__(64) k_h2c_sw1(uint32_t total, uint32_t* __rest
     stv(team, BLSVM_H1_ACC + 2 * i, dp); stv(team, BLSVM_H1_BASE + 2 * i, dp);
     stv(team, BLSVM_H1_ACC + 2 * i + 1, dm); stv(team, BLSVM_H1_BASE + 2 * i + 1, dm);
 }
+#else
+;
+#endif
 
-__global__ void __launch_bounds__(64) k_h2c_sw2(uint32_t total, uint32_t* __restrict__ img) {
+__global__ void __launch_bounds__(64) k_h2c_sw2(uint32_t total, uint32_t* __restrict__ img)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     using namespace swl;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -565,13 +607,18 @@ __global__ void __launch_bounds__(64) k_h2c_sw2(uint32_t total, uint32_t* __rest
     stv(team, BLSVM_H1_S + 5 * i + 3, r28::mul(ft, y1));
     stv(team, BLSVM_H1_S + 5 * i + 4, ft);
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // Kernel H2: one team = BLSVM_H2_NM messages: P = S0 + S1, cofactor clearing,
 // canonical affine bytes (x.c0 || x.c1 || y.c0 || y.c1, 192 B per message).
 // enc = the stage image: encoding e sits in team e / NE, slots S + 5 (e % NE) .. + 5.
 __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg,
-                                                     uint32_t* __restrict__ out) {
+                                                     uint32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t first = blockIdx.x * BLSVM_H2_NM;
@@ -598,6 +645,9 @@ __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t*
         if (first + m < n_msg) out[(size_t)(first + m) * 48 + o] = bswap32(team[(BLSVM_H2_OUT + 4 * m + e) * 12 + (11 - w)]);
     }
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // Cofactor clearing with ONE MESSAGE PER LANE, everything in registers (the same
@@ -613,7 +663,9 @@ __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t*
 // enc = the stage image (see k_h2c_stage): encoding e sits in team e / NE, slots S + 5 (e % NE) .. + 5.
 // out: n_msg x 192 bytes canonical affine (x.c0 || x.c1 || y.c0 || y.c1), (0,0) for infinity.
 __global__ void __launch_bounds__(64) k_h2c_clear_reg(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg,
-                                                      uint32_t* __restrict__ out) {
+                                                      uint32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     using namespace r28;
     typedef ptT<fe2> pt;
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -660,6 +712,9 @@ __global__ void __launch_bounds__(64) k_h2c_clear_reg(VmTables T, const uint32_t
         for (int w = 0; w < 12; w++) out[(size_t)m * 48 + k * 12 + w] = bswap32(y[11 - w]);
     }
 }
+#else
+;
+#endif
 
 // The same with ONE MESSAGE PER LANE PAIR (round 3): the Fq2 split of blsgpu_ml.hip / sp2 (even lane real parts, odd
 // lane imaginary parts).  k_h2c_clear_reg holds 460 registers and 6 KB of scratch per lane; here a lane holds half of
@@ -667,7 +722,9 @@ __global__ void __launch_bounds__(64) k_h2c_clear_reg(VmTables T, const uint32_t
 // clearing is a script (fexp_tables_gfx950.h BLS28_H2C_OPS, vmgen/gen_fexp.h2c_clear_script) over one point in
 // registers and five lane-private slots in HBM -- and 16 384 messages already give 512 wavefronts.
 __global__ void __launch_bounds__(64, 2) k_h2c_clear_pairs(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg, uint32_t* __restrict__ ws,
-                                                           uint32_t* __restrict__ out) {
+                                                           uint32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     using namespace sp2;
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t m = min(tid >> 1, n_msg - 1u), part = tid & 1u;
@@ -761,6 +818,9 @@ __global__ void __launch_bounds__(64, 2) k_h2c_clear_pairs(VmTables T, const uin
         }
     }
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // Point decompression: PublicKey.from_bytes (keys.py:28-40, DEG 1)
@@ -791,7 +851,9 @@ template <> struct DecompCfg<2> {
 // 2: image -> d*_c -> canonical bytes + accept flags.
 template <int DEG, int STAGE>
 __global__ void __launch_bounds__(64, 2) k_decompress(VmTables T, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ img,
-                                                      uint32_t* __restrict__ out, uint8_t* __restrict__ ok) {
+                                                      uint32_t* __restrict__ out, uint8_t* __restrict__ ok)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     using C = DecompCfg<DEG>;
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
@@ -843,10 +905,15 @@ __global__ void __launch_bounds__(64, 2) k_decompress(VmTables T, const uint32_t
     }
     if (lane < (uint32_t)C::NE && first + lane < n) ok[first + lane] = (uint8_t)(team[(C::OUT + NOUT * lane + 2 * DEG) * 12] & 1u);
 }
+#else
+;
+#endif
 
 #ifdef BLSGPU_STAMPS
 // diagnostic build only: see blsgpu_debug_run
-__global__ void __launch_bounds__(64) k_debug_run(VmTables T, const uint2* seq, uint32_t nrounds, uint32_t nslots, uint32_t* image, uint32_t light) {
+__global__ void __launch_bounds__(64) k_debug_run(VmTables T, const uint2* seq, uint32_t nrounds, uint32_t nslots, uint32_t* image, uint32_t light)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = lane; i < nslots * 12; i += 64) team[i] = image[i];
@@ -860,6 +927,27 @@ __global__ void __launch_bounds__(64) k_debug_run(VmTables T, const uint2* seq, 
     wave_fence();
     for (uint32_t i = lane; i < nslots * 12; i += 64) image[i] = team[i];
 }
+#else
+;
+#endif
 #endif
 
+// every instantiation the host side launches: this translation unit is the one that emits them (blsgpu_tu.h)
+#if BLSGPU_TU == BLSGPU_TU_H2C
+__attribute__((used)) static const void* const blsgpu_instances_h2c[] = {
+    (const void*)&k_h2c_stage<0, 0>,
+    (const void*)&k_h2c_stage<0, 1>,
+    (const void*)&k_h2c_stage<1, 0>,
+    (const void*)&k_h2c_stage<2, 0>,
+    (const void*)&k_h2c_sw0<0>,
+    (const void*)&k_h2c_sw0<1>,
+    (const void*)&k_h2c_swj0<0>,
+    (const void*)&k_h2c_swj0<1>,
+    (const void*)&k_decompress<1, 0>,
+    (const void*)&k_decompress<1, 1>,
+    (const void*)&k_decompress<1, 2>,
+    (const void*)&k_decompress<2, 0>,
+    (const void*)&k_decompress<2, 1>,
+    (const void*)&k_decompress<2, 2>};
+#endif
 }  // namespace blsgpu

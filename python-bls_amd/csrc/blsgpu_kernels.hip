@@ -460,7 +460,9 @@ __device__ __forceinline__ void wg_product_tree(const VmTables& T, uint32_t* sme
 // group b / bpg and never mixes groups (bpg = blocks per group), so partials
 // [g * bpg, (g + 1) * bpg) belong to group g.  A single multi-pairing is one group.
 __global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
-                                                uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials, DegenList dg) {
+                                                uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials, DegenList dg)
+#if BLSGPU_EMIT(BLSGPU_TU_VM)
+{
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
     __shared__ uint32_t any_degen;
     const uint32_t lane = threadIdx.x & 63u;
@@ -507,6 +509,9 @@ __global__ void __launch_bounds__(256, BLSGPU_MILLER_WPS) k_miller(VmTables T, c
         if (any_degen) degen_push(dg, lane);
     }
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // Kernel 1b (large batches): BLSVM_MP_G pairs per wavefront sharing ONE Miller
@@ -544,7 +549,9 @@ __device__ __forceinline__ void load_pair_raw(uint32_t* team, uint32_t p_slot, u
 
 template <int G>
 __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
-                                                     uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials, DegenList dg) {
+                                                     uint32_t gsz, uint32_t bpg, uint32_t* __restrict__ partials, DegenList dg)
+#if BLSGPU_EMIT(BLSGPU_TU_VM)
+{
     using C = MpCfg<G>;
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
@@ -598,6 +605,9 @@ __global__ void __launch_bounds__(64, BLSGPU_MP_WPS) k_miller_mp(VmTables T, con
     for (uint32_t i = lane; i < 144; i += 64) partials[(size_t)blockIdx.x * 144 + i] = team[f_dw + i];
     if (!ok) degen_push(dg, lane);                               // k_miller_slow rewrites this partial
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // The reference-faithful Miller loop for one pair (vmgen/slow_programs.py): affine twist point,
@@ -621,7 +631,9 @@ __device__ __forceinline__ void miller_exact_one(const VmTables& T, uint32_t* te
 // wavefront per listed block; every wavefront leaves the loop at the same bound.
 __global__ void __launch_bounds__(64) k_miller_slow(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
                                                     uint32_t gsz, uint32_t bpg, uint32_t per_block, uint32_t* __restrict__ partials,
-                                                    DegenList dg) {
+                                                    DegenList dg)
+#if BLSGPU_EMIT(BLSGPU_TU_VM)
+{
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
@@ -643,6 +655,9 @@ __global__ void __launch_bounds__(64) k_miller_slow(VmTables T, const uint32_t* 
         for (uint32_t i = lane; i < 144; i += 64) partials[(size_t)b * 144 + i] = team[F_DW + i];
     }
 }
+#else
+;
+#endif
 
 // register 0 (Montgomery, relaxed) of the team at the start of LDS -> 576 canonical big-endian bytes
 __device__ __forceinline__ void write_acc_bytes(const VmTables& T, uint32_t* team, uint32_t lane, uint32_t* __restrict__ dst) {
@@ -663,7 +678,9 @@ __device__ __forceinline__ void write_acc_bytes(const VmTables& T, uint32_t* tea
 // fq_miller_loop for every pair (blsgpu_miller_loop_batch): out[p] = 576 canonical big-endian
 // bytes of the reference's own Miller value -- not a multiple of it.
 __global__ void __launch_bounds__(64) k_miller_exact(VmTables T, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
-                                                     const uint8_t* __restrict__ inf, uint32_t n, uint32_t* __restrict__ out_bytes) {
+                                                     const uint8_t* __restrict__ inf, uint32_t n, uint32_t* __restrict__ out_bytes)
+#if BLSGPU_EMIT(BLSGPU_TU_VM)
+{
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     team_init_consts(T, team, lane);
@@ -673,6 +690,9 @@ __global__ void __launch_bounds__(64) k_miller_exact(VmTables T, const uint32_t*
         write_acc_bytes(T, team, lane, out_bytes + (size_t)p * 144);
     }
 }
+#else
+;
+#endif
 
 // Fq12 operations on byte inputs, one element (pair) per wavefront: op 0 add, 1 sub, 2 mul, 3 neg, 4 invert
 // (fq12_add / fq12_sub / fq12_mul / fq12_neg / fq12_invert, fields_t.py:321-352, 503-554, 328-337; 0^-1 = 0),
@@ -681,7 +701,9 @@ __global__ void __launch_bounds__(64) k_miller_exact(VmTables T, const uint32_t*
 #define BLSGPU_SEG(NAME) T.segflat + BLSVM_SEGF_##NAME##_OFF, BLSVM_SEGF_##NAME##_LEN
 __global__ void __launch_bounds__(64) k_fq12_op(VmTables T, uint32_t op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                 const uint8_t* __restrict__ ebits, uint32_t nbits, uint32_t n,
-                                                uint32_t* __restrict__ out_bytes) {
+                                                uint32_t* __restrict__ out_bytes)
+#if BLSGPU_EMIT(BLSGPU_TU_VM)
+{
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     team_init_consts(T, team, lane);
@@ -715,12 +737,17 @@ __global__ void __launch_bounds__(64) k_fq12_op(VmTables T, uint32_t op, const u
         write_acc_bytes(T, team, lane, out_bytes + (size_t)i * 144);
     }
 }
+#else
+;
+#endif
 #undef BLSGPU_SEG
 
 // fq2_double_line_eval(R, P) (fields_t.py:1035-1049; q == nullptr) / fq2_add_line_eval(R, Q, P)
 // (:1052-1078) for n triples: r, q n x 192 bytes, p n x 96 bytes -> n x 576 bytes.
 __global__ void __launch_bounds__(64) k_line_eval(VmTables T, const uint32_t* __restrict__ r, const uint32_t* __restrict__ q,
-                                                  const uint32_t* __restrict__ p, uint32_t n, uint32_t* __restrict__ out_bytes) {
+                                                  const uint32_t* __restrict__ p, uint32_t n, uint32_t* __restrict__ out_bytes)
+#if BLSGPU_EMIT(BLSGPU_TU_VM)
+{
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     team_init_consts(T, team, lane);
@@ -738,6 +765,9 @@ __global__ void __launch_bounds__(64) k_line_eval(VmTables T, const uint32_t* __
         write_acc_bytes(T, team, lane, out_bytes + (size_t)i * 144);
     }
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // Kernel 2: product of Montgomery Fq12 partials.  Block b multiplies partials
@@ -750,7 +780,9 @@ __global__ void __launch_bounds__(64) k_line_eval(VmTables T, const uint32_t* __
 __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __restrict__ in, uint32_t m, uint32_t per_block,
                                                  uint32_t istride, uint32_t gstride,
                                                  uint32_t* __restrict__ out_partials, uint32_t do_final,
-                                                 uint32_t* __restrict__ out_bytes) {
+                                                 uint32_t* __restrict__ out_bytes)
+#if BLSGPU_EMIT(BLSGPU_TU_VM)
+{
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -796,6 +828,9 @@ __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __re
         }
     }
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // Kernel 3: many independent results.  Team g multiplies partials
@@ -803,7 +838,9 @@ __global__ void __launch_bounds__(512) k_reduce(VmTables T, const uint32_t* __re
 // exponentiation and writes 576 canonical bytes to out_bytes[g].  No workgroup
 // barrier: every team is on its own.
 __global__ void __launch_bounds__(512) k_final_groups(VmTables T, const uint32_t* __restrict__ in, uint32_t gsz, uint32_t groups,
-                                                       uint32_t* __restrict__ out_bytes) {
+                                                       uint32_t* __restrict__ out_bytes)
+#if BLSGPU_EMIT(BLSGPU_TU_VM)
+{
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -838,10 +875,15 @@ __global__ void __launch_bounds__(512) k_final_groups(VmTables T, const uint32_t
         out_bytes[(size_t)g * 144 + k] = bswap32(team[R1_DW + c * 12 + (11 - w)]);
     }
 }
+#else
+;
+#endif
 
 // bytes (m x 576, canonical big-endian) -> Montgomery partials (m x 144 u32), one team each
 __global__ void __launch_bounds__(512) k_bytes_to_partials(VmTables T, const uint32_t* __restrict__ in_bytes, uint32_t m,
-                                                           uint32_t* __restrict__ out_partials) {
+                                                           uint32_t* __restrict__ out_partials)
+#if BLSGPU_EMIT(BLSGPU_TU_VM)
+{
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -857,5 +899,14 @@ __global__ void __launch_bounds__(512) k_bytes_to_partials(VmTables T, const uin
     run_rounds<true>(T, T.segflat + BLSVM_SEGF_TO_MONT_0_1_OFF, BLSVM_SEGF_TO_MONT_0_1_LEN, wave * (TEAM_BYTES / 16), lane);
     for (uint32_t k = lane; k < 144; k += 64) out_partials[(size_t)g * 144 + k] = team[F_DW + k];
 }
+#else
+;
+#endif
 
+// every instantiation the host side launches: this translation unit is the one that emits them (blsgpu_tu.h)
+#if BLSGPU_TU == BLSGPU_TU_VM
+__attribute__((used)) static const void* const blsgpu_instances_vm[] = {
+    (const void*)&k_miller_mp<2>,
+    (const void*)&k_miller_mp<BLSVM_MP_G>};
+#endif
 }  // namespace blsgpu

@@ -107,7 +107,9 @@ __device__ __forceinline__ void chord_step(fe2& X, fe2& Y, fe2& Z, const fe2& xq
 #define BLSGPU_ML_LINES_WAVES 1
 #endif
 __global__ void __launch_bounds__(64, BLSGPU_ML_LINES_WAVES) k_ml_lines(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
-                                                                         int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg) {
+                                                                         int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
     const uint32_t p = blockIdx.x * 64u + threadIdx.x;
     if (p >= n) return;
     const uint32_t* s1 = g1 + (size_t)p * 24;
@@ -147,6 +149,9 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_LINES_WAVES) k_ml_lines(const ui
         dg.blocks[at] = p;
     }
 }
+#else
+;
+#endif
 
 // ---- stage A on LANE PAIRS: an Fq2 value split over two adjacent lanes ---------------------------------------------
 // The even lane holds the real part, the odd lane the imaginary part; the partner's part is one DPP move per limb away
@@ -319,7 +324,9 @@ __device__ __forceinline__ void chord_step(h& X, h& Y, h& Z, const h& xq, const 
 #define BLSGPU_ML_LINES2_WAVES 2
 #endif
 __global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines2(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
-                                                                           int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg) {
+                                                                           int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     const uint32_t pr = t >> 1;
     const uint32_t p = pr < n ? pr : n - 1u;                      // the last wavefront's spare lanes repeat the last pair
@@ -369,6 +376,9 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines2(const 
         }
     }
 }
+#else
+;
+#endif
 
 // ---- the reference's own lines for the listed pairs ---------------------------------------------------------------
 // fq_miller_loop is a total function of the coordinates (fields_t.py:1035-1078, 641-686): affine formulas with
@@ -427,7 +437,9 @@ __device__ __forceinline__ Aff exact_double(const h& rx, const h& ry, const h& i
 // block's group).  per_block == 0: an entry is a pair and the records are that pair's own.
 __global__ void __launch_bounds__(64) k_ml_lines_exact(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
                                                        int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg,
-                                                       uint32_t gsz, uint32_t bpg, uint32_t per_block) {
+                                                       uint32_t gsz, uint32_t bpg, uint32_t per_block)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
     using namespace sp;
     const uint32_t entries = __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)dg.count);
     const uint32_t total = per_block ? entries * per_block : entries;
@@ -518,6 +530,9 @@ __global__ void __launch_bounds__(64) k_ml_lines_exact(const uint32_t* __restric
         if (part == 0u && er < total) bad[v] = (uint8_t)flag;
     }
 }
+#else
+;
+#endif
 
 // ---- stages B / merge / Horner: six lanes per accumulator -----------------------------------------------------------
 struct Team {
@@ -676,7 +691,9 @@ __device__ __forceinline__ void set_one(int32_t* __restrict__ fre, int32_t* __re
 #endif
 __global__ void __launch_bounds__(64, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad, uint32_t n,
                                                                          uint32_t gsz, uint32_t chunk, uint32_t cpg, uint32_t nteams,
-                                                                         int32_t* __restrict__ out) {
+                                                                         int32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
     const Team t = team_of_lane();
     const uint32_t id = blockIdx.x * TEAMS + t.slot;
     const bool valid = t.slot < (uint32_t)TEAMS && id < nteams;
@@ -720,11 +737,16 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const in
         for (int k = 0; k < NL; k++) { o[k] = fre[k]; o[NL + k] = fim[k]; }
     }
 }
+#else
+;
+#endif
 
 // One level of the product tree over the chunks: team (g, j', L) multiplies the records (g, j, L), j in
 // [j' * fan, min(cpg_in, (j' + 1) * fan)), of `in` (indexed as k_ml_accum's output with cpg_in) -> out (cpg_out).
 __global__ void __launch_bounds__(64, 2) k_ml_merge(const int32_t* __restrict__ in, uint32_t cpg_in, uint32_t fan, uint32_t cpg_out,
-                                                    uint32_t nteams, int32_t* __restrict__ out) {
+                                                    uint32_t nteams, int32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
     const Team t = team_of_lane();
     const uint32_t id = blockIdx.x * TEAMS + t.slot;
     const bool valid = t.slot < (uint32_t)TEAMS && id < nteams;
@@ -755,11 +777,16 @@ __global__ void __launch_bounds__(64, 2) k_ml_merge(const int32_t* __restrict__ 
         for (int k = 0; k < NL; k++) { o[k] = fre[k]; o[NL + k] = fim[k]; }
     }
 }
+#else
+;
+#endif
 
 // Team g: f = M_0; for L = 1 .. 67: (tangent: f <- f^2;) f <- f M_L with M_L = prods[(g * 68 + L) * 168]; then the
 // VM's form: partials[g * pstride + ...] (144 words, the reference's flat order, x 2^384 canonical).
 __global__ void __launch_bounds__(64, 2) k_ml_horner(const int32_t* __restrict__ prods, uint32_t groups, uint32_t* __restrict__ partials,
-                                                     uint32_t pstride) {
+                                                     uint32_t pstride)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
     __shared__ int32_t own[TEAMS + 1][DENSE_DW];
     const Team t = team_of_lane();
     const uint32_t g = blockIdx.x * TEAMS + t.slot;
@@ -796,6 +823,9 @@ __global__ void __launch_bounds__(64, 2) k_ml_horner(const int32_t* __restrict__
         for (int k = 0; k < 12; k++) o[12 + k] = w[k];
     }
 }
+#else
+;
+#endif
 
 // Small groups (a batch of verifications of a few pairs each: threshold verifies, single signatures): the classic loop
 // f <- f^2 prod_i l_{i,L} with ONE GROUP PER TEAM of six lanes, lines from k_ml_lines2 -- the per-line products of a
@@ -811,7 +841,9 @@ struct TeamRec {                                   // the team's own f as the de
 // goes to partials[index[g] * pstride].
 __global__ void __launch_bounds__(64, 2) k_ml_small(const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad, uint32_t n, uint32_t gsz,
                                                     uint32_t groups, uint32_t* __restrict__ partials, uint32_t pstride,
-                                                    const uint32_t* __restrict__ count, const uint32_t* __restrict__ index) {
+                                                    const uint32_t* __restrict__ count, const uint32_t* __restrict__ index)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
     const Team t = team_of_lane();
     if (count != nullptr) {
         groups = min(groups, __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)count));
@@ -873,6 +905,9 @@ __global__ void __launch_bounds__(64, 2) k_ml_small(const int32_t* __restrict__ 
         for (int k = 0; k < 12; k++) o[12 + k] = w[k];
     }
 }
+#else
+;
+#endif
 
 // The same chain with ONE GROUP PER WAVEFRONT and the six terms of every coefficient on six different lanes: lane
 // (t, k) = 6 t + k computes the one Fq2 product F_{k-t} g_t (two sums of two products), the six products of a coefficient
@@ -911,7 +946,9 @@ __device__ __forceinline__ void wide_op(int32_t* __restrict__ fre, int32_t* __re
     for (int j = 0; j < NL; j++) { fre[j] = nr.v[j]; fim[j] = ni.v[j]; }
 }
 __global__ void __launch_bounds__(64) k_ml_horner_wide(const int32_t* __restrict__ prods, uint32_t groups, uint32_t* __restrict__ partials,
-                                                       uint32_t pstride) {
+                                                       uint32_t pstride)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t l36 = lane < 36u ? lane : lane - 36u;
     const uint32_t t = l36 / 6u, k = l36 - t * 6u;
@@ -953,6 +990,9 @@ __global__ void __launch_bounds__(64) k_ml_horner_wide(const int32_t* __restrict
         for (int j = 0; j < 12; j++) o[12 + j] = w[j];
     }
 }
+#else
+;
+#endif
 }  // namespace ml
 
 }  // namespace blsgpu

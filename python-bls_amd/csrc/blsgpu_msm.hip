@@ -48,7 +48,9 @@ __device__ __forceinline__ uint32_t inf_dword(const uint32_t* team, uint32_t k) 
 //   scalars: 32 bytes big-endian per point, or nullptr for all-ones (plain sums)
 template <int DEG>
 __global__ void __launch_bounds__(256, 3) k_msm(VmTables T, const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars,
-                                             uint32_t k, uint32_t chunk, uint32_t bpg, uint32_t* __restrict__ partials) {
+                                             uint32_t k, uint32_t chunk, uint32_t bpg, uint32_t* __restrict__ partials)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using C = MsmCfg<DEG>;
     constexpr uint32_t PT_DW = 24 * DEG;            // dwords per affine input point
     constexpr uint32_t PJ_DW = 36 * DEG;            // dwords per projective point
@@ -139,12 +141,17 @@ __global__ void __launch_bounds__(256, 3) k_msm(VmTables T, const uint32_t* __re
         for (uint32_t i = lane; i < PJ_DW; i += 64) partials[(size_t)blockIdx.x * PJ_DW + i] = team[C::PR0 * 12 + i];
     }
 }
+#else
+;
+#endif
 
 // Kernel B: one team per group: sum of the group's bpg partials, conversion to
 // affine canonical bytes (x || y, (0,0) for infinity) and an infinity flag.
 template <int DEG>
 __global__ void __launch_bounds__(256) k_msm_finish(VmTables T, const uint32_t* __restrict__ partials, uint32_t bpg,
-                                                    uint32_t groups, uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf) {
+                                                    uint32_t groups, uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using C = MsmCfg<DEG>;
     constexpr uint32_t PJ_DW = 36 * DEG;
     constexpr uint32_t PT_DW = 24 * DEG;
@@ -183,6 +190,9 @@ __global__ void __launch_bounds__(256) k_msm_finish(VmTables T, const uint32_t* 
     const uint64_t nz = __ballot(any != 0);
     if (out_inf && lane == 0) out_inf[g] = (nz == 0) ? 1 : 0;
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // Bucket method (Pippenger) for one large sum  sum_i s_i P_i  (BLS.aggregate_pub_keys at
@@ -212,7 +222,9 @@ template <int DEG> struct PipCfg {
 // affine big-endian points -> projective Montgomery triples (36*DEG u32 each, (0:1:0) for
 // the (0,0) encoding of infinity), once, so that the 64 window passes need no conversion
 template <int DEG>
-__global__ void __launch_bounds__(256, 3) k_msm_prep(VmTables T, const uint32_t* __restrict__ pts, uint32_t k, uint32_t* __restrict__ prep) {
+__global__ void __launch_bounds__(256, 3) k_msm_prep(VmTables T, const uint32_t* __restrict__ pts, uint32_t k, uint32_t* __restrict__ prep)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using C = MsmCfg<DEG>;
     constexpr uint32_t PT_DW = 24 * DEG, PJ_DW = 36 * DEG;
     uint32_t* smem = reinterpret_cast<uint32_t*>(smem4);
@@ -243,10 +255,15 @@ __global__ void __launch_bounds__(256, 3) k_msm_prep(VmTables T, const uint32_t*
         prep[(size_t)first * PJ_DW + d] = ((zmask >> p) & 1ull) ? inf_dword<DEG>(team, d % PJ_DW) : team[C::A * 12 + d];
     }
 }
+#else
+;
+#endif
 
 template <int DEG>
 __global__ void __launch_bounds__(64, 2) k_msm_pip(VmTables T, const uint32_t* __restrict__ prep, const uint32_t* __restrict__ scalars,
-                                                   uint32_t k, uint32_t chunk, uint32_t* __restrict__ partials) {
+                                                   uint32_t k, uint32_t chunk, uint32_t* __restrict__ partials)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using C = MsmCfg<DEG>;
     using P = PipCfg<DEG>;
     constexpr uint32_t PJ_DW = 36 * DEG;
@@ -330,11 +347,16 @@ __global__ void __launch_bounds__(64, 2) k_msm_pip(VmTables T, const uint32_t* _
     uint32_t* dst = partials + (((size_t)grp * PIP_W + win) * gridDim.x + blockIdx.x) * PJ_DW;
     for (uint32_t i = lane; i < PJ_DW; i += 64) dst[i] = team[C::PR0 * 12 + i];
 }
+#else
+;
+#endif
 
 // W_w = sum over chunks of partial[w][chunk]; one team per window
 template <int DEG>
 __global__ void __launch_bounds__(64) k_msm_pip_windows(VmTables T, const uint32_t* __restrict__ partials, uint32_t chunks,
-                                                        uint32_t* __restrict__ winsums) {
+                                                        uint32_t* __restrict__ winsums)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using C = MsmCfg<DEG>;
     constexpr uint32_t PJ_DW = 36 * DEG;
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
@@ -352,11 +374,16 @@ __global__ void __launch_bounds__(64) k_msm_pip_windows(VmTables T, const uint32
     wave_fence();
     for (uint32_t d = lane; d < PJ_DW; d += 64) winsums[(size_t)win * PJ_DW + d] = team[C::PR0 * 12 + d];
 }
+#else
+;
+#endif
 
 // result = sum_w 2^(cbits w) W_w over nwin windows (Horner from the top window), affine canonical bytes
 template <int DEG>
 __global__ void __launch_bounds__(64) k_msm_pip_horner(VmTables T, const uint32_t* __restrict__ winsums, uint32_t nwin, uint32_t cbits,
-                                                       uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf) {
+                                                       uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using C = MsmCfg<DEG>;
     constexpr uint32_t PJ_DW = 36 * DEG, PT_DW = 24 * DEG;
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
@@ -391,12 +418,17 @@ __global__ void __launch_bounds__(64) k_msm_pip_horner(VmTables T, const uint32_
     const uint64_t nz = __ballot(any != 0);
     if (out_inf && lane == 0) out_inf[blockIdx.x] = (nz == 0) ? 1 : 0;
 }
+#else
+;
+#endif
 
 // The same Horner for a BATCH of G2 sums (the threshold combine of BASELINE config 4): BLSVM_HMSM2_NP sums per team in
 // lock step (vmgen/msm_programs.build_horner) -- a G2 doubling is 10-12 lane operations, so one sum per team leaves
 // five lanes in six idle.  winsums: groups x nwin projective points; out: groups x 192 bytes.
 __global__ void __launch_bounds__(64) k_msm_horner_np(VmTables T, const uint32_t* __restrict__ winsums, uint32_t nwin, uint32_t cbits,
-                                                      uint32_t groups, uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf) {
+                                                      uint32_t groups, uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     constexpr uint32_t DEG = 2, PJ_DW = 36 * DEG, PT_DW = 24 * DEG, NP = BLSVM_HMSM2_NP;
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
@@ -438,6 +470,9 @@ __global__ void __launch_bounds__(64) k_msm_horner_np(VmTables T, const uint32_t
         if (out_inf && lane == 0) out_inf[first + p] = (nz == 0) ? 1 : 0;
     }
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // Bucket method with ONE (group, chunk, window) PER LANE (fp28.h: 14 signed 28-bit limbs, sums of
@@ -465,7 +500,9 @@ template <class E> __device__ __forceinline__ void lane_st_pt_vm(const r28::ptT<
 // lane: a product by R^2 per coordinate
 template <int DEG>
 __global__ void __launch_bounds__(256) k_lane_prep(const uint32_t* __restrict__ pts, uint32_t n, uint32_t* __restrict__ prep,
-                                                   uint8_t* __restrict__ live) {
+                                                   uint8_t* __restrict__ live)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t any = 0;
@@ -478,6 +515,9 @@ __global__ void __launch_bounds__(256) k_lane_prep(const uint32_t* __restrict__ 
     }
     live[i] = any ? 1 : 0;
 }
+#else
+;
+#endif
 
 // prep / live: k_lane_prep's; partial (win, chunk) of group g is written at partials[((g * PIP_W + win) * chunks +
 // chunk) * PJ] -- the layout k_msm_pip_windows reads -- in the VM's form (PJ = 36 DEG) when vm_out, else L28 (42 DEG).
@@ -485,7 +525,9 @@ template <int DEG>
 __global__ void __launch_bounds__(64) k_msm_lane(const uint32_t* __restrict__ prep, const uint8_t* __restrict__ live,
                                                  const uint32_t* __restrict__ scalars, uint32_t k,
                                                  uint32_t chunk, uint32_t chunks, uint32_t total, uint32_t* __restrict__ buckets,
-                                                 uint32_t* __restrict__ partials, uint32_t vm_out) {
+                                                 uint32_t* __restrict__ partials, uint32_t vm_out)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     typedef typename LaneElem<DEG>::E E;
     constexpr uint32_t PJ_DW = L28_PJ * DEG, AF_DW = L28_AFF * DEG;
     const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
@@ -549,6 +591,9 @@ __global__ void __launch_bounds__(64) k_msm_lane(const uint32_t* __restrict__ pr
     if (vm_out) lane_st_pt_vm(tot, partials + o * 36 * DEG);
     else r28::pt_st(tot, partials + o * PJ_DW);
 }
+#else
+;
+#endif
 
 // ---- the same bucket sums for G2 on LANE PAIRS (round 3) ------------------------------------------------------------
 // k_msm_lane<2> needs 511 registers and 1.7 KB of scratch per lane for a twist addition (one wavefront per SIMD, 55 % of
@@ -650,7 +695,9 @@ __device__ __forceinline__ void st_vm(const pt& r, uint32_t* __restrict__ p) {  
 __global__ void __launch_bounds__(64, BLSGPU_MSM_LANE2X_WAVES) k_msm_lane2x(const uint32_t* __restrict__ prep, const uint8_t* __restrict__ live,
                                                   const uint32_t* __restrict__ scalars, uint32_t k,
                                                   uint32_t chunk, uint32_t chunks, uint32_t total, uint32_t* __restrict__ buckets,
-                                                  uint32_t* __restrict__ partials, uint32_t vm_out) {
+                                                  uint32_t* __restrict__ partials, uint32_t vm_out)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     constexpr uint32_t PJ_DW = L28_PJ * 2, AF_DW = L28_AFF * 2;
     const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t L = min(T >> 1, total - 1u);                                  // spare lanes of the last wavefront repeat the last item
@@ -718,11 +765,16 @@ __global__ void __launch_bounds__(64, BLSGPU_MSM_LANE2X_WAVES) k_msm_lane2x(cons
         else sp2::pt_st(tot, partials + o * PJ_DW);
     }
 }
+#else
+;
+#endif
 
 // out[w * nfold + f] = sum of partials[w * chunks + f * per .. + per): one run per lane; L28 in, L28 or the VM's form out
 template <int DEG>
 __global__ void __launch_bounds__(64) k_msm_lane_fold(const uint32_t* __restrict__ partials, uint32_t chunks, uint32_t per, uint32_t nfold,
-                                                      uint32_t total, uint32_t* __restrict__ out, uint32_t vm_out) {
+                                                      uint32_t total, uint32_t* __restrict__ out, uint32_t vm_out)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     typedef typename LaneElem<DEG>::E E;
     constexpr uint32_t PJ_DW = L28_PJ * DEG;
     const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
@@ -735,6 +787,9 @@ __global__ void __launch_bounds__(64) k_msm_lane_fold(const uint32_t* __restrict
     if (vm_out) lane_st_pt_vm(acc, out + ((size_t)w * nfold + f) * 36 * DEG);
     else r28::pt_st(acc, out + ((size_t)w * nfold + f) * PJ_DW);
 }
+#else
+;
+#endif
 
 // ---------------------------------------------------------------------------
 // Sorted buckets: ONE large G1 sum with scalars (BLS.aggregate_pub_keys(secure) at scale, bls.py:203-223 --
@@ -776,19 +831,26 @@ __device__ __forceinline__ void srt_histogram(uint32_t* hist, const uint32_t* __
     __syncthreads();
 }
 __global__ void __launch_bounds__(1024) k_srt_count(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ live, uint32_t n,
-                                                    uint32_t cb, uint32_t* __restrict__ cnt) {
+                                                    uint32_t cb, uint32_t* __restrict__ cnt)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     __shared__ uint32_t hist[1u << SRT_MAXBITS];
     const uint32_t w = blockIdx.y, lo = blockIdx.x * SRT_SLICE, hi = min(n, lo + SRT_SLICE);
     srt_histogram(hist, scalars, live, lo, hi, w, cb);
     for (uint32_t k = threadIdx.x; k < (1u << cb); k += blockDim.x)
         if (hist[k]) atomicAdd(&cnt[(w << cb) + k], hist[k]);
 }
+#else
+;
+#endif
 
 // start[key] = exclusive prefix sum of cnt (start[nkeys] = number of list entries), cursor = start.
 // k_srt_scan_window: workgroup w scans the 2^cb counts of its window (positions inside the window) and notes the window's
 // total and longest run; k_srt_scan_add: adds the totals of the windows before.
 __global__ void __launch_bounds__(1024) k_srt_scan_window(const uint32_t* __restrict__ cnt, uint32_t cb, uint32_t* __restrict__ start,
-                                                          uint32_t* __restrict__ wtot, uint32_t* __restrict__ wmax) {
+                                                          uint32_t* __restrict__ wtot, uint32_t* __restrict__ wmax)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     __shared__ uint32_t part[1024];
     __shared__ uint32_t mx[1024];
     const uint32_t t = threadIdx.x, nb = 1u << cb, per = (nb + 1023u) / 1024u;
@@ -814,9 +876,14 @@ __global__ void __launch_bounds__(1024) k_srt_scan_window(const uint32_t* __rest
     }
     if (t == 1023) { wtot[blockIdx.x] = part[t]; wmax[blockIdx.x] = mx[t]; }
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(1024) k_srt_scan_add(uint32_t nwin, uint32_t cb, const uint32_t* __restrict__ wtot,
                                                        const uint32_t* __restrict__ wmax, uint32_t* __restrict__ start,
-                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ maxcnt) {
+                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ maxcnt)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     uint32_t base = 0, all = 0, m = 0;
     for (uint32_t w = 0; w < nwin; w++) {
         if (w < blockIdx.x) base += wtot[w];
@@ -831,9 +898,14 @@ __global__ void __launch_bounds__(1024) k_srt_scan_add(uint32_t nwin, uint32_t c
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { start[(size_t)nwin << cb] = all; maxcnt[0] = m; }
 }
+#else
+;
+#endif
 
 __global__ void __launch_bounds__(1024) k_srt_scatter(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ live, uint32_t n,
-                                                      uint32_t cb, uint32_t* __restrict__ cursor, uint32_t* __restrict__ idx) {
+                                                      uint32_t cb, uint32_t* __restrict__ cursor, uint32_t* __restrict__ idx)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     __shared__ uint32_t hist[1u << SRT_MAXBITS];
     const uint32_t w = blockIdx.y, lo = blockIdx.x * SRT_SLICE, hi = min(n, lo + SRT_SLICE);
     srt_histogram(hist, scalars, live, lo, hi, w, cb);
@@ -845,6 +917,9 @@ __global__ void __launch_bounds__(1024) k_srt_scatter(const uint32_t* __restrict
         if (d) idx[atomicAdd(&hist[d], 1u)] = i;
     }
 }
+#else
+;
+#endif
 
 // lane l sums list entries [l per, (l + 1) per): see the header of this section.  headkey[l] = key of the piece
 // that continues a run begun before the lane (or ~0), headpart[l] its sum.
@@ -855,7 +930,9 @@ constexpr uint32_t SRT_PJ = L28_PJ;                           // dwords of a G1 
 __global__ void __launch_bounds__(64, BLSGPU_SRT_WAVES) k_srt_accum(const uint32_t* __restrict__ prep, const uint32_t* __restrict__ idx,
                                                      const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
                                                      uint32_t* __restrict__ bsum, uint32_t* __restrict__ headpart,
-                                                     uint32_t* __restrict__ headkey) {
+                                                     uint32_t* __restrict__ headkey)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using r28::fe;
     const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= nlanes) return;
@@ -893,13 +970,18 @@ __global__ void __launch_bounds__(64, BLSGPU_SRT_WAVES) k_srt_accum(const uint32
     }
     headkey[L] = hk;
 }
+#else
+;
+#endif
 
 // one lane per key: empty buckets become infinity, the pieces of later lanes are added to the bucket.  A run of more
 // than SRT_LONG pieces (the top window of 255-bit scalars has 2^8 digits for 2^20 points) goes to k_srt_fix_long.
 constexpr uint32_t SRT_LONG = 3;
 __global__ void __launch_bounds__(64) k_srt_fix(const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
                                                 const uint32_t* __restrict__ headpart, const uint32_t* __restrict__ headkey,
-                                                uint32_t* __restrict__ bsum, uint32_t* __restrict__ nlong, uint32_t* __restrict__ longkeys) {
+                                                uint32_t* __restrict__ bsum, uint32_t* __restrict__ nlong, uint32_t* __restrict__ longkeys)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using r28::fe;
     const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
@@ -915,11 +997,16 @@ __global__ void __launch_bounds__(64) k_srt_fix(const uint32_t* __restrict__ sta
         if (headkey[l] == key) acc = r28::padd(acc, r28::pt_ld<fe>(headpart + (size_t)l * SRT_PJ));
     r28::pt_st(acc, bsum + (size_t)key * SRT_PJ);
 }
+#else
+;
+#endif
 
 // one wavefront per long run: lane j sums the pieces l0 + 1 + j, + 64, ..; butterfly over the lanes; lane 0 adds the bucket
 __global__ void __launch_bounds__(64) k_srt_fix_long(const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
                                                      const uint32_t* __restrict__ headpart, uint32_t* __restrict__ bsum,
-                                                     const uint32_t* __restrict__ nlong, const uint32_t* __restrict__ longkeys) {
+                                                     const uint32_t* __restrict__ nlong, const uint32_t* __restrict__ longkeys)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using r28::fe;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = start[nkeys], per = (total + nlanes - 1u) / nlanes, cnt = *nlong;
@@ -946,13 +1033,18 @@ __global__ void __launch_bounds__(64) k_srt_fix_long(const uint32_t* __restrict_
         }
     }
 }
+#else
+;
+#endif
 
 // lane (window w, bit b, item j): the SRT_BITADDS buckets of window w whose digits are the numbers m = SRT_BITADDS j ..
 // + SRT_BITADDS - 1 with a 1 inserted at bit b (the m-th digit that has bit b) -> out[(w * cb + b) * nitem + j]; every lane
 // the same number of additions, 2^(cb-1) / SRT_BITADDS items per (window, bit)
 constexpr uint32_t SRT_BITADDS = 8;
 __global__ void __launch_bounds__(64) k_srt_bits(const uint32_t* __restrict__ bsum, uint32_t nwin, uint32_t cb, uint32_t total,
-                                                 uint32_t* __restrict__ out) {
+                                                 uint32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using r28::fe;
     const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= total) return;
@@ -966,9 +1058,14 @@ __global__ void __launch_bounds__(64) k_srt_bits(const uint32_t* __restrict__ bs
     }
     r28::pt_st(acc, out + (size_t)L * SRT_PJ);
 }
+#else
+;
+#endif
 
 // W_w = sum_b 2^b S_(w,b): one team per window, Horner over the bits
-__global__ void __launch_bounds__(64) k_srt_windows(VmTables T, const uint32_t* __restrict__ bitsums, uint32_t cb, uint32_t* __restrict__ winsums) {
+__global__ void __launch_bounds__(64) k_srt_windows(VmTables T, const uint32_t* __restrict__ bitsums, uint32_t cb, uint32_t* __restrict__ winsums)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
     using C = MsmCfg<1>;
     uint32_t* team = reinterpret_cast<uint32_t*>(smem4);
     const uint32_t lane = threadIdx.x & 63u;
@@ -986,5 +1083,30 @@ __global__ void __launch_bounds__(64) k_srt_windows(VmTables T, const uint32_t* 
     wave_fence();
     for (uint32_t d = lane; d < 36; d += 64) winsums[(size_t)blockIdx.x * 36 + d] = team[C::PR0 * 12 + d];
 }
+#else
+;
+#endif
 
+// every instantiation the host side launches: this translation unit is the one that emits them (blsgpu_tu.h)
+#if BLSGPU_TU == BLSGPU_TU_MSM
+__attribute__((used)) static const void* const blsgpu_instances_msm[] = {
+    (const void*)&k_msm<1>,
+    (const void*)&k_msm<2>,
+    (const void*)&k_msm_finish<1>,
+    (const void*)&k_msm_finish<2>,
+    (const void*)&k_msm_prep<1>,
+    (const void*)&k_msm_prep<2>,
+    (const void*)&k_msm_pip<1>,
+    (const void*)&k_msm_pip<2>,
+    (const void*)&k_msm_pip_windows<1>,
+    (const void*)&k_msm_pip_windows<2>,
+    (const void*)&k_msm_pip_horner<1>,
+    (const void*)&k_msm_pip_horner<2>,
+    (const void*)&k_lane_prep<1>,
+    (const void*)&k_lane_prep<2>,
+    (const void*)&k_msm_lane<1>,
+    (const void*)&k_msm_lane<2>,
+    (const void*)&k_msm_lane_fold<1>,
+    (const void*)&k_msm_lane_fold<2>};
+#endif
 }  // namespace blsgpu
