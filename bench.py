@@ -713,8 +713,18 @@ def run_h2c(env, args):
     reps = max(1, args.steps)
     dt = device_timed(env, lambda: eng.lib.blsgpu_hash_to_g2_dev(eng.h, tin.data_ptr(), n, tout.data_ptr(), 0), reps)
     got = bytes(tout.cpu().numpy())
-    ok = all(got[192 * i:192 * (i + 1)] == H.g2_affine_bytes(H.hash_to_g2_prehashed(msgs[32 * i:32 * (i + 1)], util.hash512))
-             for i in (0, n // 2, n - 1)) and len(set(got[192 * i:192 * (i + 1)] for i in range(0, n, max(1, n // 512)))) > 1
+    # check: the REFERENCE's digest of these very outputs where a committed fixture holds it (rank 0's first 16 384 / 20 000
+    # messages: tests/golden/h2c_20000.json, produced by importing the reference), else three messages against the host
+    # integer code (tests/test_hostmath_fixtures.py pins that to 1024 + 20 reference hashes)
+    check = None
+    if env.rank == 0 and n in (16384, 20000):
+        with open(os.path.join(ROOT, "tests", "golden", "h2c_20000.json")) as f:
+            fx = json.load(f)
+        ok = hashlib.sha256(got).hexdigest() == fx["outputs_sha256_first_16384" if n == 16384 else "outputs_sha256"]
+        check = "sha256 of all %d outputs == the reference's (tests/golden/h2c_20000.json)" % n
+    else:
+        ok = all(got[192 * i:192 * (i + 1)] == H.g2_affine_bytes(H.hash_to_g2_prehashed(msgs[32 * i:32 * (i + 1)], util.hash512))
+                 for i in (0, n // 2, n - 1)) and len(set(got[192 * i:192 * (i + 1)] for i in range(0, n, max(1, n // 512)))) > 1
     dtm = env.max_over_ranks(dt)
     oks = env.gather_objects(ok)
     if env.rank == 0:
@@ -727,7 +737,7 @@ def run_h2c(env, args):
             "warmup": 1, "ms_per_step": dtm * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "hash_to_point_prehashed_Fq2 of %d message hashes per GPU (SHA-256 chain, two SW encodings one per lane with the powers in registers, cofactor clearing one message per lane pair)" % n,
-                       "name": "h2c", "check": "3 messages against the host integer code (itself pinned to the reference's vectors)"},
+                       "name": "h2c", "check": check or "3 messages against the host integer code (itself pinned to the reference's vectors)"},
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_pow + k_h2c_stage + k_h2c_clear", "peak": PEAK_TMACS, "unit": "TMAC/s",
                          "achieved": mac * n / dt / 1e12, "frac": mac * n / dt / 1e12 / PEAK_TMACS, "traffic": None}}
     return None

@@ -66,6 +66,13 @@ int blsgpu_ctx_create(int device, blsgpu_ctx **out);
 void blsgpu_ctx_destroy(blsgpu_ctx *ctx);
 /* Pre-size the per-context workspace for batches of up to max_pairs pairs. */
 int blsgpu_ctx_reserve(blsgpu_ctx *ctx, size_t max_pairs);
+/* Bytes of device memory the context's grow-only workspace holds right now, by purpose (the high-water mark of the
+ * calls made so far; the line-stream stage keeps 68 x 336 bytes of line records per pair of its largest call, the
+ * counterpart of the n-arrays of mpz_t the reference mallocs per call, fields_t_c.pyx:2348-2388).  out[BLSGPU_WS_TOTAL]
+ * is the sum.  No device call is made. */
+enum { BLSGPU_WS_PARTIALS = 0, BLSGPU_WS_STAGING, BLSGPU_WS_LINES, BLSGPU_WS_LINE_PRODUCTS, BLSGPU_WS_FLAGS_AND_LISTS,
+       BLSGPU_WS_GROUP_SUMS, BLSGPU_WS_SLOTS, BLSGPU_WS_TOTAL, BLSGPU_WS_FIELDS };
+int blsgpu_ctx_workspace_bytes(blsgpu_ctx *ctx, size_t out[BLSGPU_WS_FIELDS]);
 /* Wait for the context's enqueued work and free the buffers that larger ones replaced. */
 int blsgpu_ctx_trim(blsgpu_ctx *ctx);
 /* Batches of at least `pairs` pairs run the throughput-oriented Miller kernel

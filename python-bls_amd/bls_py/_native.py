@@ -24,6 +24,7 @@ SYMBOLS = (
     "blsgpu_hash_to_g2", "blsgpu_hash_to_g2_dev",
     "blsgpu_miller_loop_batch", "blsgpu_miller_loop_batch_dev", "blsgpu_line_eval_batch", "blsgpu_ctx_trim",
     "blsgpu_fq12_op_batch", "blsgpu_fq12_pow_batch", "blsgpu_ctx_set_mp3_threshold", "blsgpu_ctx_set_ls_threshold", "blsgpu_ctx_set_ls_teams", "blsgpu_ctx_set_bulk_event", "blsgpu_ctx_set_fexp_team_threshold", "blsgpu_ctx_set_fexp_trace", "blsgpu_debug_read_lines",
+    "blsgpu_ctx_workspace_bytes",
 )
 
 _lib = None
@@ -69,6 +70,7 @@ def load_library(path=None):
         L.blsgpu_ctx_set_fexp_team_threshold.argtypes = [vp, sz]
         L.blsgpu_ctx_set_fexp_trace.argtypes = [vp, vp]
         L.blsgpu_debug_read_lines.argtypes = [vp, vp, sz]
+        L.blsgpu_ctx_workspace_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
         L.blsgpu_ctx_trim.argtypes = [vp]
         L.blsgpu_pairing_multi.argtypes = [vp, cp, cp, cp, sz, cp]
         L.blsgpu_pairing_multi_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
@@ -147,6 +149,14 @@ class Engine:
         """Calls >= pairs with groups >= min_group use the line-stream kernels; pairs = None: never."""
         self._check(self.lib.blsgpu_ctx_set_ls_threshold(self.h, (1 << 64) - 1 if pairs is None else pairs, min_group),
                     "blsgpu_ctx_set_ls_threshold")
+
+    WS_FIELDS = ("partials", "staging", "lines", "line_products", "flags_and_lists", "group_sums", "slots", "total")
+
+    def workspace_bytes(self):
+        """bytes of HBM the context's grow-only workspace holds, by purpose (include/blsgpu.h BLSGPU_WS_*)"""
+        out = (ctypes.c_size_t * len(self.WS_FIELDS))()
+        self._check(self.lib.blsgpu_ctx_workspace_bytes(self.h, out), "blsgpu_ctx_workspace_bytes")
+        return dict(zip(self.WS_FIELDS, (int(v) for v in out)))
 
     def set_ls_teams(self, teams):
         self._check(self.lib.blsgpu_ctx_set_ls_teams(self.h, teams), "blsgpu_ctx_set_ls_teams")

@@ -64,6 +64,7 @@ struct blsgpu_ctx {
     bool h2c_jacobi = true;            // ... with the quadratic characters decided by a Jacobi-symbol routine: two powers per encoding, not five
     size_t h2c_jacobi_threshold = 16384;   // ... from this many messages (below, five parallel powers finish sooner than three serial symbol loops)
     bool h2c_reg_pairs = true;         // ... on lane pairs (k_h2c_clear_pairs); false: one message per lane (k_h2c_clear_reg)
+    bool test_ls_nomem = false;        // test hook (BLSGPU_TEST_LS_NOMEM=1): the line-stream workspace "cannot be allocated"
     void* d_h2c_ws = nullptr;          // the lane-private point slots of k_h2c_clear_pairs
     size_t h2c_ws_cap = 0;
     size_t msm_sort_threshold = 16384;  // points from which one G1 sum with scalars uses sorted buckets (k_srt_*)
@@ -504,6 +505,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_PAIRS")) c->h2c_reg_pairs = atoi(e) != 0;
+    if (const char* e = getenv("BLSGPU_TEST_LS_NOMEM")) c->test_ls_nomem = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_H2C_JACOBI")) c->h2c_jacobi = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_H2C_JACOBI_THRESHOLD")) c->h2c_jacobi_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_LANE_THRESHOLD")) c->h2c_lane_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -738,6 +740,22 @@ BLSGPU_EXPORT int blsgpu_ctx_reserve(blsgpu_ctx* c, size_t max_pairs) {
     return 0;
 }
 
+// Bytes of HBM the context holds, by purpose (grow-only buffers: the high-water mark of the calls made so far).
+BLSGPU_EXPORT int blsgpu_ctx_workspace_bytes(blsgpu_ctx* c, size_t out[BLSGPU_WS_FIELDS]) {
+    if (!c || !out) return fail(-EINVAL, "NULL argument");
+    out[BLSGPU_WS_PARTIALS] = 2 * c->part_cap * 576;
+    out[BLSGPU_WS_STAGING] = c->io_cap;
+    out[BLSGPU_WS_LINES] = c->lines_cap;
+    out[BLSGPU_WS_LINE_PRODUCTS] = c->lsp_cap[0] + c->lsp_cap[1];
+    out[BLSGPU_WS_FLAGS_AND_LISTS] = c->bad_cap + c->degen_cap * 4;
+    out[BLSGPU_WS_GROUP_SUMS] = c->msm_part_cap * 4 + c->bucket_cap * 4;
+    out[BLSGPU_WS_SLOTS] = c->fexp_ws_cap + c->h2c_ws_cap;
+    size_t total = 0;
+    for (int i = 0; i < BLSGPU_WS_TOTAL; i++) total += out[i];
+    out[BLSGPU_WS_TOTAL] = total;
+    return 0;
+}
+
 // Waits for the context's enqueued work and releases the buffers that larger ones replaced.
 BLSGPU_EXPORT int blsgpu_ctx_trim(blsgpu_ctx* c) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
@@ -872,7 +890,8 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     cpg = (gsz + chunk - 1) / chunk;
     constexpr size_t FAN = 8;
     const bool small = gsz < c->ls_min_group;              // one accumulator per group runs the whole loop (k_ml_small)
-    if (grow_buffer(c, &c->d_lines, &c->lines_cap, n * ml::LINES * ml::LINE_DW * 4) ||
+    if (c->test_ls_nomem ||                                // tests/test_gpu_alternate_forms.py: the fallback below, without exhausting a GPU
+        grow_buffer(c, &c->d_lines, &c->lines_cap, n * ml::LINES * ml::LINE_DW * 4) ||
         (!small && grow_buffer(c, &c->d_lsp[0], &c->lsp_cap[0], groups * cpg * ml::LINES * ml::DENSE_DW * 4)) ||
         (!small && grow_buffer(c, &c->d_lsp[1], &c->lsp_cap[1], groups * ((cpg + FAN - 1) / FAN) * ml::LINES * ml::DENSE_DW * 4)) ||
         grow_buffer(c, &c->d_bad, &c->bad_cap, n) ||

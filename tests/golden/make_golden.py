@@ -703,6 +703,187 @@ def gen_scale():
     dump("scale.json", out)
 
 
+
+# ---- hash-to-G2 fixtures for the round-3 lane / Jacobi-symbol kernels ------------------------------
+def _f2mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+
+
+def _f2pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = _f2mul(r, a)
+        a = _f2mul(a, a)
+        e >>= 1
+    return r
+
+
+def _f2cbrt(c, rng):
+    """a cube root of c in Fq2 or None.  q^2 - 1 = 9 m with 3 not dividing m: c^(1/3 mod m) is a cube root up to a
+    cube root of unity, which a power of a primitive 9th root of unity repairs (plain integers; helper arithmetic of
+    this script, not reference code -- the reference only ever sees the resulting t)."""
+    n = Q * Q - 1
+    m = n // 9
+    assert n % 9 == 0 and m % 3 != 0
+    if _f2pow(c, n // 3) != (1, 0):
+        return None
+    x = _f2pow(c, pow(3, -1, m))
+    while True:
+        g = (rng.randrange(Q), rng.randrange(Q))
+        w9 = _f2pow(g, n // 9)
+        if _f2pow(w9, 3) != (1, 0):
+            break
+    for _ in range(9):
+        if _f2mul(_f2mul(x, x), x) == (c[0] % Q, c[1] % Q):
+            return x
+        x = _f2mul(x, w9)
+    return None
+
+
+def _h2c_tail(Pt):
+    """hash_to_point_prehashed_Fq2's cofactor clearing (ec.py:541-550) on a given sum of encodings"""
+    from bls_py.ec import psi
+    ect = default_ec_twist
+    xx = -ect.x
+    psi2P = psi(psi(2 * Pt, ect), ect)
+    a0 = xx * Pt
+    a1 = xx * a0
+    a2 = (a1 + a0) - Pt
+    a3 = psi((xx + 1) * Pt, ect)
+    R = a2 - a3 + psi2P
+    return R.to_affine() if hasattr(R, "to_affine") else R
+
+
+def gen_h2c_corners():
+    """Inputs of sw_encode (ec.py:449-507) on which the quadratic characters the index rule tests (`try: y_for_x`,
+    ec.py:489-498) take their corner values: the NORM a0^2 + a1^2 of u = x^3 + b' of the first or second candidate equal
+    to 1 and to q - 1 (the smallest residue and the largest non-residue: the ends of the binary symbol routine's
+    range) and generic residue / non-residue combinations for every index the rule can return.  A norm of 0 does
+    not exist (E'(Fq2) has odd order: no point with y = 0; a0^2 + a1^2 = 0 forces u = 0 as -1 is a non-residue), and
+    delta_+ = (a0 + alpha)/2 = 0 happens exactly for a real non-square u, which g2_real_u.json holds.  Recorded per
+    case: t0 || t1 (192 bytes, the input of blsgpu_map_to_g2), the candidate the reference chose, sw_encode(t0), and
+    the hash's result clear_cofactor(sw_encode(t0) + sw_encode(t1))."""
+    import random
+    rng = random.Random(29)
+    ect = default_ec_twist
+    s3, c1 = Fq2(Q, ect.sqrt_n3, 0), Fq2(Q, ect.sqrt_n3m1o2, 0)
+    B = ect.b + Fq2(Q, 1, 0)
+    bt = (int(ect.b[0]), int(ect.b[1]))
+
+    def norm_of(x):
+        u = x * x * x + ect.b
+        return (int(u[0]) ** 2 + int(u[1]) ** 2) % Q
+
+    def t_for_x1(x1):
+        z = -B * (x1 - c1) * ~(x1 - c1 + s3)                          # t^2 such that the first candidate is x1
+        try:
+            t = z.modsqrt()
+        except ValueError:
+            return None
+        if type(t) is not Fq2 or t * t != z:
+            return None
+        return t
+
+    def x_with_norm(nrm):
+        """x in Fq2 with N(x^3 + b') = nrm (nrm = 1 or q - 1)"""
+        while True:
+            # a point of the conic a0^2 + a1^2 = nrm: through a known point by a random slope
+            if nrm == 1:
+                p0 = (1, 0)
+            else:
+                while True:
+                    a = rng.randrange(Q)
+                    r = (nrm - a * a) % Q
+                    if pow(r, (Q - 1) // 2, Q) == 1:
+                        p0 = (a, pow(r, (Q + 1) // 4, Q))
+                        break
+            k = rng.randrange(1, Q)
+            # line (p0x + s, p0y + k s): s = -2 (p0x + k p0y) / (1 + k^2)
+            s = (-2 * (p0[0] + k * p0[1])) * pow(1 + k * k, Q - 2, Q) % Q
+            u = ((p0[0] + s) % Q, (p0[1] + k * s) % Q)
+            assert (u[0] * u[0] + u[1] * u[1]) % Q == nrm
+            if u[1] == 0:
+                continue
+            x = _f2cbrt(((u[0] - bt[0]) % Q, (u[1] - bt[1]) % Q), rng)
+            if x is not None:
+                X = Fq2(Q, x[0], x[1])
+                assert norm_of(X) == nrm
+                return X
+
+    def record(kind, t0, t1):
+        w = t0 * t0 + ect.b + 1
+        w = ~w * ect.sqrt_n3 * t0
+        x1 = -w * t0 + ect.sqrt_n3m1o2
+        x2 = Fq2.from_fq(Q, Fq(Q, -1)) - x1
+        x3 = ~(w * w) + 1
+        P0 = sw_encode(t0, ect, Fq2)
+        chosen = [i + 1 for i, x in enumerate((x1, x2, x3)) if P0.x == x]
+        assert len(chosen) >= 1
+        P1 = sw_encode(t1, ect, Fq2)
+        R = _h2c_tail(P0 + P1)
+        leg = lambda v: {1: 1, Q - 1: -1, 0: 0}[pow(v, (Q - 1) // 2, Q)]
+        return {"kind": kind, "t": tup_hex(t0.ZT) + tup_hex(t1.ZT), "chosen_candidate": chosen[0],
+                "norm_x1": fq_hex(norm_of(x1)), "norm_x2": fq_hex(norm_of(x2)),
+                "norm_characters": [leg(norm_of(x1)), leg(norm_of(x2)), leg(norm_of(x3))],
+                "sw_encode_t0": g2_bytes(P0).hex(), "point": g2_bytes(R).hex()}
+
+    cases = []
+    for nrm, name in ((1, "one"), (Q - 1, "q_minus_1")):
+        for which in (1, 2):
+            while True:
+                x = x_with_norm(nrm)
+                x1 = x if which == 1 else Fq2.from_fq(Q, Fq(Q, -1)) - x
+                t0 = t_for_x1(x1)
+                if t0 is None:
+                    continue
+                t1 = Fq2(Q, rng.randrange(Q), rng.randrange(Q))
+                try:
+                    rec = record("norm_x%d_is_%s" % (which, name), t0, t1)
+                except ValueError:
+                    continue
+                cases.append(rec)
+                break
+    # generic t: until every (chi(x1), chi(x2)) pattern and every chosen index 1, 2, 3 has been seen twice
+    seen = {}
+    while len(seen) < 4 or min(seen.values()) < 2:
+        t0 = Fq2(Q, rng.randrange(Q), rng.randrange(Q))
+        t1 = Fq2(Q, rng.randrange(Q), rng.randrange(Q))
+        rec = record("generic", t0, t1)
+        key = tuple(rec["norm_characters"][:2])
+        if seen.get(key, 0) >= 2:
+            continue
+        seen[key] = seen.get(key, 0) + 1
+        cases.append(rec)
+    assert {c["chosen_candidate"] for c in cases} == {1, 2, 3}
+    # (t = 0: sw_encode returns a JacobianPoint at infinity, ec.py:450-452, and the hash's own `+` then raises
+    # ValueError("Incorrect object"), ec.py:148 -- the reference defines no hash for it; the sw_encode vectors of
+    # hash_to_curve.json pin the encoding itself)
+    dump("h2c_corners.json", {"cases": cases})
+    print("  kinds:", [c["kind"] for c in cases])
+
+
+def _h2c_worker(m):
+    return g2_bytes(hash_to_point_prehashed_Fq2(m))
+
+
+def gen_h2c_20000():
+    """20 000 message hashes through hash_to_point_prehashed_Fq2 (ec.py:528-550): above every selection threshold of
+    the engine (encodings one per lane from 2048, symbols by the binary routine from 16 384, lane-pair cofactor clearing
+    from 8192), so the DEFAULT path meets the reference.  Messages: sha256(b"bench-h2c-0-%d" % i) -- bench.py's h2c
+    workload on rank 0, whose first 16 384 outputs get their own digest.  Pure Python on all cores: about a minute."""
+    import multiprocessing as mp
+    n = 20000
+    msgs = [hashlib.sha256(b"bench-h2c-0-%d" % i).digest() for i in range(n)]
+    with mp.Pool(os.cpu_count()) as pool:
+        pts = pool.map(_h2c_worker, msgs, chunksize=50)
+    dump("h2c_20000.json", {"rule": "message hash i = sha256(b'bench-h2c-0-%d' % i), i < 20000 (bench.py run_h2c, rank 0)",
+                            "n": n, "inputs_sha256": hashlib.sha256(b"".join(msgs)).hexdigest(),
+                            "outputs_sha256": hashlib.sha256(b"".join(pts)).hexdigest(),
+                            "outputs_sha256_first_16384": hashlib.sha256(b"".join(pts[:16384])).hexdigest(),
+                            "every_1000th": {str(i): pts[i].hex() for i in range(0, n, 1000)}})
+
+
 def gen_threshold(big):
     """Deterministic Joint-Feldman-free variant: one polynomial per group from
     the PRF, shares = P(j); unit signatures combined with Lagrange weights
@@ -804,6 +985,12 @@ if __name__ == "__main__":
     if "scale" in only:                     # opt-in: a few minutes of pure Python
         gen_scale()
         only = [a for a in only if a != "scale"] or ["-"]
+    if "h2c_corners" in only:               # opt-in: a minute (cube roots in Fq2 by trial)
+        gen_h2c_corners()
+        only = [a for a in only if a != "h2c_corners"] or ["-"]
+    if "h2c_20000" in only:                 # opt-in: about a minute on 8 cores
+        gen_h2c_20000()
+        only = [a for a in only if a != "h2c_20000"] or ["-"]
     if "seeded8192" in only:                # opt-in: ~10 minutes of pure Python
         gen_seeded_digest(8192)
         only = [a for a in only if a != "seeded8192"] or ["-"]

@@ -1,0 +1,92 @@
+"""The kernel forms the engine ships but does not select by default, and the fallback it takes when the line-stream
+workspace cannot be allocated (VERDICT r3 item 1 d / e): each is reachable through an environment knob read at context
+creation (csrc/blsgpu_api.hip), so each gets the reference's vectors.
+
+  BLSGPU_LS_LINES_FORM=1    k_ml_lines: the point chains with one pair per lane (default: k_ml_lines2, lane pairs)
+  BLSGPU_LS_HORNER_FORM=1   k_ml_horner: ten groups per wavefront (default: k_ml_horner_wide, one group per wavefront)
+  BLSGPU_VM_EXACT_LANES=0   degenerate blocks of the wavefront-VM kernels recomputed by k_miller_slow
+                            (default: k_ml_lines_exact in block mode + k_ml_small in list mode)
+  BLSGPU_TEST_LS_NOMEM=1    test hook: launch_miller_ls reports -ENOMEM before touching the device, the call must go
+                            through the wavefront-VM kernels and return the same bytes
+
+Expected values: tests/golden/pairing.json (1025-pair seeded batch, edge cases) and pairing_degenerate.json -- generated
+by importing the reference -- and the CPU oracle for spliced batches."""
+import os
+
+import pytest
+
+from conftest import cat
+from test_gpu_linestream import EDGE, _spliced, flags
+
+pytestmark = pytest.mark.gpu
+
+FORMS = {
+    "lines_one_pair_per_lane": ({"BLSGPU_LS_LINES_FORM": "1"}, True),
+    "horner_ten_groups_per_wavefront": ({"BLSGPU_LS_HORNER_FORM": "1"}, True),
+    "both_old_forms": ({"BLSGPU_LS_LINES_FORM": "1", "BLSGPU_LS_HORNER_FORM": "1"}, True),
+    "vm_slow_program_for_degenerate_blocks": ({"BLSGPU_VM_EXACT_LANES": "0"}, False),
+    "line_stream_workspace_unavailable": ({"BLSGPU_TEST_LS_NOMEM": "1"}, True),
+}
+_cache = {}
+
+
+def form_engine(name):
+    from bls_py import _native
+    if name not in _cache:
+        env, force_ls = FORMS[name]
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            e = _native.Engine(0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        if force_ls:
+            e.set_ls_threshold(1, 1)          # every multi-pairing asks for the line-stream kernels
+        _cache[name] = e
+    return _cache[name]
+
+
+@pytest.mark.parametrize("name", sorted(FORMS))
+def test_reference_vectors(name, golden, seeded_pairs, oracle):
+    e = form_engine(name)
+    g1, g2 = seeded_pairs
+    want = golden("pairing.json")["seeded"]["1025"]["out"]
+    assert e.pairing_multi(g1, g2, 1025).hex() == want
+    v = golden("pairing.json")["small4"]
+    assert e.pairing_multi(cat(v["g1"]), cat(v["g2"]), 4).hex() == v["out"]
+    for edge in EDGE:
+        v = golden("pairing.json")["edge"][edge]
+        assert e.pairing_multi(cat(v["g1"]), cat(v["g2"]), len(v["g1"]), flags(v)).hex() == v["out"], edge
+    # every reference-generated degenerate case (all_kinds among them), alone ...
+    for case, v in golden("pairing_degenerate.json")["cases"].items():
+        assert e.pairing_multi(cat(v["g1"]), cat(v["g2"]), len(v["g1"]), flags(v)).hex() == v["out"], case
+    # ... and sprinkled into a 333-pair batch (the oracle is pinned to the same fixtures)
+    a, b, inf = _spliced(golden, seeded_pairs)
+    n = len(a) // 96
+    assert e.pairing_multi(a, b, n, inf) == oracle.pairing_multi(a, b, n, threads=8, inf=inf)
+    # a batch of 20 verifications (the batch entry: groups, the per-group product tree / Horner, final exponentiations)
+    out = e.pairing_multi_batch(g1 * 20, g2 * 20, 1025, 20)
+    assert all(out[576 * g:576 * (g + 1)].hex() == want for g in range(20))
+
+
+def test_fallback_engine_really_refuses_the_line_stream_path(seeded_pairs):
+    """the hook is live: a FRESH context with it answers calls that ask for the line-stream kernels without ever
+    allocating the line-stream stage's partial products, a context
+    without it does allocate them, and both return the same bytes -- two paths compared, not one with itself"""
+    from bls_py import _native
+    g1, g2 = seeded_pairs
+    _cache.pop("line_stream_workspace_unavailable", None)
+    hooked = form_engine("line_stream_workspace_unavailable")
+    plain = _native.Engine(0)
+    plain.set_ls_threshold(1, 1)
+    for n in (1, 7, 300, 1025):
+        assert hooked.pairing_multi(g1[:96 * n], g2[:192 * n], n) == plain.pairing_multi(g1[:96 * n], g2[:192 * n], n)
+    # (the wavefront-VM kernels keep a scratch of line records for their degenerate blocks, so "lines" is no evidence; the
+    # per-line-index partial products exist only on the line-stream path)
+    assert hooked.workspace_bytes()["line_products"] == 0 and plain.workspace_bytes()["line_products"] >= 68 * 168 * 4
+    ws = plain.workspace_bytes()
+    assert ws["total"] == sum(v for k, v in ws.items() if k != "total")

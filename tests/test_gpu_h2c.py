@@ -104,22 +104,26 @@ def test_one_message_per_lane_clearing(golden):
 
 
 def test_default_selection_at_65536_messages(engine):
-    """from 65 536 messages on the default engine clears cofactors one message per lane: same bytes as the VM form
-    (an engine with the threshold out of reach), a strided sample against the host"""
+    """from 65 536 messages on the default engine runs the lane / symbol encodings and the lane-pair clearing: same bytes
+    as an engine with every one of those switched off (wavefront-VM kernels only), a strided sample against the host"""
     import os
     from bls_py import _native
     n = 65536 + 7
     msgs = b"".join(hashlib.sha256(b"h2c-65k-%d" % i).digest() for i in range(n))
     got = engine.hash_to_g2(msgs)
-    old = os.environ.get("BLSGPU_H2C_REG_THRESHOLD")
-    os.environ["BLSGPU_H2C_REG_THRESHOLD"] = str(1 << 40)
+    # the comparison engine runs NONE of the round-3 kernels: encodings on the wavefront VM with five powers each (lanes
+    # and symbols off), cofactor clearing on the VM
+    knobs = {"BLSGPU_H2C_REG_THRESHOLD": str(1 << 40), "BLSGPU_H2C_LANE_THRESHOLD": str(1 << 40), "BLSGPU_H2C_JACOBI": "0"}
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
     try:
         vm = _native.Engine(0)
     finally:
-        if old is None:
-            del os.environ["BLSGPU_H2C_REG_THRESHOLD"]
-        else:
-            os.environ["BLSGPU_H2C_REG_THRESHOLD"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     assert got == vm.hash_to_g2(msgs)
     for i in range(0, n, 8191):
         assert got[192 * i:192 * (i + 1)] == H.g2_affine_bytes(H.hash_to_g2_prehashed(msgs[32 * i:32 * (i + 1)], hash512))

@@ -1,0 +1,126 @@
+"""Every hash-to-G2 kernel family FORCED onto reference-generated vectors.
+
+The engine picks its kernels by batch size (csrc/blsgpu_api.hip map_to_g2_impl): encodings on the wavefront VM below
+2048 messages, one encoding per lane (k_h2c_sw0/1/2) from there, the quadratic characters by the binary symbol routine
+(k_h2c_swj0/1/2) from 16 384; cofactor clearing on the VM below 8192, on lane pairs (k_h2c_clear_pairs) above, one
+message per lane (k_h2c_clear_reg) as an alternative.  No committed fixture is that large except h2c_20000.json, so
+here the thresholds are moved (BLSGPU_H2C_* read at context creation) and EVERY combination runs
+
+  * tests/golden/hash_to_curve.json   the reference's hash_to_point_prehashed_Fq2 (ec.py:528-550) and sw_encode
+                                      (ec.py:449-507) vectors, incl. t = 0 and S + (-S)
+  * tests/golden/g2_real_u.json       first candidates with a real u (the reference skips them; delta_+ = 0 for the
+                                      non-square ones)
+  * tests/golden/h2c_corners.json     candidate norms equal to 1 and to q - 1, every (chi(x1), chi(x2)) pattern, every
+                                      chosen index
+  * tests/golden/scale.json           1024 hashes: the reference's digest and every 64th output
+  * tests/golden/h2c_20000.json       20 000 hashes through the DEFAULT selection: the reference's digest
+
+All expected values were produced by importing the reference (tests/golden/make_golden.py); nothing here is compared
+with the product's own host code."""
+import contextlib
+import hashlib
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BIG = str(1 << 40)
+# name -> environment of the context.  enc: vm / lane / jacobi; clear: vm / pairs / reg
+CONFIGS = {}
+for enc, env_enc in (("vm", {"BLSGPU_H2C_LANE_THRESHOLD": BIG}),
+                     ("lane", {"BLSGPU_H2C_LANE_THRESHOLD": "1", "BLSGPU_H2C_JACOBI_THRESHOLD": BIG}),
+                     ("jacobi", {"BLSGPU_H2C_LANE_THRESHOLD": "1", "BLSGPU_H2C_JACOBI_THRESHOLD": "1"})):
+    for clr, env_clr in (("vm", {"BLSGPU_H2C_REG_THRESHOLD": BIG}),
+                         ("pairs", {"BLSGPU_H2C_REG_THRESHOLD": "1", "BLSGPU_H2C_REG_PAIRS": "1"}),
+                         ("reg", {"BLSGPU_H2C_REG_THRESHOLD": "1", "BLSGPU_H2C_REG_PAIRS": "0"})):
+        CONFIGS["%s+%s" % (enc, clr)] = dict(env_enc, **env_clr)
+
+
+@contextlib.contextmanager
+def environment(env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+_engines = {}
+
+
+def forced(name):
+    from bls_py import _native
+    if name not in _engines:
+        with environment(CONFIGS[name]):
+            _engines[name] = _native.Engine(0)
+    return _engines[name]
+
+
+def stream(tag, n, size):
+    return [b"".join(hashlib.sha256(tag + i.to_bytes(4, "big") + j.to_bytes(4, "big")).digest()
+                     for j in range((size + 31) // 32))[:size] for i in range(n)]
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_reference_vectors_every_kernel_family(name, golden):
+    e = forced(name)
+    h = golden("hash_to_curve.json")
+    vec = h["hash_to_g2"]
+    out = e.hash_to_g2(b"".join(bytes.fromhex(r["msg_hash"]) for r in vec))          # SHA-256 chain + wide reduction + map
+    assert [out[192 * i:192 * (i + 1)].hex() for i in range(len(vec))] == [r["point"] for r in vec]
+    # sw_encode vectors (t = 0 among them): t1 = 0 encodes to infinity, so the map is clear_cofactor(sw_encode(t0)) -- the
+    # same point whichever slot holds t0, the wavefront-VM engine's bytes (pinned by tests/test_gpu_h2c.py), and S + (-S)
+    # cancels
+    sw = h["sw_encode_fq2"]
+    t = [bytes.fromhex(r["t"]) for r in sw]
+    a = e.map_to_g2(b"".join(x + bytes(96) for x in t))
+    b = e.map_to_g2(b"".join(bytes(96) + x for x in t))
+    assert a == b
+    assert a == forced("vm+vm").map_to_g2(b"".join(x + bytes(96) for x in t))
+    q = int("1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab", 16)
+    tt = t[1]
+    neg = b"".join(((q - int.from_bytes(tt[48 * j:48 * j + 48], "big")) % q).to_bytes(48, "big") for j in range(2))
+    assert e.map_to_g2(bytes(192) + tt + neg) == bytes(384)
+    # real-u first candidates and the symbol's corner values: the reference's full hash tail
+    for fixture, key in (("g2_real_u.json", "sw_encode"), ("h2c_corners.json", "cases")):
+        recs = golden(fixture)[key]
+        out = e.map_to_g2(b"".join(bytes.fromhex(r["t"]) for r in recs))
+        for i, r in enumerate(recs):
+            assert out[192 * i:192 * (i + 1)].hex() == r["point"], (fixture, i, r.get("kind"))
+    # ragged sizes around the lane kernels' 64-lane wavefronts (prefixes of the 1024-hash fixture, which the next test
+    # compares in full): the tails of partly filled wavefronts
+    msgs = stream(b"blsgpu/h2c", 130, 32)
+    full = e.hash_to_g2(b"".join(msgs))
+    for n in (1, 31, 32, 33, 63, 65, 129):
+        assert e.hash_to_g2(b"".join(msgs[:n])) == full[:192 * n]
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_1024_reference_hashes_every_kernel_family(name, golden):
+    rec = golden("scale.json")["hash_to_g2"]
+    msgs = stream(b"blsgpu/h2c", rec["n"], 32)
+    assert hashlib.sha256(b"".join(msgs)).hexdigest() == rec["inputs_sha256"]
+    out = forced(name).hash_to_g2(b"".join(msgs))
+    assert hashlib.sha256(out).hexdigest() == rec["outputs_sha256"]
+    for i, want in rec["every_64th"].items():
+        assert out[192 * int(i):192 * (int(i) + 1)].hex() == want
+
+
+def test_20000_reference_hashes_default_selection(engine, golden):
+    """the engine as shipped: 20 000 > every threshold (lanes, symbols, lane-pair clearing)"""
+    rec = golden("h2c_20000.json")
+    msgs = b"".join(hashlib.sha256(b"bench-h2c-0-%d" % i).digest() for i in range(rec["n"]))
+    assert hashlib.sha256(msgs).hexdigest() == rec["inputs_sha256"]
+    out = engine.hash_to_g2(msgs)
+    assert hashlib.sha256(out).hexdigest() == rec["outputs_sha256"]
+    assert hashlib.sha256(out[:192 * 16384]).hexdigest() == rec["outputs_sha256_first_16384"]
+    for i, want in rec["every_1000th"].items():
+        assert out[192 * int(i):192 * (int(i) + 1)].hex() == want
+    # and the same bytes from the engine with lanes and symbols OFF (the wavefront-VM encodings, five powers)
+    assert forced("vm+pairs").hash_to_g2(msgs) == out
