@@ -102,9 +102,11 @@ int blsgpu_ctx_set_ls_teams(blsgpu_ctx *ctx, size_t teams);
  * next call's stream wait for this event instead of the end of the call (bench.py does). */
 int blsgpu_ctx_set_bulk_event(blsgpu_ctx *ctx, void *event);
 /* Calls that end in at least `results` final exponentiations (fq12_final_exp, fields_t.py:1124-1128) run them six
- * lanes per result, ten results per wavefront, on the register arithmetic (csrc/blsgpu_fexp.hip: ~4x fewer
- * instructions per result than the one-wavefront-per-result VM program, which keeps the lower latency for a few
- * results).  Default 256; (size_t)-1: never.  Results are identical either way. */
+ * lanes per result, ten results per wavefront, on the register arithmetic (csrc/blsgpu_fexp.hip: the fewest
+ * instructions per result, 2.6 ms of latency).  Fewer results run ONE PER WAVEFRONT with every Fq product of a step
+ * on its own lane (csrc/blsgpu_fexpw.hip: 0.70 ms for one result against 1.25 ms of the wavefront-VM program of
+ * rounds 1 - 3, which BLSGPU_FEXP_WIDE=0 in the environment brings back).  Default 5120 (the measured crossover: 4096 results 3.55 against 4.04 ms, 6144 results 5.09 against 4.77 ms);
+ * (size_t)-1: never.  Results are identical either way. */
 int blsgpu_ctx_set_fexp_team_threshold(blsgpu_ctx *ctx, size_t results);
 /* Diagnostic: a device buffer of (script length) x 576 bytes that receives the accumulator of result 0 after every
  * operation of the batched final exponentiation's script (tools/fexp_trace.py compares it with the integer model), or

@@ -17,6 +17,7 @@
 #include "fp28.h"
 #include "blsgpu_ml.hip"
 #include "blsgpu_fexp.hip"
+#include "blsgpu_fexpw.hip"
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
 
@@ -88,7 +89,9 @@ struct blsgpu_ctx {
     bool vm_exact_lanes = true;        // degenerate blocks of the VM kernels through the lane kernels (k_ml_lines_exact / k_ml_small) instead of k_miller_slow
     int ls_horner_form = 2;            // 2: one group per wavefront, a product spread over 36 lanes; 1: ten groups per wavefront
     int ls_lines_form = 2;             // 2: the point chains on lane pairs (k_ml_lines2); 1: one pair per lane (k_ml_lines)
-    size_t fexp_team_threshold = 256;  // results per call from which the final exponentiations run six lanes each (blsgpu_fexp.hip)
+    size_t fexp_team_threshold = 5120; // results per call from which the final exponentiations run six lanes each (blsgpu_fexp.hip); below: one result per wavefront (measured crossover, tools/fexp_latency.py)
+    bool fexp_wide = true;             // fewer results than that: one result per wavefront, a product per lane (blsgpu_fexpw.hip); false: the VM program
+    size_t fexp_wide_max_partials = 8; // ... which also multiplies up to this many partials per result itself (a dense product is ~2.5 us)
     void* d_fexp_dbg = nullptr;        // tools/fexp_trace.py: the accumulator of result 0 after every operation of the script
     void* d_fexp_ws = nullptr;         // their slots
     size_t fexp_ws_cap = 0;
@@ -498,6 +501,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_LS_MIN_GROUP")) c->ls_min_group = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_TEAMS")) c->ls_teams = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_FEXP_TEAM_THRESHOLD")) c->fexp_team_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_FEXP_WIDE")) c->fexp_wide = atoi(e) != 0;
+    if (const char* e = getenv("BLSGPU_FEXP_WIDE_MAX_PARTIALS")) c->fexp_wide_max_partials = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_VM_EXACT_LANES")) c->vm_exact_lanes = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_LS_LINES_FORM")) c->ls_lines_form = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("BLSGPU_LS_HORNER_FORM")) c->ls_horner_form = atoi(e) == 1 ? 1 : 2;
@@ -781,6 +786,26 @@ static int launch_fexp_team(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_
     return 0;
 }
 
+// Fewer results than the team form wants: one result per wavefront (blsgpu_fexpw.hip), the latency form.
+static bool use_fexp_wide(const blsgpu_ctx* c, size_t m, size_t groups) {
+    return c->fexp_wide && groups < c->fexp_team_threshold && m >= 1 && m <= c->fexp_wide_max_partials && groups <= 0x7FFFFFFFull;
+}
+static int launch_fexp_wide(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_t istride, size_t gstride, size_t groups, void* d_out_bytes,
+                            hipStream_t st) {
+    KernelTimer kt(c, st, 2);
+    hipLaunchKernelGGL(blsgpu::fxw::k_fexp_wide, dim3((unsigned)groups), dim3(64), 0, st, d_in, (uint32_t)m, (uint32_t)istride,
+                       (uint32_t)gstride, (uint32_t*)d_out_bytes, (unsigned long long*)c->d_fexp_dbg);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// the register forms of the final exponentiation: batches six lanes per result, a few results one wavefront each
+static bool use_fexp_reg(const blsgpu_ctx* c, size_t m, size_t groups) { return use_fexp_team(c, m, groups) || use_fexp_wide(c, m, groups); }
+static int launch_fexp_reg(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_t istride, size_t gstride, size_t groups, void* d_out_bytes,
+                           hipStream_t st) {
+    return use_fexp_team(c, m, groups) ? launch_fexp_team(c, d_in, m, istride, gstride, groups, d_out_bytes, st)
+                                       : launch_fexp_wide(c, d_in, m, istride, gstride, groups, d_out_bytes, st);
+}
+
 // For each of `groups` groups fold its m partials down to one; the last launch
 // optionally applies the final exponentiation and writes 576 bytes per group to
 // d_out_bytes, otherwise one partial per group to d_out_partial.  Partial i of
@@ -791,20 +816,25 @@ static int reduce_chain(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_t gr
     int pp = (d_in == c->d_part[0]) ? 1 : 0;
     size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
     if (groups > 65535) return fail(-EINVAL, "too many groups");
-    if (do_final && use_fexp_team(c, m, groups)) return launch_fexp_team(c, d_in, m, istride, gstride, groups, d_out_bytes, st);
     while (true) {
+        // the final exponentiation in registers as soon as few enough partials per group are left
+        if (do_final && use_fexp_reg(c, m, groups)) return launch_fexp_reg(c, src, m, istride, gstride, groups, d_out_bytes, st);
         size_t blocks = (m + REDUCE_PER_BLOCK - 1) / REDUCE_PER_BLOCK;
         if (blocks == 0) blocks = 1;
         bool last = blocks == 1;
-        uint32_t* dst = last ? d_out_partial : c->d_part[pp];
+        // the level that leaves one partial per group hands it to the register forms (one more launch, but the VM's
+        // final exponentiation inside k_reduce is 1.25 ms of one wavefront)
+        const bool hand_over = last && do_final && use_fexp_reg(c, 1, groups) && groups <= c->part_cap;
+        uint32_t* dst = (last && !hand_over) ? d_out_partial : c->d_part[pp];
         if (!last && blocks * groups > c->part_cap) return fail(-ENOMEM, "workspace too small; call blsgpu_ctx_reserve");
         {
-            KernelTimer kt(c, st, (last && do_final) ? 2 : 1);
+            KernelTimer kt(c, st, (last && do_final && !hand_over) ? 2 : 1);
             hipLaunchKernelGGL(blsgpu::k_reduce, dim3((unsigned)blocks, (unsigned)groups), dim3(REDUCE_WAVES * 64), lds, st, c->tabs,
                                src, (uint32_t)m, (uint32_t)REDUCE_PER_BLOCK, (uint32_t)istride, (uint32_t)gstride, dst,
-                               (uint32_t)(last && do_final ? 1 : 0), (uint32_t*)d_out_bytes);
+                               (uint32_t)(last && do_final && !hand_over ? 1 : 0), (uint32_t*)d_out_bytes);
         }
         HIP_TRY(hipGetLastError());
+        if (hand_over) return launch_fexp_reg(c, dst, 1, 1, 1, groups, d_out_bytes, st);
         if (last) break;
         src = dst;
         m = blocks;
@@ -1208,8 +1238,8 @@ BLSGPU_EXPORT int blsgpu_final_exp_batch(blsgpu_ctx* c, const uint8_t* in, size_
     hipLaunchKernelGGL(blsgpu::k_bytes_to_partials, dim3(blocks), dim3(REDUCE_WAVES * 64), lds, 0, c->tabs,
                        (const uint32_t*)din, (uint32_t)m, c->d_part[1]);
     HIP_TRY(hipGetLastError());
-    if (use_fexp_team(c, 1, m)) {
-        if (int rc2 = launch_fexp_team(c, c->d_part[1], 1, 1, 1, m, dout, 0)) return rc2;
+    if (use_fexp_reg(c, 1, m)) {
+        if (int rc2 = launch_fexp_reg(c, c->d_part[1], 1, 1, 1, m, dout, 0)) return rc2;
     } else {
         hipLaunchKernelGGL(blsgpu::k_final_groups, dim3(blocks), dim3(REDUCE_WAVES * 64), lds, 0, c->tabs, c->d_part[1],
                            1u, (uint32_t)m, (uint32_t*)dout);
@@ -1243,7 +1273,7 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1
         // a large batch of small groups: point chains on lane pairs, then one accumulator per group (blsgpu_ml.hip)
         rc = launch_miller_ls(c, d_g1, d_g2, d_inf, gsz, groups, c->d_part[0], st);
         if (rc == 0) {
-            if (use_fexp_team(c, 1, groups)) return launch_fexp_team(c, c->d_part[0], 1, 1, 1, groups, d_out, st);
+            if (use_fexp_reg(c, 1, groups)) return launch_fexp_reg(c, c->d_part[0], 1, 1, 1, groups, d_out, st);
             size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
             unsigned blocks = (unsigned)((groups + REDUCE_WAVES - 1) / REDUCE_WAVES);
             KernelTimer kt(c, st, 2);
@@ -1263,8 +1293,8 @@ BLSGPU_EXPORT int blsgpu_pairing_multi_batch_dev(blsgpu_ctx* c, const void* d_g1
                          : launch_miller(c, d_g1, d_g2, d_inf, n, 1, true, c->d_part[0], st, &bpg);
         if (rc) return rc;
     }
-    if (use_fexp_team(c, team_groups ? 1 : gsz, groups))
-        return launch_fexp_team(c, c->d_part[0], team_groups ? 1 : gsz, 1, team_groups ? 1 : gsz, groups, d_out, st);
+    if (use_fexp_reg(c, team_groups ? 1 : gsz, groups))
+        return launch_fexp_reg(c, c->d_part[0], team_groups ? 1 : gsz, 1, team_groups ? 1 : gsz, groups, d_out, st);
     size_t lds = (size_t)REDUCE_WAVES * blsgpu::TEAM_BYTES;
     unsigned blocks = (unsigned)((groups + REDUCE_WAVES - 1) / REDUCE_WAVES);
     {

@@ -12,6 +12,7 @@
 #define BLSGPU_TU_FX 4      // blsgpu_fexp.hip: batched final exponentiations
 #define BLSGPU_TU_MSM 5     // blsgpu_msm.hip: multi-scalar sums
 #define BLSGPU_TU_H2C 6     // blsgpu_h2c.hip: hash to G2, decompression
+#define BLSGPU_TU_FXW 7     // blsgpu_fexpw.hip: one final exponentiation per wavefront
 #ifndef BLSGPU_TU
 #define BLSGPU_TU 0
 #endif

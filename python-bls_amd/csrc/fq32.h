@@ -411,4 +411,90 @@ BLS_HD void fq_inv(uint32_t* __restrict__ r, const uint32_t* __restrict__ a) {
     fq_mul(r, y, r3);
 }
 
+// ---- the same inverse for a value that is THE SAME IN EVERY LANE of the wavefront (round 4) ----------------------------
+// k_fexp_wide (blsgpu_fexpw.hip) inverts one Fq value per result while the whole wavefront waits: every lane runs the
+// routine on the same number, so data-dependent control flow costs nothing (the branches are wave-uniform) and the
+// constant-time schedule above -- 37 x 30 single division steps, ~990 instructions per batch -- is not needed.  Same
+// algorithm and matrices (Bernstein-Yang division steps, eprint 2019/266), in the variable-time form: runs of zero bits
+// of g are shifted out at once (count of trailing zeros) and up to six low bits of g are cancelled per iteration with
+// w = -g/f mod 2^6 (f (f^2 - 2) = -1/f mod 64 for odd f), so a batch of 30 steps takes ~6 iterations, and the loop ends as
+// soon as g = 0 (~27 batches on average for 381-bit inputs instead of the proven bound 37).  Results are identical to
+// fq_inv's for every input, 0 -> 0 included (tests/test_abi_and_host.py runs both on the host).
+// low 32 bits of a b + c: on the GPU one full-rate v_mad_u64_u32 (v_mul_lo_u32 is a quarter-rate instruction)
+BLS_HD uint32_t inv_mad32(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t t;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=&v"(t) : "v"(a), "v"(b), "v"((uint64_t)c) : "vcc");
+    return (uint32_t)t;
+#else
+    return a * b + c;
+#endif
+}
+BLS_HD int32_t inv_divsteps30_var(int32_t eta, uint32_t f0, uint32_t g0, inv_trans& t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+    int i = 30;
+    for (;;) {
+        const uint32_t zeros = (uint32_t)__builtin_ctz(g | (0xFFFFFFFFu << i));     // at most i
+        g >>= zeros; u <<= zeros; v <<= zeros;
+        eta -= (int32_t)zeros; i -= (int)zeros;
+        if (i == 0) break;
+        // f and g are odd
+        if (eta < 0) {                                   // delta > 0: (f, g) <- (g, -f), the matrix rows likewise
+            eta = -eta;
+            uint32_t tmp = f; f = g; g = 0u - tmp;
+            tmp = u; u = q; q = 0u - tmp;
+            tmp = v; v = r; r = 0u - tmp;
+        }
+        // cancel min(eta + 1, i, 6) low bits of g:  g <- g + w f  with  w = -g / f mod 2^limit
+        const int lim = (eta + 1) > i ? i : (eta + 1);
+        const uint32_t m = (0xFFFFFFFFu >> (32 - lim)) & 63u;
+        const uint32_t fi = inv_mad32(f, inv_mad32(f, f, 0u - 2u), 0u);          // f (f^2 - 2) = -1/f mod 2^6
+        const uint32_t w = inv_mad32(g, fi, 0u) & m;
+        g = inv_mad32(f, w, g); q = inv_mad32(u, w, q); r = inv_mad32(v, w, r);
+    }
+    t.u = (int32_t)u; t.v = (int32_t)v; t.q = (int32_t)q; t.r = (int32_t)r;
+    return eta;
+}
+BLS_HD void fq_inv_var(uint32_t* __restrict__ r, const uint32_t* __restrict__ a) {
+    const uint32_t r3[12] = BLS_R3_LIMBS;
+    const int32_t m[13] = BLS_Q30_LIMBS;
+    uint32_t x[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) x[j] = a[j];
+    fq_canon(x);
+    int32_t f[13], g[13], d[13], e[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int bit = 30 * i, w = bit >> 5, s = bit & 31;
+        uint32_t lo = x[w] >> s;
+        if (s > 2 && w + 1 < 12) lo |= x[w + 1] << (32 - s);
+        g[i] = (int32_t)(lo & 0x3FFFFFFFu);
+        f[i] = m[i]; d[i] = 0; e[i] = 0;
+    }
+    e[0] = 1;
+    int32_t eta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 37; it++) {                    // never more than the constant-time bound
+        int32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < 13; i++) nz |= g[i];
+        if (nz == 0) break;
+        inv_trans t;
+        eta = inv_divsteps30_var(eta, (uint32_t)f[0], (uint32_t)g[0], t);
+        inv_update_de(d, e, t);
+        inv_update_fg(f, g, t);
+    }
+    inv_normalize(d, f[12]);
+    uint32_t y[12];
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const int bit = 32 * w, i = bit / 30, s = bit - 30 * i;
+        uint32_t v = (uint32_t)d[i] >> s;
+        v |= (uint32_t)d[i + 1] << (30 - s);
+        if (60 - s < 32 && i + 2 < 13) v |= (uint32_t)d[i + 2] << (60 - s);
+        y[w] = v;
+    }
+    fq_mul(r, y, r3);
+}
+
 }  // namespace bls

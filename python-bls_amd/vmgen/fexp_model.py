@@ -169,6 +169,35 @@ def script():
                 run = 0
         if run:
             S.append((CSQ, run))
+
+    def pow_win3(e):
+        """acc <- acc^e with sliding windows of three bits (round 4): (x - 1)/3 = 0b100011 0^10 (10)^12 11 0 (10)^5 11 has
+        28 set bits -- 27 dense products bit by bit, 14 + 2 with the odd powers b, b^3, b^5 (the only window values that
+        occur) kept in slots 1, 0, 2 (free at this point of the script; b^2 passes through slot 4) and one more squaring"""
+        slot_of = {1: 1, 3: 0, 5: 2}
+        bits = bin(e)[2:]
+        wins, i = [], 0
+        while i < len(bits):
+            if bits[i] == "0":
+                i += 1
+                continue
+            n = min(3, len(bits) - i)
+            while bits[i + n - 1] == "0":
+                n -= 1
+            wins.append((i, n, int(bits[i:i + n], 2)))
+            i += n
+        assert {v for _, _, v in wins} <= set(slot_of)
+        S.extend([(ST, 1), (CSQ, 1), (ST, 4), (MUL, 1), (ST, 0), (MUL, 4), (ST, 2)])      # b, b^2, b^3, b^5
+        pos, n, v = wins[0]
+        assert pos == 0
+        S.append((LD, slot_of[v]))
+        done = n
+        for pos, n, v in wins[1:]:
+            S.append((CSQ, pos + n - done))
+            S.append((MUL, slot_of[v]))
+            done = pos + n
+        if done < len(bits):
+            S.append((CSQ, len(bits) - done))
     # easy part: f^-1 through norms, then f^(q^6 - 1), then (.)^(q^2 + 1)
     S += [(ST, 0), (CONJ, 0), (ST, 1), (MUL, 0), (ST, 2),        # M0 = f, M1 = conj f, M2 = N = f conj f
           (FROB, 1), (ST, 3), (LD, 2), (FROB, 2), (MUL, 3), (ST, 3),   # M3 = N^(q^2) N^(q^4)
@@ -176,7 +205,7 @@ def script():
           (MUL, 1),                                               # acc = conj(f) f^-1
           (ST, 2), (FROB, 1), (MUL, 2), (ST, 3)]                  # acc = M3 = t
     e1 = (NX + 1) // 3
-    pow_acc(e1)                                                   # s
+    pow_win3(e1)                                                  # s
     pow_acc(NX)
     S += [(MUL, 1), (ST, 4)]                                      # a
     pow_acc(NX)

@@ -50,7 +50,8 @@ int main(){ char op[16], a[200], b[200];
     if(!strcmp(op,"mul")) { bls::fq_mul(r,x,y); pr(r);}
     else if(!strcmp(op,"add")) { bls::fq_add_mod(x,y); pr(x);}
     else if(!strcmp(op,"sub")) { bls::fq_neg_raw(y); bls::fq_add_mod(x,y); pr(x);}
-    else if(!strcmp(op,"inv")) { bls::fq_inv(r,x); pr(r);} }
+    else if(!strcmp(op,"inv")) { bls::fq_inv(r,x); uint32_t r2[12]; bls::fq_inv_var(r2,x);          // both forms of the inversion
+      if(memcmp(r,r2,48)) { printf("inv_var_differs\n"); } else pr(r);} }
   return 0; }
 '''
 
