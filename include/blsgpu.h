@@ -116,6 +116,22 @@ int blsgpu_ctx_set_fexp_trace(blsgpu_ctx *ctx, void *d_buf);
  * (lines[(L * n + pair) * 84] int32, csrc/blsgpu_ml.hip); tools/exact_trace.py compares them with the integer model. */
 int blsgpu_debug_read_lines(blsgpu_ctx *ctx, void *host_buf, size_t bytes);
 
+/* The device work of BLS.verify (bls.py:153-201) in ONE call:  e(-G1, sig) * prod_i e(P_i, H(m_i))  for n distinct
+ * message hashes (32 bytes each) -- hash_to_point_prehashed_Fq2 of every hash (bls.py:194-195, ec.py:528-550), the
+ * per-message key P_i either given (keys_affine: n x 96 bytes) or folded here as sum_j t_ij pk_ij (bls.py:177-192:
+ * key_pts n x k x 96 bytes, key_scalars n x k x 32 bytes big-endian), then the (n + 1)-pair multi-pairing in the
+ * reference's order Ps[0] = -G1, Qs[0] = sig (bls.py:197-199).  One upload, nothing returns to the host between the
+ * stages, 576 bytes back: the caller compares them with Fq12 one.  The scheme logic around it (grouping keys by
+ * message, the False of a missing tree key, bls.py:181-190) stays with the caller. */
+int blsgpu_verify_pipeline(blsgpu_ctx *ctx, const uint8_t neg_g1[BLSGPU_G1_BYTES], const uint8_t sig[BLSGPU_G2_BYTES],
+                           const uint8_t *msg_hashes, size_t n, const uint8_t *keys_affine, const uint8_t *key_pts,
+                           const uint8_t *key_scalars, size_t k, uint8_t out[BLSGPU_FQ12_BYTES]);
+/* The same on device-resident buffers, enqueued on `stream`: d_g1 = (n + 1) x 96 bytes with slot 0 = -G1 and slots
+ * 1 .. n the keys (k == 0) or left for the key sums to fill (k > 0); d_g2 = (n + 1) x 192 bytes with slot 0 = sig,
+ * slots 1 .. n filled by the hash; d_out receives 576 bytes. */
+int blsgpu_verify_pipeline_dev(blsgpu_ctx *ctx, void *d_g1, void *d_g2, const void *d_msg_hashes, size_t n,
+                               const void *d_key_pts, const void *d_key_scalars, size_t k, void *d_out, void *stream);
+
 /* fq_ate_pairing_multi(Ps, Qs) -- fields_t.py:1114-1121 / fields_t_c.pyx:2333-2391.
  * Host buffers in, 576 result bytes out; synchronous.  n == 0 returns one. */
 int blsgpu_pairing_multi(blsgpu_ctx *ctx, const uint8_t *g1, const uint8_t *g2, const uint8_t *inf,

@@ -24,7 +24,7 @@ SYMBOLS = (
     "blsgpu_hash_to_g2", "blsgpu_hash_to_g2_dev",
     "blsgpu_miller_loop_batch", "blsgpu_miller_loop_batch_dev", "blsgpu_line_eval_batch", "blsgpu_ctx_trim",
     "blsgpu_fq12_op_batch", "blsgpu_fq12_pow_batch", "blsgpu_ctx_set_mp3_threshold", "blsgpu_ctx_set_ls_threshold", "blsgpu_ctx_set_ls_teams", "blsgpu_ctx_set_bulk_event", "blsgpu_ctx_set_fexp_team_threshold", "blsgpu_ctx_set_fexp_trace", "blsgpu_debug_read_lines",
-    "blsgpu_ctx_workspace_bytes",
+    "blsgpu_ctx_workspace_bytes", "blsgpu_verify_pipeline", "blsgpu_verify_pipeline_dev",
 )
 
 _lib = None
@@ -71,6 +71,8 @@ def load_library(path=None):
         L.blsgpu_ctx_set_fexp_trace.argtypes = [vp, vp]
         L.blsgpu_debug_read_lines.argtypes = [vp, vp, sz]
         L.blsgpu_ctx_workspace_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
+        L.blsgpu_verify_pipeline.argtypes = [vp, cp, cp, cp, sz, cp, cp, cp, sz, cp]
+        L.blsgpu_verify_pipeline_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp, sz, vp, vp]
         L.blsgpu_ctx_trim.argtypes = [vp]
         L.blsgpu_pairing_multi.argtypes = [vp, cp, cp, cp, sz, cp]
         L.blsgpu_pairing_multi_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
@@ -157,6 +159,14 @@ class Engine:
         out = (ctypes.c_size_t * len(self.WS_FIELDS))()
         self._check(self.lib.blsgpu_ctx_workspace_bytes(self.h, out), "blsgpu_ctx_workspace_bytes")
         return dict(zip(self.WS_FIELDS, (int(v) for v in out)))
+
+    def verify_pipeline(self, neg_g1, sig, hashes, n, keys_affine=None, key_pts=None, key_scalars=None, k=0):
+        """blsgpu_verify_pipeline: e(-G1, sig) * prod e(P_i, H(m_i)) -- hash to G2, key sums and multi-pairing in one
+        call on host buffers (ctypes only: no torch)"""
+        out = ctypes.create_string_buffer(576)
+        self._check(self.lib.blsgpu_verify_pipeline(self.h, neg_g1, sig, hashes if n else None, n, keys_affine, key_pts, key_scalars,
+                                                    k, out), "blsgpu_verify_pipeline")
+        return out.raw
 
     def set_ls_teams(self, teams):
         self._check(self.lib.blsgpu_ctx_set_ls_teams(self.h, teams), "blsgpu_ctx_set_ls_teams")

@@ -48,32 +48,11 @@ class HipProvider:
 
     # ---- the whole of BLS.verify's device work without a host round trip between its steps (bls.py:153-201) ----
     def verify_pipeline(self, neg_g1: bytes, sig: bytes, hashes: bytes, n: int, keys_affine=None, key_pts=None, key_scalars=None, k=0) -> bytes:
-        """e(-G1, sig) * prod_i e(P_i, H(m_i)) for n message hashes (32 bytes each): ONE upload, then on the device
-        hash-to-G2 of the hashes, P_i = either the given affine keys (n x 96 bytes) or the per-message key sums
-        (key_pts: n x k x 96 bytes, key_scalars: n x k x 32 bytes big-endian) and the (n + 1)-pair multi-pairing;
-        576 bytes come back.  The points, hashes and key sums never leave HBM between the three engine calls."""
-        import torch
-        e = self._eng
-        dev = torch.device("cuda", e.device if hasattr(e, "device") else 0)
-        parts = [neg_g1, keys_affine if keys_affine is not None else bytes(96 * n), sig, bytes(192 * n), hashes]
-        if keys_affine is None:
-            parts += [key_pts, key_scalars]
-        host = torch.frombuffer(bytearray(b"".join(parts)), dtype=torch.uint8)
-        buf = host.to(dev, non_blocking=False)
-        o_g1, o_g2 = 0, 96 * (n + 1)
-        o_h = o_g2 + 192 * (n + 1)
-        o_kp = o_h + 32 * n
-        base = buf.data_ptr()
-        st = torch.cuda.current_stream(dev).cuda_stream
-        if n:
-            e._check(e.lib.blsgpu_hash_to_g2_dev(e.h, base + o_h, n, base + o_g2 + 192, st), "blsgpu_hash_to_g2_dev")
-            if keys_affine is None:
-                inf = torch.empty(n, dtype=torch.uint8, device=dev)
-                e._check(e.lib.blsgpu_g1_msm_dev(e.h, base + o_kp, base + o_kp + 96 * n * k, k, n, base + o_g1 + 96, inf.data_ptr(), st),
-                         "blsgpu_g1_msm_dev")
-        out = torch.empty(576, dtype=torch.uint8, device=dev)
-        e.pairing_multi_dev(base + o_g1, base + o_g2, n + 1, out.data_ptr(), st)
-        return bytes(out.cpu().numpy())
+        """e(-G1, sig) * prod_i e(P_i, H(m_i)) for n message hashes (32 bytes each): blsgpu_verify_pipeline -- ONE upload,
+        then on the device hash-to-G2 of the hashes, P_i = either the given affine keys (n x 96 bytes) or the per-message
+        key sums (key_pts: n x k x 96 bytes, key_scalars: n x k x 32 bytes big-endian) and the (n + 1)-pair
+        multi-pairing; 576 bytes come back.  Nothing but the C ABI (no torch)."""
+        return self._eng.verify_pipeline(neg_g1, sig, hashes, n, keys_affine, key_pts, key_scalars, k)
 
 
 def use(provider):

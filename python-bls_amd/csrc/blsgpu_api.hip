@@ -87,7 +87,8 @@ struct blsgpu_ctx {
     void* d_bad = nullptr;             // one byte per pair: left to the slow program
     size_t bad_cap = 0;
     bool vm_exact_lanes = true;        // degenerate blocks of the VM kernels through the lane kernels (k_ml_lines_exact / k_ml_small) instead of k_miller_slow
-    int ls_horner_form = 2;            // 2: one group per wavefront, a product spread over 36 lanes; 1: ten groups per wavefront
+    int ls_horner_form = 3;            // 3: one group per wavefront, a product PER LANE (blsgpu_fexpw.hip; merges of few outputs likewise); 2: a product spread over 36 lanes; 1: ten groups per wavefront
+    size_t ls_merge_wide_max = 16384;  // merge levels with at most this many outputs run one wavefront per output
     int ls_lines_form = 2;             // 2: the point chains on lane pairs (k_ml_lines2); 1: one pair per lane (k_ml_lines)
     size_t fexp_team_threshold = 5120; // results per call from which the final exponentiations run six lanes each (blsgpu_fexp.hip); below: one result per wavefront (measured crossover, tools/fexp_latency.py)
     bool fexp_wide = true;             // fewer results than that: one result per wavefront, a product per lane (blsgpu_fexpw.hip); false: the VM program
@@ -505,7 +506,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_FEXP_WIDE_MAX_PARTIALS")) c->fexp_wide_max_partials = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_VM_EXACT_LANES")) c->vm_exact_lanes = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_LS_LINES_FORM")) c->ls_lines_form = atoi(e) == 1 ? 1 : 2;
-    if (const char* e = getenv("BLSGPU_LS_HORNER_FORM")) c->ls_horner_form = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("BLSGPU_LS_HORNER_FORM")) c->ls_horner_form = atoi(e) == 1 ? 1 : (atoi(e) == 2 ? 2 : 3);
+    if (const char* e = getenv("BLSGPU_LS_MERGE_WIDE_MAX")) c->ls_merge_wide_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -905,8 +907,10 @@ static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, cons
 static bool use_ls(const blsgpu_ctx* c, size_t gsz, size_t groups) {
     return gsz >= 1 && gsz * groups >= c->ls_threshold && gsz * groups <= 0x3FFFFFF0ull;
 }
+// d_fused_out (optional): the caller wants nothing but the final exponentiation of each group's product -- the kernel
+// that ends the stage (k_ml_horner_fexp) then goes on to it in place: no partial, no further launch; *fused tells.
 static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups,
-                            uint32_t* d_partials, hipStream_t st) {
+                            uint32_t* d_partials, hipStream_t st, void* d_fused_out = nullptr, bool* fused = nullptr) {
     using namespace blsgpu;
     const size_t n = gsz * groups;
     // chunks: equal runs of a group's pairs, one accumulator each per line index, sized so that about ls_teams
@@ -972,16 +976,26 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
         const size_t cpo = (cpg + FAN - 1) / FAN;
         teams = groups * cpo * ml::LINES;
         KernelTimer kt(c, st, 6);
-        hipLaunchKernelGGL(ml::k_ml_merge, dim3((unsigned)((teams + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur],
-                           (uint32_t)cpg, (uint32_t)FAN, (uint32_t)cpo, (uint32_t)teams, (int32_t*)c->d_lsp[cur ^ 1]);
+        if (c->ls_horner_form == 3 && teams <= c->ls_merge_wide_max)       // few outputs: one wavefront each, a product per lane
+            hipLaunchKernelGGL(fxw::k_ml_merge_wide, dim3((unsigned)teams), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur], (uint32_t)cpg,
+                               (uint32_t)FAN, (uint32_t)cpo, (int32_t*)c->d_lsp[cur ^ 1]);
+        else
+            hipLaunchKernelGGL(ml::k_ml_merge, dim3((unsigned)((teams + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st,
+                               (const int32_t*)c->d_lsp[cur], (uint32_t)cpg, (uint32_t)FAN, (uint32_t)cpo, (uint32_t)teams,
+                               (int32_t*)c->d_lsp[cur ^ 1]);
         HIP_TRY(hipGetLastError());
         cpg = cpo;
         cur ^= 1;
     }
     if (c->bulk_event) HIP_TRY(hipEventRecord(c->bulk_event, st));
     {
-        KernelTimer kt(c, st, 7);
-        if (c->ls_horner_form == 1)
+        const bool fuse = c->ls_horner_form == 3 && d_fused_out != nullptr && use_fexp_wide(c, 1, groups);
+        KernelTimer kt(c, st, fuse ? 2 : 7);
+        if (c->ls_horner_form == 3) {
+            hipLaunchKernelGGL(fxw::k_ml_horner_fexp, dim3((unsigned)groups), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur], d_partials, 144u,
+                               (uint32_t*)(fuse ? d_fused_out : nullptr));
+            if (fused) *fused = fuse;
+        } else if (c->ls_horner_form == 1)
             hipLaunchKernelGGL(ml::k_ml_horner, dim3((unsigned)((groups + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st,
                                (const int32_t*)c->d_lsp[cur], (uint32_t)groups, d_partials, 144u);
         else
@@ -1019,7 +1033,9 @@ static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, co
         // or, for ONE long group, runs of its pairs that each leave a partial for the product below.
         int rc = 0;
         if (gsz * groups <= LS_MAX_PAIRS) {
-            rc = launch_miller_ls(c, d_g1, d_g2, d_inf, gsz, groups, c->d_part[0], st);
+            bool fused = false;
+            rc = launch_miller_ls(c, d_g1, d_g2, d_inf, gsz, groups, c->d_part[0], st, d_out_bytes, &fused);
+            if (rc == 0 && fused) return 0;               // the stage's last kernel ran the final exponentiations too
             bpg = 1;
         } else if (gsz <= LS_MAX_PAIRS) {
             const size_t per = LS_MAX_PAIRS / gsz;
@@ -1437,6 +1453,59 @@ BLSGPU_EXPORT int blsgpu_hash_to_g2_dev(blsgpu_ctx* c, const void* d_msg_hashes,
     if (!c || (n && (!d_msg_hashes || !d_out))) return fail(-EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     return map_to_g2_impl(c, d_msg_hashes, n, d_out, (hipStream_t)stream, true);
+}
+
+// ---- the device work of BLS.verify (bls.py:153-201) in one call ----------------------------------------------------------
+// d_g1: (n + 1) x 96 bytes, slot 0 = -G1, slots 1 .. n = the per-message keys (given, or written here by the key sums);
+// d_g2: (n + 1) x 192 bytes, slot 0 = the aggregate signature, slots 1 .. n written here by the hash to G2.
+BLSGPU_EXPORT int blsgpu_verify_pipeline_dev(blsgpu_ctx* c, void* d_g1, void* d_g2, const void* d_msg_hashes, size_t n, const void* d_key_pts,
+                                             const void* d_key_scalars, size_t k, void* d_out, void* stream) {
+    if (!c || !d_g1 || !d_g2 || !d_out || (n && !d_msg_hashes)) return fail(-EINVAL, "NULL argument");
+    if (k && (!d_key_pts || !d_key_scalars)) return fail(-EINVAL, "NULL key buffer");
+    if (n > 0x03FFFFF0ull) return fail(-EINVAL, "batch too large");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n) {
+        if (int rc = map_to_g2_impl(c, d_msg_hashes, n, (char*)d_g2 + BLSGPU_G2_BYTES, (hipStream_t)stream, true)) return rc;
+        if (k)
+            if (int rc = msm_dev<1>(c, d_key_pts, d_key_scalars, k, n, (char*)d_g1 + BLSGPU_G1_BYTES, nullptr, (hipStream_t)stream)) return rc;
+    }
+    return blsgpu_pairing_multi_dev(c, d_g1, d_g2, nullptr, n + 1, d_out, stream);
+}
+
+// Host buffers: ONE upload (points, hashes, keys), the three stages on the device, 576 bytes back.
+BLSGPU_EXPORT int blsgpu_verify_pipeline(blsgpu_ctx* c, const uint8_t neg_g1[96], const uint8_t sig[192], const uint8_t* msg_hashes, size_t n,
+                                         const uint8_t* keys_affine, const uint8_t* key_pts, const uint8_t* key_scalars, size_t k,
+                                         uint8_t out[576]) {
+    if (!c || !neg_g1 || !sig || !out || (n && !msg_hashes)) return fail(-EINVAL, "NULL argument");
+    if (n && !keys_affine && !(k && key_pts && key_scalars)) return fail(-EINVAL, "neither keys nor key sums given");
+    if (n > 0x03FFFFF0ull) return fail(-EINVAL, "batch too large");
+    HIP_TRY(hipSetDevice(c->device));
+    const bool sums = n && !keys_affine;
+    const size_t o_g1 = 0, o_g2 = (n + 1) * BLSGPU_G1_BYTES, o_h = o_g2 + (n + 1) * BLSGPU_G2_BYTES, o_kp = o_h + ((n * 32 + 63) & ~(size_t)63);
+    const size_t o_ks = o_kp + (sums ? n * k * BLSGPU_G1_BYTES : 0), o_out = o_ks + (sums ? n * k * 32 : 0);
+    // the VM kernels round their team counts up: reserve as a call of n + 1 pairs does
+    if (int rc = grow_buffer(c, &c->d_io, &c->io_cap, o_out + 576 + 64)) return rc;
+    if (int rc = ensure_workspace(c, (n + 4) * MILLER_WAVES)) return rc;
+    char* d = (char*)c->d_io;
+    {
+        StreamGuard sg(c, nullptr);
+        HIP_TRY(hipMemcpyAsync(d + o_g1, neg_g1, BLSGPU_G1_BYTES, hipMemcpyHostToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(d + o_g2, sig, BLSGPU_G2_BYTES, hipMemcpyHostToDevice, nullptr));
+        if (n) {
+            HIP_TRY(hipMemcpyAsync(d + o_h, msg_hashes, n * 32, hipMemcpyHostToDevice, nullptr));
+            if (sums) {
+                HIP_TRY(hipMemcpyAsync(d + o_kp, key_pts, n * k * BLSGPU_G1_BYTES, hipMemcpyHostToDevice, nullptr));
+                HIP_TRY(hipMemcpyAsync(d + o_ks, key_scalars, n * k * 32, hipMemcpyHostToDevice, nullptr));
+            } else {
+                HIP_TRY(hipMemcpyAsync(d + o_g1 + BLSGPU_G1_BYTES, keys_affine, n * BLSGPU_G1_BYTES, hipMemcpyHostToDevice, nullptr));
+            }
+        }
+    }
+    if (int rc = blsgpu_verify_pipeline_dev(c, d + o_g1, d + o_g2, d + o_h, n, sums ? d + o_kp : nullptr, sums ? d + o_ks : nullptr,
+                                            sums ? k : 0, d + o_out, nullptr))
+        return rc;
+    HIP_TRY(hipMemcpy(out, d + o_out, 576, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 BLSGPU_EXPORT int blsgpu_hash_to_g2(blsgpu_ctx* c, const uint8_t* msg_hashes, size_t n, uint8_t* out) {

@@ -124,55 +124,13 @@ __device__ __forceinline__ void tinv(int32_t* __restrict__ V, uint32_t quad, int
     }
 }
 
-// Result g = blockIdx.x: product of the partials in[(i * istride + g * gstride) * 144], i < m (the wavefront VM's form:
-// 12 x 12 words x 2^384, flat order), then the final exponentiation; 576 canonical big-endian bytes to out_bytes[g].
-// stamps (diagnostic, may be null): result 0 writes the cycle counter before the script and after every operation of it
-// (tools/fexpw_stamps.py).
-__global__ void __launch_bounds__(64) k_fexp_wide(const uint32_t* __restrict__ in, uint32_t m, uint32_t istride, uint32_t gstride,
-                                                  uint32_t* __restrict__ out_bytes, unsigned long long* __restrict__ stamps)
-#if BLSGPU_EMIT(BLSGPU_TU_FXW)
-{
-    __shared__ int32_t slots[BLS28_FEXP_NSLOTS][64][ROW];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t quad = lane >> 2;
-    const bool home_lane = quad < 12u;
-    const uint32_t k = (quad >> 1) % 6u, part = quad & 1u;
-    const uint32_t flat = (k & 1u) ? 3u + (k >> 1) : (k >> 1);                 // w-powers 0,2,4,1,3,5 in the flat order
-    const size_t g = blockIdx.x;
-    const uint32_t vr = lane & 3u;
-    const int32_t variant = vr == 0u ? 1 : (vr == 1u ? -1 : (vr == 2u ? 2 : -2));     // this lane holds variant x the quad's value
-    int32_t V[NL], G[NL];
-    {
-        const int32_t third[NL] = BLS28W_THIRD;
-        int32_t t[NL];
-#pragma unroll
-        for (int j = 0; j < NL; j++) { t[j] = quad == 12u ? third[j] : 0; G[j] = 0; }
-        scale_norm(V, t, variant);                         // quad 12: 1/3 in its variants; quads 13 .. 15: zero
-    }
+// the script of fexp_tables_gfx950.h (vmgen/fexp_model.script) on the accumulator V; G and the LDS rows are scratch
+__device__ __forceinline__ void final_exp_script(int32_t* __restrict__ V, int32_t* __restrict__ G, int32_t (*slots)[64][ROW], uint32_t lane,
+                                                 uint32_t quad, int32_t variant, bool home_lane, const P3& p_mul,
+                                                 unsigned long long* __restrict__ stamps) {
     const P1 p_csq = load_p1(BLS28W_CSQ, lane);
-    const P3 p_mul = load_p3(BLS28W_MUL, lane);
-#pragma unroll 1
-    for (uint32_t i = 0; i < m; i++) {
-        const uint32_t* p = in + ((size_t)i * istride + g * gstride) * 144 + flat * 24u + part * 12u;
-        uint32_t w[12];
-#pragma unroll
-        for (int j = 0; j < 12; j++) w[j] = p[j];
-        const fe a = r28::from_vm(w);
-        if (i == 0) {
-            int32_t s[NL];
-            scale_norm(s, a.v, variant);
-            if (home_lane) {
-#pragma unroll
-                for (int j = 0; j < NL; j++) V[j] = s[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NL; j++) G[j] = a.v[j];    // the products read lane 0 of a quad only: the value itself
-            step_vg(V, G, p_mul, variant, home_lane);
-        }
-    }
     uint32_t g_slot = 255u;                                // the slot G holds (255: none)
-    const bool stamp = stamps != nullptr && g == 0 && lane == 0u;
+    const bool stamp = stamps != nullptr && lane == 0u;
     if (stamp) stamps[0] = __builtin_readcyclecounter();
 #pragma unroll 1
     for (uint32_t pc = 0; pc < (uint32_t)BLS28_FEXP_NOPS; pc++) {
@@ -212,16 +170,164 @@ __global__ void __launch_bounds__(64) k_fexp_wide(const uint32_t* __restrict__ i
         }
     }
     if (stamp) stamps[BLS28_FEXP_NOPS] = __builtin_readcyclecounter();
-    if (home_lane && (lane & 3u) == 0u) {
-        uint32_t* o = out_bytes + g * 144 + flat * 24u + part * 12u;
-        fe a;
+}
+// the value itself (lane 0 of a home quad), canonical, as 48 big-endian bytes
+__device__ __forceinline__ void store_bytes(const int32_t* __restrict__ V, uint32_t* __restrict__ o, bool active) {
+    if (!active) return;
+    fe a;
 #pragma unroll
-        for (int j = 0; j < NL; j++) a.v[j] = V[j];
-        uint32_t w[12];
-        r28::to_raw(w, a);
+    for (int j = 0; j < NL; j++) a.v[j] = V[j];
+    uint32_t w[12];
+    r28::to_raw(w, a);
 #pragma unroll
-        for (int j = 0; j < 12; j++) o[j] = bswap32(w[11 - j]);
+    for (int j = 0; j < 12; j++) o[j] = bswap32(w[11 - j]);
+}
+
+// Result g = blockIdx.x: product of the partials in[(i * istride + g * gstride) * 144], i < m (the wavefront VM's form:
+// 12 x 12 words x 2^384, flat order), then the final exponentiation; 576 canonical big-endian bytes to out_bytes[g].
+// stamps (diagnostic, may be null): result 0 writes the cycle counter before the script and after every operation of it
+// (tools/fexpw_stamps.py).
+__global__ void __launch_bounds__(64) k_fexp_wide(const uint32_t* __restrict__ in, uint32_t m, uint32_t istride, uint32_t gstride,
+                                                  uint32_t* __restrict__ out_bytes, unsigned long long* __restrict__ stamps)
+#if BLSGPU_EMIT(BLSGPU_TU_FXW)
+{
+    __shared__ int32_t slots[BLS28_FEXP_NSLOTS][64][ROW];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t quad = lane >> 2;
+    const bool home_lane = quad < 12u;
+    const uint32_t k = (quad >> 1) % 6u, part = quad & 1u;
+    const uint32_t flat = (k & 1u) ? 3u + (k >> 1) : (k >> 1);                 // w-powers 0,2,4,1,3,5 in the flat order
+    const size_t g = blockIdx.x;
+    const uint32_t vr = lane & 3u;
+    const int32_t variant = vr == 0u ? 1 : (vr == 1u ? -1 : (vr == 2u ? 2 : -2));     // this lane holds variant x the quad's value
+    int32_t V[NL], G[NL];
+    {
+        const int32_t third[NL] = BLS28W_THIRD;
+        int32_t t[NL];
+#pragma unroll
+        for (int j = 0; j < NL; j++) { t[j] = quad == 12u ? third[j] : 0; G[j] = 0; }
+        scale_norm(V, t, variant);                         // quad 12: 1/3 in its variants; quads 13 .. 15: zero
     }
+    const P3 p_mul = load_p3(BLS28W_MUL, lane);
+#pragma unroll 1
+    for (uint32_t i = 0; i < m; i++) {
+        const uint32_t* p = in + ((size_t)i * istride + g * gstride) * 144 + flat * 24u + part * 12u;
+        uint32_t w[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) w[j] = p[j];
+        const fe a = r28::from_vm(w);
+        if (i == 0) {
+            int32_t s[NL];
+            scale_norm(s, a.v, variant);
+            if (home_lane) {
+#pragma unroll
+                for (int j = 0; j < NL; j++) V[j] = s[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NL; j++) G[j] = a.v[j];    // the products read lane 0 of a quad only: the value itself
+            step_vg(V, G, p_mul, variant, home_lane);
+        }
+    }
+    final_exp_script(V, G, slots, lane, quad, variant, home_lane, p_mul, g == 0 ? stamps : nullptr);
+    store_bytes(V, out_bytes + g * 144 + flat * 24u + part * 12u, home_lane && (lane & 3u) == 0u);
+}
+#else
+;
+#endif
+
+// ---- the same lane layout for the serial tails of the line-stream Miller stage (blsgpu_ml.hip) -------------------------
+// A dense record is 12 x 14 limbs in w-power order: value (k, part) at [(2 k + part) * 14].  In the six-lanes-per-value
+// layout of k_ml_merge / k_ml_horner_wide a dense product is 6.8 k (1.6 k) instructions deep; with a product per lane it is
+// 1.2 k: what a call waits for once few teams are left.
+__device__ __forceinline__ void load_dense(int32_t* __restrict__ X, const int32_t* __restrict__ rec, uint32_t quad) {
+    const int32_t* p = rec + (quad < 12u ? quad : 0u) * NL;
+#pragma unroll
+    for (int j = 0; j < NL; j++) X[j] = p[j];
+}
+// One wavefront per output record: team (g, jo, L) multiplies the records (g, j, L), j in [jo * fan, min(cpg_in, (jo + 1) * fan)),
+// of `in` (indexed as k_ml_accum's output with cpg_in) -> out (cpg_out): the tree levels of k_ml_merge with few outputs.
+__global__ void __launch_bounds__(64) k_ml_merge_wide(const int32_t* __restrict__ in, uint32_t cpg_in, uint32_t fan, uint32_t cpg_out,
+                                                      int32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_FXW)
+{
+    const uint32_t lane = threadIdx.x & 63u, quad = lane >> 2, vr = lane & 3u;
+    const bool home_lane = quad < 12u;
+    const int32_t variant = vr == 0u ? 1 : (vr == 1u ? -1 : (vr == 2u ? 2 : -2));
+    const uint32_t id = blockIdx.x;
+    const uint32_t L = id % (uint32_t)ml::LINES, gj = id / (uint32_t)ml::LINES, jo = gj % cpg_out, g = gj / cpg_out;
+    const uint32_t lo = jo * fan, hi = min(cpg_in, lo + fan);
+    const P3 p_mul = load_p3(BLS28W_MUL, lane);
+    const int32_t* rec = in + ((size_t)(g * cpg_in + lo) * ml::LINES + L) * ml::DENSE_DW;
+    int32_t V[NL], G[NL], t[NL];
+    load_dense(t, rec, quad);
+    scale_norm(V, t, home_lane ? variant : 0);             // quads 12 .. 15: zero
+#pragma unroll 1
+    for (uint32_t i = lo + 1u; i < hi; i++) {
+        rec += (size_t)ml::LINES * ml::DENSE_DW;
+        load_dense(G, rec, quad);
+        step_vg(V, G, p_mul, variant, home_lane);
+    }
+    if (home_lane && vr == 0u) {
+        int32_t* o = out + (size_t)id * ml::DENSE_DW + quad * NL;
+#pragma unroll
+        for (int j = 0; j < NL; j++) o[j] = V[j];
+    }
+}
+#else
+;
+#endif
+
+// Group g = blockIdx.x: f = M_0; for L = 1 .. 67: (tangent: f <- f^2;) f <- f M_L with M_L = prods[(g * 68 + L) * 168] (the serial
+// chain of the line-stream stage, k_ml_horner_wide's job) -- then either the wavefront VM's form of f to
+// partials[g * pstride] (144 words; the sharded entries and k_reduce take it from there), or, with out_bytes, the final
+// exponentiation right here (no partial, no second launch): 576 canonical big-endian bytes to out_bytes[g].
+__global__ void __launch_bounds__(64) k_ml_horner_fexp(const int32_t* __restrict__ prods, uint32_t* __restrict__ partials, uint32_t pstride,
+                                                       uint32_t* __restrict__ out_bytes)
+#if BLSGPU_EMIT(BLSGPU_TU_FXW)
+{
+    __shared__ int32_t slots[BLS28_FEXP_NSLOTS][64][ROW];
+    const uint32_t lane = threadIdx.x & 63u, quad = lane >> 2, vr = lane & 3u;
+    const bool home_lane = quad < 12u;
+    const int32_t variant = vr == 0u ? 1 : (vr == 1u ? -1 : (vr == 2u ? 2 : -2));
+    const uint32_t k = (quad >> 1) % 6u, part = quad & 1u;
+    const uint32_t flat = (k & 1u) ? 3u + (k >> 1) : (k >> 1);
+    const size_t g = blockIdx.x;
+    const P3 p_mul = load_p3(BLS28W_MUL, lane);
+    const int32_t* rec = prods + g * ml::LINES * ml::DENSE_DW;
+    int32_t V[NL], G[NL], t[NL];
+    load_dense(t, rec, quad);
+    {
+        const int32_t third[NL] = BLS28W_THIRD;
+#pragma unroll
+        for (int j = 0; j < NL; j++) t[j] = home_lane ? t[j] : (quad == 12u ? third[j] : 0);
+    }
+    scale_norm(V, t, variant);
+#pragma unroll 1
+    for (uint32_t L = 1; L < (uint32_t)ml::LINES; L++) {
+        if (ml::line_is_tangent(L)) {
+#pragma unroll
+            for (int j = 0; j < NL; j++) G[j] = V[j];      // lane 0 of a quad holds the value itself: f <- f f
+            step_vg(V, G, p_mul, variant, home_lane);
+        }
+        load_dense(G, rec + (size_t)L * ml::DENSE_DW, quad);
+        step_vg(V, G, p_mul, variant, home_lane);
+    }
+    if (out_bytes == nullptr) {
+        if (home_lane && vr == 0u) {
+            uint32_t* o = partials + g * pstride + flat * 24u + part * 12u;
+            fe a;
+#pragma unroll
+            for (int j = 0; j < NL; j++) a.v[j] = V[j];
+            uint32_t w[12];
+            r28::to_vm(w, a);                              // a product by 2^384 mod q, canonical (limbs normalised, |value| < 16 q)
+#pragma unroll
+            for (int j = 0; j < 12; j++) o[j] = w[j];
+        }
+        return;
+    }
+    final_exp_script(V, G, slots, lane, quad, variant, home_lane, p_mul, nullptr);
+    store_bytes(V, out_bytes + g * 144 + flat * 24u + part * 12u, home_lane && vr == 0u);
 }
 #else
 ;

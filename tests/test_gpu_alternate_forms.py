@@ -3,7 +3,9 @@ workspace cannot be allocated (VERDICT r3 item 1 d / e): each is reachable throu
 creation (csrc/blsgpu_api.hip), so each gets the reference's vectors.
 
   BLSGPU_LS_LINES_FORM=1    k_ml_lines: the point chains with one pair per lane (default: k_ml_lines2, lane pairs)
-  BLSGPU_LS_HORNER_FORM=1   k_ml_horner: ten groups per wavefront (default: k_ml_horner_wide, one group per wavefront)
+  BLSGPU_LS_HORNER_FORM=1   k_ml_horner: ten groups per wavefront; =2 k_ml_horner_wide: a product over 36 lanes
+                            (default since round 4: k_ml_horner_fexp, a product per lane, and k_ml_merge_wide for merge
+                            levels with few outputs -- BLSGPU_LS_MERGE_WIDE_MAX=0 keeps k_ml_merge for all of them)
   BLSGPU_VM_EXACT_LANES=0   degenerate blocks of the wavefront-VM kernels recomputed by k_miller_slow
                             (default: k_ml_lines_exact in block mode + k_ml_small in list mode)
   BLSGPU_TEST_LS_NOMEM=1    test hook: launch_miller_ls reports -ENOMEM before touching the device, the call must go
@@ -23,6 +25,8 @@ pytestmark = pytest.mark.gpu
 FORMS = {
     "lines_one_pair_per_lane": ({"BLSGPU_LS_LINES_FORM": "1"}, True),
     "horner_ten_groups_per_wavefront": ({"BLSGPU_LS_HORNER_FORM": "1"}, True),
+    "horner_product_over_36_lanes": ({"BLSGPU_LS_HORNER_FORM": "2"}, True),                # round 3's default
+    "merge_levels_six_lanes_per_value": ({"BLSGPU_LS_MERGE_WIDE_MAX": "0"}, True),          # k_ml_merge for every level
     "both_old_forms": ({"BLSGPU_LS_LINES_FORM": "1", "BLSGPU_LS_HORNER_FORM": "1"}, True),
     "vm_slow_program_for_degenerate_blocks": ({"BLSGPU_VM_EXACT_LANES": "0"}, False),
     "line_stream_workspace_unavailable": ({"BLSGPU_TEST_LS_NOMEM": "1"}, True),

@@ -1,5 +1,9 @@
 """The reference's scheme-level scenarios with the pairing on the GPU (default
 provider = HIP engine through the C ABI).  Needs an MI355X."""
+import hashlib
+import json
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -212,3 +216,48 @@ def test_verify_pipeline_equals_the_tuple_path(golden):
     finally:
         backend.use(None)
     assert fast == slow == [True, True, True, False, False]
+
+
+def test_verify_needs_nothing_but_the_c_abi(golden):
+    """blsgpu_verify_pipeline (include/blsgpu.h; bls.py:153-201): BLS.verify of the reference's 4-signature scenario
+    (tests/golden/verify4.json: True; the tampered aggregate: False) in a process where torch is never imported -- the
+    host side is ctypes over libblsgpu.so and nothing else -- and the entry itself against the multi-pairing of the
+    same points assembled by hand."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import json, os, sys
+sys.path.insert(0, os.path.join(%r, "python-bls_amd"))
+from bls_py.bls import BLS
+from bls_py.keys import PrivateKey
+v = json.load(open(os.path.join(%r, "tests", "golden", "verify4.json")))
+sks = [PrivateKey.from_seed(bytes([i + 1] * 5)) for i in range(4)]
+sigs = [sk.sign(bytes([i, 100 + i])) for i, sk in enumerate(sks)]
+agg = BLS.aggregate_sigs(sigs)
+assert agg.serialize().hex() == v["agg_sig"], "aggregate differs from the reference's"
+ok = BLS.verify(agg)
+bad = BLS.aggregate_sigs(sigs[:3]); bad.set_aggregation_info(agg.aggregation_info)
+print(json.dumps({"verify": ok, "tampered": BLS.verify(bad), "torch_loaded": "torch" in sys.modules}))
+''' % (ROOT, ROOT)
+    env = dict(os.environ, BLSGPU_NO_TORCH="1", PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec == {"verify": True, "tampered": False, "torch_loaded": False}
+    # the entry point itself: keys given / key sums with exponent 1 and padding, against blsgpu_pairing_multi on the same points
+    from bls_py import _native, hostmath as H
+    from bls_py.util import hash512
+    e = _native.engine(0)
+    n = 5
+    hashes = [hashlib.sha256(b"pipeline-%d" % i).digest() for i in range(n)]
+    keys = [H.g1_affine_bytes(H.jac_to_affine(H.F1, H.jac_mul(H.F1, H.aff_to_jac(H.F1, H.G1_GEN), 3 + i))) for i in range(n)]
+    sig = H.g2_affine_bytes(H.jac_to_affine(H.F2, H.jac_mul(H.F2, H.aff_to_jac(H.F2, H.G2_GEN), 77)))
+    neg = H.g1_affine_bytes(H.jac_to_affine(H.F1, H.jac_neg(H.F1, H.aff_to_jac(H.F1, H.G1_GEN))))
+    qs = e.hash_to_g2(b"".join(hashes))
+    want = e.pairing_multi(neg + b"".join(keys), sig + qs, n + 1)
+    assert e.verify_pipeline(neg, sig, b"".join(hashes), n, keys_affine=b"".join(keys)) == want
+    pts = b"".join(k + bytes(96) for k in keys)                                  # k = 2: the key and a padding slot
+    sc = b"".join((1).to_bytes(32, "big") + bytes(32) for _ in keys)
+    assert e.verify_pipeline(neg, sig, b"".join(hashes), n, key_pts=pts, key_scalars=sc, k=2) == want
+    assert e.verify_pipeline(neg, sig, b"", 0) == e.pairing_multi(neg, sig, 1)
