@@ -424,14 +424,31 @@ def run_pairing(env, args):
     info = env.gather_objects({"rank": rank, "sums": sums, "k_miller_ms_avg": miller_avg, "pairs": n * B,
                                "device": torch.cuda.get_device_name(dev)})
     # latency views of the literal configs on this GPU alone: one 1025-pair verification, one 8192-pair shard
+    # ONE step alone on an idle GPU with the kernel timers on: the durations of the few-wavefront kernels (products of
+    # partials, Horner, final exponentiations) as they are, not stretched by the next step's chip-filling point chains
+    solo = {}
+    if rank == 0 and env.dist is None:
+        torch.cuda.synchronize()
+        eng.timing_enable(True)
+        step(0)
+        torch.cuda.synchronize()
+        kt = eng.timing_read()
+        eng.timing_enable(False)
+        names = {0: "k_miller", 1: "k_reduce", 2: "final_exp", 3: "k_ml_lines_exact", 4: "k_ml_lines", 5: "k_ml_accum", 6: "k_ml_merge", 7: "k_ml_horner"}
+        for kind, ms in kt:
+            solo[names.get(kind, str(kind))] = solo.get(names.get(kind, str(kind)), 0.0) + ms
     eng.set_mp_threshold(4096)
     lat = {}
     if rank == 0 and not args.no_latency:
-        for m in (1025, 8192):
+        # the throughput-against-batch curve of ONE call (the headline needs 524 800 pairs in flight per step): the literal
+        # configs among them -- 1025 pairs = configs[1], 8192 = the per-GPU shard of configs[2], 65 536 = configs[2] on one GPU
+        for m in (1, 1025, 4096, 8192, 16384, 65536, 262144, 1048576):
             reps = (m + len(g1) // 96 - 1) // (len(g1) // 96)
             x1, x2 = env.up((g1 * reps)[:96 * m]), env.up((g2 * reps)[:192 * m])
-            ms = latency_probe(env, eng, x1, x2, m, streams[0])
+            eng.reserve(m)
+            ms = latency_probe(env, eng, x1, x2, m, streams[0], reps=4 if m <= 65536 else 2)
             lat["%d_pairs" % m] = {"latency_ms": ms, "pairings_per_s": m / (ms * 1e-3)}
+            del x1, x2
 
     if rank == 0:
         total_pairs = sum(i["pairs"] for i in info) * args.steps
@@ -488,9 +505,14 @@ def run_pairing(env, args):
                          "kernel": kname,
                          "kernel_launches_timed": launches, "kernel_ms_avg": miller_avg,
                          "pairings_per_launch": n * B, "mac_per_pairing": MAC_PER_PAIRING,
-                         "reduce_kernels_ms_per_step": sum(reduce_ms) / max(1, launches),
+                         # (overlapped: these few-wavefront kernels of step i run beside the chip-filling point chains of step
+                         # i + 1 and are stretched by them; *_solo_ms: the same kernels of one step alone on the idle GPU)
+                         "reduce_kernels_ms_per_step_overlapped": sum(reduce_ms) / max(1, launches),
                          "degenerate_pair_kernel_ms_per_step": sum(slow_ms) / max(1, launches),
-                         "final_exp_kernel_ms_avg": (sum(fexp_ms) / len(fexp_ms)) if fexp_ms else None,
+                         "final_exp_kernel_ms_avg_overlapped": (sum(fexp_ms) / len(fexp_ms)) if fexp_ms else None,
+                         "one_step_alone_kernel_ms": solo,
+                         "hbm_workspace_bytes": {"all_contexts": sum(e.workspace_bytes()["total"] for e in engs),
+                                                 "contexts": len(engs), "one_context": eng.workspace_bytes()},
                          "whole_step_TMACs": (MAC_PER_PAIRING * n + MAC_PER_FINAL_EXP) * B * world / (dt / args.steps) / 1e12,
                          "step_latency_ms_avg": sum(step_ms) / len(step_ms), "step_latency_ms_min": step_ms[0],
                          "hbm_GBps_algorithmic": alg_bytes / (miller_avg * 1e-3) / 1e9,
@@ -506,6 +528,17 @@ def run_pairing(env, args):
             line["roofline"]["stage_kernels_ms_avg"] = ls_avg
             line["roofline"]["k_ml_accum_executed_mad28_Tps"] = exec_mads / (ls_avg["k_ml_accum"] * 1e-3) / 1e12
             line["roofline"]["k_ml_accum_frac_of_mad_i64_i32_peak"] = exec_mads / (ls_avg["k_ml_accum"] * 1e-3) / 1e12 / PEAK_MAD28_T
+            # the point-chain kernel likewise: v_mad_i64_i32 per wavefront and step read off the ISA of the shipped build
+            # (tangent step 5320, chord step 8847; 32 pairs per wavefront, both lanes of a pair count)
+            lines_mads = (63 * 5320 + 5 * 8847) * 2 * n * B
+            line["roofline"]["k_ml_lines_executed_mad28_Tps"] = lines_mads / (ls_avg["k_ml_lines"] * 1e-3) / 1e12
+            line["roofline"]["k_ml_lines_frac_of_mad_i64_i32_peak"] = lines_mads / (ls_avg["k_ml_lines"] * 1e-3) / 1e12 / PEAK_MAD28_T
+            line["roofline"]["executed_mad28_per_pairing"] = (exec_mads + lines_mads) / (n * B)
+            line["roofline"]["stage_frac_by_executed_work"] = (exec_mads + lines_mads) / (miller_avg * 1e-3) / 1e12 / PEAK_MAD28_T
+            line["roofline"]["note"] = ("frac credits SURVEY 8(d)'s 2.026 M MAC32 per pairing, which counts a 36 m squaring of the accumulator "
+                                        "per pair and step (this design squares once per GROUP in the Horner kernel) and 300 MAC32 per Fq "
+                                        "product (28-bit limbs execute 392); the two nearly cancel: executed_mad28_per_pairing / "
+                                        "stage_frac_by_executed_work state what the two kernels really issue")
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(g1[:96 * min(n, 1025)], g2[:192 * min(n, 1025)], min(n, 1025), per[0] if n == 1025 else None)
             if not cb["matches_gpu"]:
@@ -547,7 +580,53 @@ def secondary(env, args, eng, gen1, gen2):
                      "workload": ln["config"]["workload"], "roofline_frac": ln["roofline"]["frac"]}
         if name == "c4":
             out[name].update(combine_ms=ln["combine_s"] * 1e3, verify_ms=ln["verify_s"] * 1e3)
+    out["verify_pipeline"] = run_verify_pipeline(env, eng)
     return out
+
+
+def run_verify_pipeline(env, eng, B=256, n=1024):
+    """The device part of B x BLS.verify (bls.py:153-201) on aggregates of n signatures over n distinct messages, everything
+    resident in HBM: hash the B x n message hashes to G2 (ec.py:528-550), place them behind each aggregate signature, one
+    batched (n + 1)-pair multi-pairing per aggregate, compare with one.  One key per message with exponent 1 (plain
+    aggregation, bls.py:177-192).  ONE real aggregate (signed and aggregated through the package) verified B times with
+    rotated message order."""
+    torch = env.torch
+    from bls_py import hostmath as H
+    from bls_py.bls import BLS
+    from bls_py.keys import PrivateKey
+    sks = [PrivateKey(int.from_bytes(hashlib.sha256(b"pipe%d" % i).digest(), "big") % (N_ORDER - 1) + 1) for i in range(n)]
+    msgs = [i.to_bytes(4, "big") for i in range(n)]
+    sigs = PrivateKey.sign_batch(sks, msgs)
+    agg = BLS.aggregate_sigs(sigs)
+    mh = [hashlib.sha256(m).digest() for m in msgs]
+    pks = [H.g1_affine_bytes(s.aggregation_info.public_keys[0].value.to_affine()._aff()) for s in sigs]
+    neg_g1 = H.g1_affine_bytes(H.jac_to_affine(H.F1, H.jac_mul(H.F1, H.aff_to_jac(H.F1, H.G1_GEN), N_ORDER - 1)))
+    sig_b = H.g2_affine_bytes(agg.value.to_affine()._aff())
+    g1_all, mh_all = bytearray(), bytearray()
+    for v in range(B):
+        order = [(i + 31 * v) % n for i in range(n)]
+        g1_all += neg_g1 + b"".join(pks[i] for i in order)
+        mh_all += b"".join(mh[i] for i in order)
+    d_g1, d_mh = env.up(g1_all), env.up(mh_all)
+    d_g2 = torch.zeros(B * (n + 1) * 192, dtype=torch.uint8, device=env.dev).view(B, n + 1, 192)
+    d_g2[:, 0, :] = env.up(sig_b)
+    d_h = torch.zeros(B * n * 192, dtype=torch.uint8, device=env.dev)
+    d_out = torch.zeros(B * 576, dtype=torch.uint8, device=env.dev)
+    eng.reserve((n + 4) * B)
+    eng.set_mp_threshold(0)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        eng.lib.blsgpu_hash_to_g2_dev(eng.h, d_mh.data_ptr(), B * n, d_h.data_ptr(), st)
+        d_g2[:, 1:, :] = d_h.view(B, n, 192)
+        eng.pairing_multi_batch_dev(d_g1.data_ptr(), d_g2.data_ptr(), n + 1, B, d_out.data_ptr(), st)
+    dt = device_timed(env, run, 3)
+    one = (1).to_bytes(48, "big") + bytes(48 * 11)
+    if bytes(d_out.cpu().numpy()) != one * B:
+        raise SystemExit("verify pipeline: an aggregate did not verify -- bench invalid")
+    eng.set_mp_threshold(4096)
+    return {"value": B * n / dt, "unit": "signatures/s", "ms": dt * 1e3, "check": "every aggregate verifies (result == Fq12 one)",
+            "workload": "%d aggregate verifications x %d messages, device resident: hash to G2 + %d-pair multi-pairing each" % (B, n, n + 1)}
 
 
 def device_timed(env, fn, reps):

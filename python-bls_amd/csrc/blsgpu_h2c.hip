@@ -308,10 +308,20 @@ __device__ __forceinline__ int jacobi(uint32_t (&a)[12]) {
     for (int j = 1; j < 12; j++) rest |= n[j];
     return rest ? 0 : (sg ? -1 : 1);
 }
-template <int A, int B> __device__ __forceinline__ int chi(const r28::F<A, B>& v) {    // the quadratic character of v
+// the quadratic character of v.  Round 4: from division steps (fq32.h fq_jacobi_var, a third of the binary routine's
+// instructions even with the lanes of a wavefront waiting for the slowest); the binary routine above remains the
+// answer for a value the batches did not finish (never observed; tests/test_jacobi_model.py) and, with
+// BLSGPU_H2C_BINARY_JACOBI builds, the A/B reference.
+template <int A, int B> __device__ __forceinline__ int chi(const r28::F<A, B>& v) {
     uint32_t x[12];
     r28::to_raw(x, r28::norm(v));
+#ifdef BLSGPU_H2C_BINARY_JACOBI
     return jacobi(x);
+#else
+    int r = bls::fq_jacobi_var(x);
+    if (r == 2) r = jacobi(x);
+    return r;
+#endif
 }
 }  // namespace swl
 

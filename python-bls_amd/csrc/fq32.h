@@ -497,4 +497,76 @@ BLS_HD void fq_inv_var(uint32_t* __restrict__ r, const uint32_t* __restrict__ a)
     fq_mul(r, y, r3);
 }
 
+// ---- the quadratic character (a / q) from the same division steps (round 4) ------------------------------------------------
+// Hash to G2 decides three quadratic characters per encoding (csrc/blsgpu_h2c.hip: which candidate x has a square norm,
+// which of delta+- is a square; ec.py:489-500, fields.py:463-482).  Round 3 did it with the binary algorithm on the
+// full numbers: 768 iterations of compare / swap / subtract / halve on 12 words, ~77 k instructions.  Here the Jacobi
+// symbol rides on division steps that keep f and g NON-NEGATIVE (so that the reciprocity and the (2 / f) rules apply as
+// they stand): batches of 30 steps on the low words -- runs of zero bits of g shifted out at once (the sign flips when
+// the run is odd and f is 3 or 5 mod 8), f and g swapped when delta > 0 (flip when both are 3 mod 4), up to six low
+// bits of g cancelled by adding a multiple of f -- each applied to the full numbers as one 2x2 matrix with
+// non-negative entries.  gcd(a, q) = 1 for 0 < a < q, so f reaches 1 (38 batches on average, 42 at most over 30 000
+// random values: tests/test_jacobi_model.py holds the integer model and the histogram); the symbol is latched there.
+// The loops are data dependent: lanes of a wavefront wait for the slowest (~12 inner iterations, ~42 batches), still a
+// third of the binary routine.  A value that has not converged after BLS_JACOBI_BATCHES batches reports 2 and the caller
+// falls back to the binary routine (never observed).
+#define BLS_JACOBI_BATCHES 56
+BLS_HD int32_t jac_posdivsteps30_var(int32_t eta, uint32_t f0, uint32_t g0, inv_trans& t, uint32_t& jac) {
+    uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+    int i = 30;
+    for (;;) {
+        const uint32_t zeros = (uint32_t)__builtin_ctz(g | (0xFFFFFFFFu << i));
+        g >>= zeros; u <<= zeros; v <<= zeros;
+        eta -= (int32_t)zeros; i -= (int)zeros;
+        jac ^= zeros & ((f >> 1) ^ (f >> 2));            // (2 / f)^zeros: -1 iff zeros is odd and f is 3 or 5 mod 8
+        if (i == 0) break;
+        if (eta < 0) {                                   // (f, g) <- (g, f): reciprocity, -1 iff both are 3 mod 4
+            eta = -eta;
+            jac ^= (f & g) >> 1;
+            uint32_t tmp = f; f = g; g = tmp;
+            tmp = u; u = q; q = tmp;
+            tmp = v; v = r; r = tmp;
+        }
+        const int lim = (eta + 1) > i ? i : (eta + 1);
+        const uint32_t m = (0xFFFFFFFFu >> (32 - lim)) & 63u;
+        const uint32_t fi = inv_mad32(f, inv_mad32(f, f, 0u - 2u), 0u);          // f (f^2 - 2) = -1/f mod 2^6
+        const uint32_t w = inv_mad32(g, fi, 0u) & m;
+        g = inv_mad32(f, w, g); q = inv_mad32(u, w, q); r = inv_mad32(v, w, r);
+    }
+    t.u = (int32_t)u; t.v = (int32_t)v; t.q = (int32_t)q; t.r = (int32_t)r;
+    return eta;
+}
+// a: canonical residue (12 words).  Returns 1 / -1 (a is a non-zero square / non-square mod q), 0 (a = 0), 2 (not converged).
+BLS_HD int fq_jacobi_var(const uint32_t* __restrict__ a) {
+    const int32_t m[13] = BLS_Q30_LIMBS;
+    int32_t f[13], g[13];
+    int32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int bit = 30 * i, w = bit >> 5, s = bit & 31;
+        uint32_t lo = a[w] >> s;
+        if (s > 2 && w + 1 < 12) lo |= a[w + 1] << (32 - s);
+        g[i] = (int32_t)(lo & 0x3FFFFFFFu);
+        f[i] = m[i];
+        nz |= g[i];
+    }
+    int32_t eta = -1;
+    uint32_t jac = 0;
+    int res = nz == 0 ? 0 : 2;                           // 0: a = 0; 2: still running
+#pragma unroll 1
+    for (int it = 0; it < BLS_JACOBI_BATCHES; it++) {
+        if (res != 2) break;
+        inv_trans t;
+        // 32 low bits of f and g: 30 steps and the two bits above them that the mod-8 / mod-4 tests read
+        const uint32_t f0 = (uint32_t)f[0] | ((uint32_t)f[1] << 30), g0 = (uint32_t)g[0] | ((uint32_t)g[1] << 30);
+        eta = jac_posdivsteps30_var(eta, f0, g0, t, jac);
+        inv_update_fg(f, g, t);
+        int32_t rest = f[0] ^ 1;
+#pragma unroll
+        for (int i = 1; i < 13; i++) rest |= f[i];
+        if (rest == 0) res = (jac & 1u) ? -1 : 1;        // f = 1: the symbol is what has been collected
+    }
+    return res;
+}
+
 }  // namespace bls

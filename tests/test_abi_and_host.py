@@ -51,7 +51,8 @@ int main(){ char op[16], a[200], b[200];
     else if(!strcmp(op,"add")) { bls::fq_add_mod(x,y); pr(x);}
     else if(!strcmp(op,"sub")) { bls::fq_neg_raw(y); bls::fq_add_mod(x,y); pr(x);}
     else if(!strcmp(op,"inv")) { bls::fq_inv(r,x); uint32_t r2[12]; bls::fq_inv_var(r2,x);          // both forms of the inversion
-      if(memcmp(r,r2,48)) { printf("inv_var_differs\n"); } else pr(r);} }
+      if(memcmp(r,r2,48)) { printf("inv_var_differs\n"); } else pr(r);}
+    else if(!strcmp(op,"jac")) { printf("%d\n", bls::fq_jacobi_var(x)); } }
   return 0; }
 '''
 
@@ -79,6 +80,14 @@ def test_fq32_host_build_matches_python_ints(tmp_path):
     for a in more:
         inp.append("inv %096x %096x" % (a, 0))
         exp.append((pow(a % Q, -1, Q) * R * R) % Q if a % Q else 0)
+    # the quadratic character from division steps (fq_jacobi_var) against Euler's criterion: canonical values, corners
+    jvals = [0, 1, 2, 3, 4, Q - 1, Q - 2, (Q - 1) // 2, (Q + 1) // 2, 1 << 380] + [rnd.randrange(Q) for _ in range(4000)]
+    jvals += [rnd.randrange(1 << k) for k in (8, 64, 200, 380) for _ in range(100)]
+    ninp = len(inp)
+    for a in jvals:
+        inp.append("jac %096x %096x" % (a, 0))
     out = subprocess.run([str(exe)], input="\n".join(inp) + "\n", capture_output=True, text=True).stdout.split()
-    assert len(out) == len(exp)
-    assert [int(o, 16) for o in out] == exp
+    assert len(out) == len(exp) + len(jvals)
+    assert [int(o, 16) for o in out[:ninp]] == exp
+    euler = lambda a: {0: 0, 1: 1, Q - 1: -1}[pow(a, (Q - 1) // 2, Q)]
+    assert [int(o) for o in out[ninp:]] == [euler(a) for a in jvals]
