@@ -116,9 +116,11 @@ def pmc_traffic(kernels, pairings_per_launch):
     WRITE_SIZE, KB per dispatch, separate passes; tools/ml_pmc.sh on this same workload).  Counters cannot be read
     inside this process, so the figure is reported only when the summary's header names THIS build (source hash) and
     this launch size; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads."""
-    path = os.path.join(ROOT, "profiles", "r03_ls_pmc_summary.csv")
-    if not os.path.exists(path):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ls_pmc_summary.csv")))
+    if not cands:
         return None, None
+    path = cands[-1]                                     # the latest round's passes; used only if its header names this build
     kb, ok = {}, False
     with open(path) as f:
         for row in f:
@@ -126,12 +128,12 @@ def pmc_traffic(kernels, pairings_per_launch):
                 ok = ("build " + source_hash()) in row and ("pairs %d" % pairings_per_launch) in row
                 continue
             c = row.strip().split(",")
-            if len(c) == 4 and c[0].split("::")[-1].replace("k_ml_lines2", "k_ml_lines").replace("k_ml_horner_wide", "k_ml_horner") in kernels and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if len(c) == 4 and c[0].split("::")[-1].replace("k_ml_lines2", "k_ml_lines").replace("k_ml_horner_wide", "k_ml_horner").replace("k_ml_horner_fexp", "k_ml_horner").replace("k_ml_merge_wide", "k_ml_merge") in kernels and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
                 kb[(c[0].split("::")[-1], c[1])] = float(c[3])
     if not ok or not kb:
         return None, None
     total = sum(v * (2 if k[1] == "FETCH_SIZE" else 1) for k, v in kb.items()) * 1024
-    return int(total), "profiles/r03_ls_pmc_summary.csv"
+    return int(total), "profiles/" + os.path.basename(path)
 
 
 def cpu_model():
@@ -450,6 +452,36 @@ def run_pairing(env, args):
             lat["%d_pairs" % m] = {"latency_ms": ms, "pairings_per_s": m / (ms * 1e-3)}
             del x1, x2
 
+    # c3: what ONE rank of an 8-GPU node would do, timed here on one GPU with the very entries the sharded step uses -- the
+    # Miller loops + product of a 8192-pair shard (blsgpu_miller_product_batch_dev), the final exponentiation of the product
+    # of 8 gathered partials (blsgpu_final_exp_product_batch_dev) -- so that the first measured SCALE line can be read
+    # against a stated expectation; the all-gather of 8 x 576 bytes is a latency (assumed 0.05 ms, not measured here)
+    projection = None
+    if c3 and rank == 0 and world == 1 and not args.no_latency:
+        shard_pairs, ranks8 = args.pairs_total // 8, 8
+        x1, x2 = env.up(g1[:96 * shard_pairs]), env.up(g2[:192 * shard_pairs])
+        p8 = torch.zeros(ranks8 * 144, dtype=torch.int32, device=dev)
+        o8 = torch.zeros(576, dtype=torch.uint8, device=dev)
+        eng.reserve(shard_pairs + 3)
+        st0 = streams[0].cuda_stream
+
+        def timed(fn, reps=4):
+            best = 1e9
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(streams[0]); fn(); e1.record(streams[0]); streams[0].synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            return best
+        t_mil = timed(lambda: eng.miller_product_batch_dev(x1.data_ptr(), x2.data_ptr(), shard_pairs, 1, p8.data_ptr(), st0))
+        for r in range(1, ranks8):                       # eight copies of that partial stand in for the gathered ones
+            p8[r * 144:(r + 1) * 144] = p8[:144]
+        t_fin = timed(lambda: eng.final_exp_product_batch_dev(p8.data_ptr(), ranks8, 1, o8.data_ptr(), st0))
+        gather_ms = 0.05
+        projection = {"ranks": ranks8, "pairs_per_rank": shard_pairs, "miller_and_product_ms": t_mil, "all_gather_ms_assumed": gather_ms,
+                      "final_exp_of_8_partials_ms": t_fin, "step_ms": t_mil + gather_ms + t_fin,
+                      "pairings_per_s": args.pairs_total / ((t_mil + gather_ms + t_fin) * 1e-3),
+                      "speedup_over_this_gpu_alone": (dt / args.steps * 1e3) / (t_mil + gather_ms + t_fin)}
+        del x1, x2
     if rank == 0:
         total_pairs = sum(i["pairs"] for i in info) * args.steps
         value = total_pairs / dt
@@ -520,6 +552,8 @@ def run_pairing(env, args):
             "per_rank": [{"rank": i["rank"], "device": i["device"], "k_miller_ms_avg": i["k_miller_ms_avg"]} for i in info],
             "single_call_latency": lat,
         }
+        if projection:
+            line["projected_8_gpu_step"] = projection
         if line_stream:
             # the stage's kernels one by one; k_ml_accum also by the multiply-accumulates it EXECUTES (2 x 7 x 196
             # v_mad_i64_i32 per line product per lane, six lanes; 68 lines per pair) against the measured rate of that

@@ -2,7 +2,7 @@
 into profiles/ under round names.  ROUND=r02 python tools/collect_profiles.py"""
 import collections, csv, glob, json, os, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RN = os.environ.get("ROUND", "r02")
+RN = os.environ.get("ROUND", "r04")
 R = os.path.join(ROOT, "gpurun_out", RN)
 P = os.path.join(ROOT, "profiles")
 
@@ -33,8 +33,11 @@ for src, dst in (("bench_default.json", "_bench_line.json"), ("kt_bench.json", "
 with open(os.path.join(P, RN + "_configs_c4_c5_h2c.jsonl"), "w") as f:
     for c in ("c4", "c5", "h2c"):
         f.write(json_line(os.path.join(R, "bench_%s.json" % c)))
-if os.path.exists(os.path.join(R, "sweep_n.jsonl")):
-    shutil.copy(os.path.join(R, "sweep_n.jsonl"), os.path.join(P, RN + "_scaling_curve_single_call.jsonl"))
+for src, dst in (("sweep_n.jsonl", "_scaling_curve_single_call.jsonl"), ("fexp_latency.jsonl", "_fexp_forms_latency.jsonl"),
+                 ("fexpw_stamps.json", "_fexp_wide_cycles.json"), ("h2c_sweep.jsonl", "_h2c_sweep.jsonl"),
+                 ("pipeline_rate.json", "_verify_pipeline_rate.json")):
+    if os.path.exists(os.path.join(R, src)) and os.path.getsize(os.path.join(R, src)):
+        shutil.copy(os.path.join(R, src), os.path.join(P, RN + dst))
 
 
 def pmc_rows(dirs):

@@ -1,7 +1,7 @@
 # Runs on the GPU box (gpurun): the round's bench lines, rocprofv3 kernel stats and PMC passes.
-# ROUND=r03 bash tools/profile_round.sh ; then ROUND=r03 python tools/collect_profiles.py here copies the summaries into profiles/.
+# ROUND=r04 bash tools/profile_round.sh ; then ROUND=r04 python tools/collect_profiles.py here copies the summaries into profiles/.
 set -e
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
@@ -13,7 +13,8 @@ timeout -k 10 200 python bench.py --config c3 --steps 10 --warmup 2 --no-cpu-bas
 timeout -k 10 200 python bench.py --config c3 --gpus 2 --backend gloo --steps 8 --warmup 2 > $O/bench_c3_2rank_gloo.json 2> $O/bench_c3_2rank.err
 for c in c4 c5 h2c; do timeout -k 10 300 python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; done
 echo "config lines done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-latency > $O/kt_bench.json 2> $O/kt.err
+# the timed region ALONE under the kernel trace (no latency probes, no secondary configs): per-kernel averages of this CSV are the bench's
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-latency --no-secondary > $O/kt_bench.json 2> $O/kt.err
 for c in c4 c5 h2c; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt_$c -o kt --output-format csv -- python3 bench.py --config $c --steps 2 > $O/kt_$c.json 2> $O/kt_$c.err
 done
@@ -26,4 +27,8 @@ for c in c4 c5 h2c; do
 done
 echo "pmc done"
 timeout -k 10 200 python tools/sweep_n.py > $O/sweep_n.jsonl 2> $O/sweep_n.err || echo "sweep failed"
+timeout -k 10 200 python tools/fexp_latency.py > $O/fexp_latency.jsonl 2> $O/fexp_latency.err || echo "fexp latency failed"
+timeout -k 10 100 python tools/fexpw_stamps.py > $O/fexpw_stamps.json 2> $O/fexpw_stamps.err || echo "stamps failed"
+timeout -k 10 100 python tools/h2c_sweep.py 16384 65536 262144 > $O/h2c_sweep.jsonl 2> $O/h2c_sweep.err || echo "h2c sweep failed"
+timeout -k 10 200 python tools/pipeline_rate.py 256 > $O/pipeline_rate.json 2> $O/pipeline_rate.err || echo "pipeline failed"
 cat $O/bench_default.json
