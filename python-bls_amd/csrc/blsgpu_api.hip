@@ -1039,8 +1039,11 @@ static int grouped_pairing(blsgpu_ctx* c, const void* d_g1, const void* d_g2, co
         int rc = 0;
         if (gsz * groups <= LS_MAX_PAIRS) {
             bool fused = false;
-            rc = launch_miller_ls(c, d_g1, d_g2, d_inf, gsz, groups, c->d_part[0], st, d_out_bytes, &fused);
-            if (rc == 0 && fused) return 0;               // the stage's last kernel ran the final exponentiations too
+            // one partial per group comes out of the stage: straight into the caller's buffer when that is all it wants
+            // (the sharded entries), no copying pass of k_reduce behind it
+            uint32_t* target = (d_out_partial && !d_out_bytes) ? d_out_partial : c->d_part[0];
+            rc = launch_miller_ls(c, d_g1, d_g2, d_inf, gsz, groups, target, st, d_out_bytes, &fused);
+            if (rc == 0 && (fused || target == d_out_partial)) return 0;   // (fused: the stage's last kernel ran the final exponentiations too)
             bpg = 1;
         } else if (gsz <= LS_MAX_PAIRS) {
             const size_t per = LS_MAX_PAIRS / gsz;
