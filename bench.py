@@ -563,8 +563,9 @@ def run_pairing(env, args):
             line["roofline"]["k_ml_accum_executed_mad28_Tps"] = exec_mads / (ls_avg["k_ml_accum"] * 1e-3) / 1e12
             line["roofline"]["k_ml_accum_frac_of_mad_i64_i32_peak"] = exec_mads / (ls_avg["k_ml_accum"] * 1e-3) / 1e12 / PEAK_MAD28_T
             # the point-chain kernel likewise: v_mad_i64_i32 per wavefront and step read off the ISA of the shipped build
-            # (tangent step 5320, chord step 8847; 32 pairs per wavefront, both lanes of a pair count)
-            lines_mads = (63 * 5320 + 5 * 8847) * 2 * n * B
+            # (tangent step 4718 -- 5320 before the mixed products became squares in round 4 --, chord step 8847; 32 pairs per
+            # wavefront, both lanes of a pair count)
+            lines_mads = (63 * 4718 + 5 * 8847) * 2 * n * B
             line["roofline"]["k_ml_lines_executed_mad28_Tps"] = lines_mads / (ls_avg["k_ml_lines"] * 1e-3) / 1e12
             line["roofline"]["k_ml_lines_frac_of_mad_i64_i32_peak"] = lines_mads / (ls_avg["k_ml_lines"] * 1e-3) / 1e12 / PEAK_MAD28_T
             line["roofline"]["executed_mad28_per_pairing"] = (exec_mads + lines_mads) / (n * B)

@@ -279,22 +279,27 @@ template <int M> __device__ __forceinline__ void store_part(int32_t* __restrict_
     for (int j = 0; j < NL; j++) o[j] = x.v[j];
 }
 
-__device__ __forceinline__ void tangent_step(h& X, h& Y, h& Z, const fe& px3n, const fe& py2, int32_t* __restrict__ rec) {
+__device__ __forceinline__ void tangent_step(h& X, h& Y, h& Z, const fe& px3n, const fe& py, int32_t* __restrict__ rec) {
     // (the statements are asm volatile underneath, so this order IS the execution order: every value is consumed as
     // early as the data flow allows, which keeps the step inside 256 registers)
-    store_part(rec, 1, mulf(sqr(X), px3n));                           // X^2 (-3 px)
-    const h YZ = mul(left(Y), right(Z));
-    store_part(rec, 2, mulf(YZ, py2));                                // 2YZ py
-    const h z8 = mulc_norm<8>(YZ);
-    const h E = b3(sqr(Z));
+    // Round 4: the two mixed products as squares -- 2YZ = (Y + Z)^2 - Y^2 - Z^2 and 2XY = (X + Y)^2 - X^2 - Y^2 with the
+    // squares the step computes anyway: a complex squaring is ONE product per lane (392 multiply-adds), a product a sum
+    // of two (588); the sums are normalised first (a square of 2^29-limbs would not fit the columns).  Same field
+    // elements, same line records.
+    const h XX = sqr(X);
+    store_part(rec, 1, mulf(XX, px3n));                               // X^2 (-3 px)
+    const h C = sqr(Z);
     const h B = sqr(Y);
-    const h A = mul(left(X), right(Y));
+    const S<3> H = sub(sub(sqr(norm(add(Y, Z))), B), C);              // 2YZ
+    store_part(rec, 2, mulf(H, py));                                  // 2YZ py
+    const h z8 = mulc_norm<4>(H);                                     // 8YZ
+    const h E = b3(C);
+    const S<3> A2 = sub(sub(sqr(norm(add(X, Y))), XX), B);            // 2XY
     store_part(rec, 0, sub(B, E));
     const S<3> F3 = mulc<3>(E);
     const h BmF = norm(sub(B, F3)), G = norm(add(B, F3));
-    const h nE12 = mulc_norm<12>(neg(E));
-    X = mul(left(add(A, A)), right(BmF));
-    Y = dot2(left(G), right(G), left(nE12), right(E));
+    X = mul(left(A2), right(BmF));
+    Y = norm(sub(sqr(G), mulc_norm<12>(sqr(E))));                     // G^2 - 12 E^2 as two squares (2 x 392 against 980 for the sum of four products)
     Z = mul(left(B), right(z8));
 }
 __device__ __forceinline__ void chord_step(h& X, h& Y, h& Z, const h& xq, const h& yq, const fe& px3n, const fe& py3,
@@ -333,13 +338,13 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines2(const 
     const uint32_t part = t & 1u;
     const uint32_t* s1 = g1 + (size_t)p * 24;
     const uint32_t* s2 = g2 + (size_t)p * 48 + part * 12;
-    fe px3n, py2;
+    fe px3n, pyv;
     sp::h X, Y, Z;
     bool ok = !q_flagged(dg, p);
     {
         const fe px = load_coord(s1), py = load_coord(s1 + 12);
         px3n = r28::mulc_norm<3>(r28::neg(px));
-        py2 = r28::mulc_norm<2>(py);
+        pyv = py;
         X = sp::load_part(s2);
         Y = sp::load_part(s2 + 24);
         const int32_t one[NL] = BLS28_ONE;
@@ -358,7 +363,7 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines2(const 
     const size_t lstride = (size_t)n * LINE_DW;
 #pragma unroll 1
     for (int bit = 62; bit >= 0; bit--) {
-        sp::tangent_step(X, Y, Z, px3n, py2, rec);
+        sp::tangent_step(X, Y, Z, px3n, pyv, rec);
         rec += lstride;
         if ((ML_NX >> bit) & 1ull) {
             const sp::h xq = sp::load_part(s2), yq = sp::load_part(s2 + 24);
