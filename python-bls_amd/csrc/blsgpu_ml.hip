@@ -587,17 +587,19 @@ __device__ __forceinline__ void fetch(Xop& X, const Pub& P, const Team& t) {
     }
     const uint32_t src = t.c >= (uint32_t)J ? t.c - J : t.c + 6u - J;
     const uint32_t addr = t.base4 + src * 4u;
-    const bool wrap = t.c < (uint32_t)J;
-    int32_t a[NL], b[NL];
-    bperm14(a, P.re, addr); bperm14(b, P.xre, addr);
+    // the SOURCE chooses the form (round 4): lane s is read by lane (s + J) mod 6 alone, which wants the xi form iff it wraps,
+    // i.e. iff s + J >= 6 -- one select per limb here and ONE fetch instead of two fetches and a select at the reader
+    const bool offer_xi = t.c + (uint32_t)J >= 6u;
+    int32_t o[NL];
 #pragma unroll
-    for (int j = 0; j < NL; j++) X.re[j] = wrap ? b[j] : a[j];
-    bperm14(a, P.im, addr); bperm14(b, P.xim, addr);
+    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.xre[j] : P.re[j];
+    bperm14(X.re, o, addr);
 #pragma unroll
-    for (int j = 0; j < NL; j++) X.im[j] = wrap ? b[j] : a[j];
-    bperm14(a, P.nim, addr); bperm14(b, P.nxim, addr);
+    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.xim[j] : P.im[j];
+    bperm14(X.im, o, addr);
 #pragma unroll
-    for (int j = 0; j < NL; j++) X.nim[j] = wrap ? b[j] : a[j];
+    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.nxim[j] : P.nim[j];
+    bperm14(X.nim, o, addr);
 }
 // (re, im) = sum over three terms of F_{c - J} y_J; y given as (re, im) arrays.  Column bound of fp28_dot6 (units of
 // 2^56): an unwrapped term 1 + 1, a wrapped one 1 + 2 (|xi f| limbs below 2^29 when not normalised) -- at most
@@ -619,17 +621,17 @@ __device__ __forceinline__ void mul3(int32_t* __restrict__ re, int32_t* __restri
 __device__ __forceinline__ void fetch_rt(Xop& X, const Pub& P, const Team& t, uint32_t J) {
     const uint32_t src = t.c >= J ? t.c - J : t.c + 6u - J;
     const uint32_t addr = t.base4 + src * 4u;
-    const bool wrap = t.c < J;
-    int32_t a[NL], b[NL];
-    bperm14(a, P.re, addr); bperm14(b, P.xre, addr);
+    const bool offer_xi = t.c + J >= 6u;                  // (the source chooses the form: see fetch<J>)
+    int32_t o[NL];
 #pragma unroll
-    for (int j = 0; j < NL; j++) X.re[j] = wrap ? b[j] : a[j];
-    bperm14(a, P.im, addr); bperm14(b, P.xim, addr);
+    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.xre[j] : P.re[j];
+    bperm14(X.re, o, addr);
 #pragma unroll
-    for (int j = 0; j < NL; j++) X.im[j] = wrap ? b[j] : a[j];
-    bperm14(a, P.nim, addr); bperm14(b, P.nxim, addr);
+    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.xim[j] : P.im[j];
+    bperm14(X.im, o, addr);
 #pragma unroll
-    for (int j = 0; j < NL; j++) X.nim[j] = wrap ? b[j] : a[j];
+    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.nxim[j] : P.nim[j];
+    bperm14(X.nim, o, addr);
 }
 __device__ __forceinline__ void mul_line(int32_t* __restrict__ re, int32_t* __restrict__ im, const Pub& P, const Team& t, uint32_t jA, uint32_t jB,
                                          const int32_t* y0r, const int32_t* y0i, const int32_t* y1r, const int32_t* y1i,
