@@ -790,6 +790,12 @@ __global__ void __launch_bounds__(64, 2) k_h2c_clear_pairs(VmTables T, const uin
             acc = ld_slot(sl);
         } else if (op == 5u) {
             acc = pdbl(acc);
+        } else if (op == 7u) {                                   // a long run of doublings: through Jacobian coordinates
+            acc = to_jacobian(acc);
+        } else if (op == 8u) {
+            acc = pdblj(acc);
+        } else if (op == 9u) {
+            acc = to_homogeneous(acc);
         } else if (op == 6u) {                                   // psi: (conj X psix, conj Y psiy, conj Z)
             S<1> cx, cy, cz;
     #pragma unroll

@@ -673,6 +673,47 @@ __device__ __forceinline__ pt pdbl(const pt& P) {
     return R;
 }
 __device__ __forceinline__ pt pneg(const pt& P) { return {P.X, norm(neg(P.Y)), P.Z}; }
+// ---- Jacobian coordinates (X / Z^2, Y / Z^3) for long runs of doublings (round 4; the cofactor clearing of the hash) -----
+// 2 P for a = 0 (EFD dbl-2009-l): A = X^2, B = Y^2, C = B^2, D = 2 ((X + B)^2 - A - C), E = 3 A, X3 = E^2 - 2 D,
+// Y3 = E (D - X3) - 8 C, Z3 = 2 Y Z: five squares (one product per lane each) and two products -- 3136 multiply-adds per lane
+// against 4116 of the complete homogeneous doubling.  Exact for every point of E'(Fq2): the group order is odd (no point
+// with Y = 0 doubles to infinity), and infinity itself is carried as (1 : 1 : 0), which this map fixes.
+__device__ __forceinline__ pt pdblj(const pt& P) {
+    const h A = sqr(P.X), B = sqr(P.Y);
+    const h C = sqr(B);
+    const h D = mulc_norm<2>(sub(sub(sqr(norm(add(P.X, B))), A), C));
+    const h E = mulc_norm<3>(A);
+    pt R;
+    R.X = norm(sub(sqr(E), mulc<2>(D)));
+    R.Z = mul(left(add(P.Y, P.Y)), right(P.Z));
+    R.Y = norm(sub(mul(left(E), right(norm(sub(D, R.X)))), mulc_norm<8>(C)));
+    return R;
+}
+// homogeneous (X : Y : Z) -> Jacobian (X Z : Y Z^2 : Z); infinity (Z = 0) -> (1 : 1 : 0)
+__device__ __forceinline__ pt to_jacobian(const pt& P) {
+    const bool inf = zero2(P.Z);
+    const int32_t one[r28::NL] = BLS28_ONE;
+    const h zz = sqr(P.Z);
+    const h x = mul(left(P.X), right(P.Z)), y = mul(left(P.Y), right(zz));
+    pt R;
+#pragma unroll
+    for (int j = 0; j < r28::NL; j++) {
+        const int32_t o = odd() ? 0 : one[j];
+        R.X.v[j] = inf ? o : x.v[j];
+        R.Y.v[j] = inf ? o : y.v[j];
+        R.Z.v[j] = P.Z.v[j];
+    }
+    return R;
+}
+// Jacobian (X : Y : Z) -> homogeneous (X Z : Y : Z^3); (1 : 1 : 0) -> (0 : 1 : 0)
+__device__ __forceinline__ pt to_homogeneous(const pt& P) {
+    const h zz = sqr(P.Z);
+    pt R;
+    R.X = mul(left(P.X), right(P.Z));
+    R.Y = P.Y;
+    R.Z = mul(left(zz), right(P.Z));
+    return R;
+}
 __device__ __forceinline__ void st_vm(const pt& r, uint32_t* __restrict__ p) {     // the VM's projective form: 72 dwords
     const h* c[3] = {&r.X, &r.Y, &r.Z};
 #pragma unroll
