@@ -65,6 +65,7 @@ struct blsgpu_ctx {
     bool h2c_jacobi = true;            // ... with the quadratic characters decided by a Jacobi-symbol routine: two powers per encoding, not five
     size_t h2c_jacobi_threshold = 16384;   // ... from this many messages (below, five parallel powers finish sooner than three serial symbol loops)
     bool h2c_reg_pairs = true;         // ... on lane pairs (k_h2c_clear_pairs); false: one message per lane (k_h2c_clear_reg)
+    size_t h2c_quad_max = 20480;       // ... on lane QUADS up to this many messages (k_h2c_clear_quads: half the depth while the chip is not full)
     bool test_ls_nomem = false;        // test hook (BLSGPU_TEST_LS_NOMEM=1): the line-stream workspace "cannot be allocated"
     void* d_h2c_ws = nullptr;          // the lane-private point slots of k_h2c_clear_pairs
     size_t h2c_ws_cap = 0;
@@ -512,6 +513,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_PAIRS")) c->h2c_reg_pairs = atoi(e) != 0;
+    if (const char* e = getenv("BLSGPU_H2C_QUAD_MAX")) c->h2c_quad_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_TEST_LS_NOMEM")) c->test_ls_nomem = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_H2C_JACOBI")) c->h2c_jacobi = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_H2C_JACOBI_THRESHOLD")) c->h2c_jacobi_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -1438,6 +1440,10 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
         unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);
         hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)d_out);
+    } else if (c->h2c_reg_pairs && n <= c->h2c_quad_max) {   // a batch that leaves SIMDs empty on lane pairs: one message per lane QUAD
+        if (int rc2 = grow_buffer(c, &c->d_h2c_ws, &c->h2c_ws_cap, (4 * n + 64) * BLS28_H2C_NSLOTS * 3 * blsgpu::r28::NL * 4)) return rc2;
+        hipLaunchKernelGGL(blsgpu::k_h2c_clear_quads, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, st, c->tabs, img, (uint32_t)n,
+                           (uint32_t*)c->d_h2c_ws, (uint32_t*)d_out);
     } else if (c->h2c_reg_pairs) {         // one message per lane pair, the point operations as a script
         if (int rc2 = grow_buffer(c, &c->d_h2c_ws, &c->h2c_ws_cap, (2 * n + 64) * BLS28_H2C_NSLOTS * 3 * blsgpu::r28::NL * 4)) return rc2;
         hipLaunchKernelGGL(blsgpu::k_h2c_clear_pairs, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, c->tabs, img, (uint32_t)n,

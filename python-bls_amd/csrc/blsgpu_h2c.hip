@@ -838,6 +838,119 @@ __global__ void __launch_bounds__(64, 2) k_h2c_clear_pairs(VmTables T, const uin
 ;
 #endif
 
+// The same with ONE MESSAGE PER LANE QUAD (round 4; sp4 in blsgpu_msm.hip): the two pairs of a quad share the levels of
+// independent Fq2 products of every point operation, so the script is about half as deep -- what counts while the batch
+// leaves SIMDs empty on lane pairs (16 384 messages: 512 wavefronts for 1024 SIMDs).  Same script, same slots (written
+// lane-private like the pair kernel's), same results.
+__global__ void __launch_bounds__(64, 2) k_h2c_clear_quads(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg, uint32_t* __restrict__ ws,
+                                                           uint32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
+    using namespace sp2;                                          // (the point operations below are sp4's, named so)
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t m = min(tid >> 2, n_msg - 1u), part = tid & 1u;
+    const bool first_pair = (tid & 2u) == 0u;
+    const bool store = (tid >> 2) < n_msg && first_pair;
+    auto vmh = [&](const uint32_t* p) {                           // the lane's half of a VM value pair at p (12 words each)
+        uint32_t x[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) x[j] = p[12 * part + j];
+        const r28::fe t = r28::from_vm(x);
+        h r;
+#pragma unroll
+        for (int j = 0; j < r28::NL; j++) r.v[j] = t.v[j];
+        return r;
+    };
+    uint32_t* slots = ws + (size_t)tid * BLS28_H2C_NSLOTS * 3 * r28::NL;      // every lane its own rows (the two pairs of a quad hold the same values)
+    auto st_slot = [&](uint32_t sl, const pt& P) {
+        uint32_t* o = slots + sl * 3 * r28::NL;
+#pragma unroll
+        for (int j = 0; j < r28::NL; j++) { o[j] = (uint32_t)P.X.v[j]; o[r28::NL + j] = (uint32_t)P.Y.v[j]; o[2 * r28::NL + j] = (uint32_t)P.Z.v[j]; }
+    };
+    auto ld_slot = [&](uint32_t sl) {
+        const uint32_t* o = slots + sl * 3 * r28::NL;
+        pt P;
+#pragma unroll
+        for (int j = 0; j < r28::NL; j++) { P.X.v[j] = (int32_t)o[j]; P.Y.v[j] = (int32_t)o[r28::NL + j]; P.Z.v[j] = (int32_t)o[2 * r28::NL + j]; }
+        return P;
+    };
+    pt acc;
+    for (int sidx = 1; sidx >= 0; sidx--) {                       // S1 -> slot 0, S0 -> the accumulator
+        const uint32_t e = 2 * m + sidx;
+        const uint32_t* src = enc + ((size_t)(e / BLSVM_H1_NE) * H1_IMG + (BLSVM_H1_S - BLSVM_H1_STATE0) + 5 * (e % BLSVM_H1_NE)) * 12;
+        acc.X = vmh(src); acc.Y = vmh(src + 24);
+        uint32_t x[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) x[j] = src[48 + j];
+        const r28::fe z = r28::from_vm(x);
+#pragma unroll
+        for (int j = 0; j < r28::NL; j++) acc.Z.v[j] = part ? 0 : z.v[j];
+        if (sidx == 1) st_slot(0, acc);
+    }
+    constexpr uint32_t PSIX = BLSVM_HC_PSIX - BLSVM_HC_SLOT0 + BLSVM_HC_TBL0, PSIY = BLSVM_HC_PSIY - BLSVM_HC_SLOT0 + BLSVM_HC_TBL0;
+    const h psix = vmh(T.consts + PSIX * 12), psiy = vmh(T.consts + PSIY * 12);
+#pragma unroll 1
+    for (uint32_t pc = 0; pc < (uint32_t)BLS28_H2C_NOPS; pc++) {
+        const uint32_t op = BLS28_H2C_OPS[pc][0], sl = BLS28_H2C_OPS[pc][1];
+        if (op == 1u || op == 2u) {
+            pt Q = ld_slot(sl);
+            if (op == 2u) Q.Y = norm(neg(Q.Y));
+            acc = sp4::padd(acc, Q);
+        } else if (op == 3u) {
+            st_slot(sl, acc);
+        } else if (op == 4u) {
+            acc = ld_slot(sl);
+        } else if (op == 5u) {
+            acc = sp4::pdbl(acc);
+        } else if (op == 7u) {                                   // a long run of doublings: through Jacobian coordinates
+            acc = sp4::to_jacobian(acc);
+        } else if (op == 8u) {
+            acc = sp4::pdblj(acc);
+        } else if (op == 9u) {
+            acc = sp4::to_homogeneous(acc);
+        } else if (op == 6u) {                                   // psi: (conj X psix, conj Y psiy, conj Z): one product per pair
+            S<1> cx, cy, cz;
+#pragma unroll
+            for (int j = 0; j < r28::NL; j++) { cx.v[j] = part ? -acc.X.v[j] : acc.X.v[j]; cy.v[j] = part ? -acc.Y.v[j] : acc.Y.v[j]; cz.v[j] = part ? -acc.Z.v[j] : acc.Z.v[j]; }
+            const h pm = mul(left(sp4::pick(cx, cy)), right(sp4::pick(psix, psiy))), po = sp4::oth(pm);
+            acc.X = sp4::pick(pm, po);
+            acc.Y = sp4::pick(po, pm);
+            acc.Z = norm(cz);
+        } else {
+            break;
+        }
+    }
+    // affine: (X, Y) / Z with 1 / Z = conj(Z) / N(Z); Z = 0 gives (0, 0).  safegcd inversion of fq32.h on the VM's form of the norm.
+    const h zp = swp(acc.Z);
+    r28::fe n;
+    bls28::fp28_dot2(n.v, acc.Z.v, acc.Z.v, zp.v, zp.v);
+    uint32_t nv[12], niv[12];
+    r28::to_vm(nv, n);
+    bls::fq_inv(niv, nv);
+    const r28::fe ninv = r28::from_vm(niv);
+    S<1> zc;
+#pragma unroll
+    for (int j = 0; j < r28::NL; j++) zc.v[j] = part ? -acc.Z.v[j] : acc.Z.v[j];
+    const h zi = mulf(zc, ninv);
+    const Rop<1> rzi = right(zi);
+    const h xa = mul(left(acc.X), rzi), ya = mul(left(acc.Y), rzi);
+    if (store) {
+        const h* o[2] = {&xa, &ya};
+        for (int k = 0; k < 2; k++) {
+            r28::fe t;
+    #pragma unroll
+        for (int j = 0; j < r28::NL; j++) t.v[j] = o[k]->v[j];
+            uint32_t y[12];
+            r28::to_raw(y, t);
+#pragma unroll
+            for (int w = 0; w < 12; w++) out[(size_t)m * 48 + (2 * k + part) * 12 + w] = bswap32(y[11 - w]);
+        }
+    }
+}
+#else
+;
+#endif
+
 // ---------------------------------------------------------------------------
 // Point decompression: PublicKey.from_bytes (keys.py:28-40, DEG 1)
 // and Signature.from_bytes (signature.py:21-38, DEG 2) for a batch.  in: n x 48*DEG

@@ -730,6 +730,122 @@ __device__ __forceinline__ void st_vm(const pt& r, uint32_t* __restrict__ p) {  
 }
 }  // namespace sp2
 
+// ---- the same curve arithmetic on LANE QUADS (round 4): one point per four lanes ----------------------------------------
+// A batch of a few thousand points leaves most SIMDs empty on lane pairs (16 384 messages of the hash = 512 wavefronts) and
+// what the call waits for is the length of one wavefront's instruction stream.  Here the two lane PAIRS of a quad hold
+// the same point (each lane its real or imaginary halves, as in sp2) and every level of independent Fq2 products of a
+// formula is dealt out over them -- both pairs execute the same instructions on operands picked by the pair index, then
+// swap results (DPP quad_perm [2,3,0,1]) -- so a formula is about half as deep: Jacobian doubling 3 squares + 1 product
+// deep instead of 5 + 2, complete addition 6 products instead of 12.  Throughput-wise it is the same work plus the
+// swaps, so it is used only while the batch does not fill the chip on pairs (blsgpu_api.hip h2c_quad_max).
+namespace sp4 {
+using namespace sp2;
+__device__ __forceinline__ bool hi() { return (threadIdx.x & 2u) != 0; }               // the second pair of the quad
+template <int M> __device__ __forceinline__ S<M> oth(const S<M>& x) {                    // the other pair's value
+    S<M> r;
+#pragma unroll
+    for (int j = 0; j < r28::NL; j++) r.v[j] = __builtin_amdgcn_update_dpp(0, x.v[j], 0x4E, 0xF, 0xF, true);
+    return r;
+}
+template <int M> __device__ __forceinline__ S<M> pick(const S<M>& a, const S<M>& b) {    // pair 0: a, pair 1: b
+    S<M> r;
+#pragma unroll
+    for (int j = 0; j < r28::NL; j++) r.v[j] = hi() ? b.v[j] : a.v[j];
+    return r;
+}
+template <int M> __device__ __forceinline__ S<2> wide(const S<M>& x) {                   // the same limbs under the looser bound
+    static_assert(M <= 2, "");
+    S<2> r;
+#pragma unroll
+    for (int j = 0; j < r28::NL; j++) r.v[j] = x.v[j];
+    return r;
+}
+// 2 P, Jacobian, a = 0 (sp2::pdblj): levels {A = X^2 | B = Y^2}, {C = B^2 | (X + B)^2}, {E^2}, {E (D - X3) | 2Y Z}
+__device__ __forceinline__ pt pdblj(const pt& P) {
+    const h r1 = sqr(pick(P.X, P.Y)), o1 = oth(r1);
+    const h A = pick(r1, o1), B = pick(o1, r1);
+    const h r2 = sqr(pick(B, norm(add(P.X, B)))), o2 = oth(r2);
+    const h C = pick(r2, o2), T = pick(o2, r2);
+    const h D = mulc_norm<2>(sub(sub(T, A), C));
+    const h E = mulc_norm<3>(A);
+    pt R;
+    R.X = norm(sub(sqr(E), mulc<2>(D)));
+    const h r4 = mul(left(pick(wide(E), add(P.Y, P.Y))), right(pick(norm(sub(D, R.X)), P.Z))), o4 = oth(r4);
+    R.Z = pick(o4, r4);
+    R.Y = norm(sub(pick(r4, o4), mulc_norm<8>(C)));
+    return R;
+}
+// 2 P, complete homogeneous (sp2::pdbl, RCB algorithm 9): levels {Y^2, Y Z | Z^2, X Y}, {d 2XY, YZ 8Y^2 | 3b'Z^2 8Y^2, d (Y^2 + 3b'Z^2)}
+__device__ __forceinline__ pt pdbl(const pt& P) {
+    const h s1 = sqr(pick(P.Y, P.Z)), m1 = mul(left(pick(P.Y, P.X)), right(pick(P.Z, P.Y)));
+    const h os = oth(s1), om = oth(m1);
+    const h t0 = pick(s1, os), t1 = pick(m1, om), t2 = b3(pick(os, s1)), txy = pick(om, m1);
+    const h z8 = mulc_norm<8>(t0);
+    const h d = norm(sub(t0, mulc<3>(t2)));
+    const h ma = mul(left(pick(wide(d), wide(t2))), right(pick(norm(add(txy, txy)), z8)));
+    const h mb = mul(left(pick(wide(t1), wide(d))), right(pick(z8, norm(add(t0, t2)))));
+    const h oa = oth(ma), ob = oth(mb);
+    pt R;
+    R.X = pick(ma, oa);
+    R.Z = pick(mb, ob);
+    R.Y = norm(add(pick(oa, ma), pick(ob, mb)));
+    return R;
+}
+// P + Q, complete homogeneous (sp2::padd, RCB algorithm 7): levels {X1X2, Y1Y2, Z1Z2 | the three products of sums},
+// {t3 t1m, t1m z3, z3 t4 | (-t4) y3, y3 x3, x3 t3}
+__device__ __forceinline__ pt padd(const pt& P, const pt& Q) {
+    const S<2> l0 = pick(wide(P.X), add(P.X, P.Y)), l1 = pick(wide(P.Y), add(P.Y, P.Z)), l2 = pick(wide(P.Z), add(P.X, P.Z));
+    const S<2> q0 = pick(wide(Q.X), add(Q.X, Q.Y)), q1 = pick(wide(Q.Y), add(Q.Y, Q.Z)), q2 = pick(wide(Q.Z), add(Q.X, Q.Z));
+    const h a0 = mul(left(l0), right(q0)), a1 = mul(left(l1), right(q1)), a2 = mul(left(l2), right(q2));
+    const h b0 = oth(a0), b1 = oth(a1), b2 = oth(a2);
+    const h t0 = pick(a0, b0), t1 = pick(a1, b1), t2 = pick(a2, b2);
+    const h u3 = pick(b0, a0), u4 = pick(b1, a1), u5 = pick(b2, a2);
+    const h t3 = norm(sub(sub(u3, t0), t1));
+    const h t4 = norm(sub(sub(u4, t1), t2));
+    const S<3> t5 = sub(sub(u5, t0), t2);
+    const h x3 = mulc_norm<3>(t0);
+    const h bz = b3(t2);
+    const h z3 = norm(add(t1, bz)), t1m = norm(sub(t1, bz));
+    const h y3 = b3(t5);
+    const h nt4 = norm(neg(t4));
+    const h c0 = mul(left(pick(t3, nt4)), right(pick(t1m, y3)));
+    const h c1 = mul(left(pick(t1m, y3)), right(pick(z3, x3)));
+    const h c2 = mul(left(pick(z3, x3)), right(pick(t4, t3)));
+    pt R;
+    R.X = norm(add(c0, oth(c0)));
+    R.Y = norm(add(c1, oth(c1)));
+    R.Z = norm(add(c2, oth(c2)));
+    return R;
+}
+// homogeneous -> Jacobian (sp2::to_jacobian): {Z^2}, {X Z | Y Z^2}
+__device__ __forceinline__ pt to_jacobian(const pt& P) {
+    const bool inf = zero2(P.Z);
+    const int32_t one[r28::NL] = BLS28_ONE;
+    const h zz = sqr(P.Z);
+    const h m = mul(left(pick(P.X, P.Y)), right(pick(P.Z, zz))), o = oth(m);
+    const h x = pick(m, o), y = pick(o, m);
+    pt R;
+#pragma unroll
+    for (int j = 0; j < r28::NL; j++) {
+        const int32_t u = odd() ? 0 : one[j];
+        R.X.v[j] = inf ? u : x.v[j];
+        R.Y.v[j] = inf ? u : y.v[j];
+        R.Z.v[j] = P.Z.v[j];
+    }
+    return R;
+}
+// Jacobian -> homogeneous (sp2::to_homogeneous): {Z^2}, {X Z | Z^2 Z}
+__device__ __forceinline__ pt to_homogeneous(const pt& P) {
+    const h zz = sqr(P.Z);
+    const h m = mul(left(pick(P.X, zz)), right(P.Z)), o = oth(m);
+    pt R;
+    R.X = pick(m, o);
+    R.Y = P.Y;
+    R.Z = pick(o, m);
+    return R;
+}
+}  // namespace sp4
+
 #ifndef BLSGPU_MSM_LANE2X_WAVES
 #define BLSGPU_MSM_LANE2X_WAVES 2
 #endif
