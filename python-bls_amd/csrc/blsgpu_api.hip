@@ -78,7 +78,7 @@ struct blsgpu_ctx {
     uint32_t* d_msm_part = nullptr;    // MSM partials
     // line-stream multi-pairing (blsgpu_ml.hip): used from ls_threshold pairs per call when every group has at least
     // ls_min_group pairs
-    size_t ls_threshold = 16384;       // measured crossover (tools/sweep_n.py): 12 288 pairs 3.9 vs 4.3 ms, 16 384 pairs 4.95 vs 4.5 ms
+    size_t ls_threshold = 5120;        // measured crossover (tools/ls_crossover.py, round 4 with the point chains on lane quads): 4096 pairs 1.97 (VM) vs 2.04 ms, 6144 pairs 2.40 vs 2.14 ms; 16 384 in round 3
     size_t ls_min_group = 64;
     size_t ls_teams = 163840;          // accumulators k_ml_accum aims at (10 per wavefront: 8 wavefronts per place at two per SIMD)
     void* d_lines = nullptr;           // 68 x pairs line records
@@ -90,6 +90,7 @@ struct blsgpu_ctx {
     bool vm_exact_lanes = true;        // degenerate blocks of the VM kernels through the lane kernels (k_ml_lines_exact / k_ml_small) instead of k_miller_slow
     int ls_horner_form = 3;            // 3: one group per wavefront, a product PER LANE (blsgpu_fexpw.hip; merges of few outputs likewise); 2: a product spread over 36 lanes; 1: ten groups per wavefront
     size_t ls_merge_wide_max = 16384;  // merge levels with at most this many outputs run one wavefront per output
+    size_t ls_quad_max = 20480;        // calls of at most this many pairs run the point chains on lane QUADS (k_ml_lines4: 0.6 of the depth while lane pairs leave SIMDs empty)
     int ls_lines_form = 2;             // 2: the point chains on lane pairs (k_ml_lines2); 1: one pair per lane (k_ml_lines)
     size_t fexp_team_threshold = 5120; // results per call from which the final exponentiations run six lanes each (blsgpu_fexp.hip); below: one result per wavefront (measured crossover, tools/fexp_latency.py)
     bool fexp_wide = true;             // fewer results than that: one result per wavefront, a product per lane (blsgpu_fexpw.hip); false: the VM program
@@ -509,6 +510,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_LS_LINES_FORM")) c->ls_lines_form = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("BLSGPU_LS_HORNER_FORM")) c->ls_horner_form = atoi(e) == 1 ? 1 : (atoi(e) == 2 ? 2 : 3);
     if (const char* e = getenv("BLSGPU_LS_MERGE_WIDE_MAX")) c->ls_merge_wide_max = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_LS_QUAD_MAX")) c->ls_quad_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -947,6 +949,9 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
         if (c->ls_lines_form == 1)
             hipLaunchKernelGGL(ml::k_ml_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1, (const uint32_t*)d_g2,
                                (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
+        else if (n <= c->ls_quad_max)                         // few pairs: four lanes each, the tangent step's levels shared by the two pairs
+            hipLaunchKernelGGL(ml::k_ml_lines4, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1,
+                               (const uint32_t*)d_g2, (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
         else
             hipLaunchKernelGGL(ml::k_ml_lines2, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1,
                                (const uint32_t*)d_g2, (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);

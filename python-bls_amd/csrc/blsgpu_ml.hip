@@ -324,6 +324,64 @@ __device__ __forceinline__ void chord_step(h& X, h& Y, h& Z, const h& xq, const 
 }
 }  // namespace sp
 
+// ---- lane QUADS: both lane pairs of a quad hold the same Fq2 values and share a level of independent products ------------
+// (round 4; also the G2 point operations of blsgpu_msm.hip sp4).  Both pairs execute the same instructions on operands
+// picked by the pair index and swap results with DPP quad_perm [2,3,0,1].
+namespace sq {
+using namespace sp;
+__device__ __forceinline__ bool hi() { return (threadIdx.x & 2u) != 0; }               // the second pair of the quad
+template <int M> __device__ __forceinline__ S<M> oth(const S<M>& x) {                    // the other pair's value
+    S<M> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = __builtin_amdgcn_update_dpp(0, x.v[j], 0x4E, 0xF, 0xF, true);
+    return r;
+}
+template <int M> __device__ __forceinline__ S<M> pick(const S<M>& a, const S<M>& b) {    // pair 0: a, pair 1: b
+    S<M> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = hi() ? b.v[j] : a.v[j];
+    return r;
+}
+template <int W, int M> __device__ __forceinline__ S<W> widen(const S<M>& x) {           // the same limbs under a looser bound
+    static_assert(M <= W, "");
+    S<W> r;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = x.v[j];
+    return r;
+}
+// The tangent step of sp::tangent_step dealt out over the two pairs: level 1 the five squares (X^2, Y^2, (X + Y)^2 | Z^2,
+// (Y + Z)^2), level 2 {2XY (B - F), G^2, X^2 (-3 px) | B 8YZ, E^2, 2YZ py}: 3 squares + product + square + product by an Fq
+// value deep (2548 multiply-adds per lane) instead of 4718.  Pair 0 stores the line's coefficients 0 and 1, pair 1 the third.
+__device__ __forceinline__ void tangent_step(h& X, h& Y, h& Z, const fe& px3n, const fe& py, int32_t* __restrict__ rec) {
+    const h sa = sqr(pick(X, Z)), sb = sqr(pick(Y, norm(add(Y, Z)))), sc = sqr(norm(add(X, Y)));
+    const h oa = oth(sa), ob = oth(sb);
+    const h XX = pick(sa, oa), C = pick(oa, sa), B = pick(sb, ob), T1 = pick(ob, sb);
+    const h& T2 = sc;                                                 // (both pairs computed it)
+    const S<3> H = sub(sub(T1, B), C);                                // 2YZ
+    const h z8 = mulc_norm<4>(H);
+    const h E = b3(C);
+    const S<3> A2 = sub(sub(T2, XX), B);                              // 2XY
+    if (!hi()) store_part(rec, 0, sub(B, E));
+    const S<3> F3 = mulc<3>(E);
+    const h BmF = norm(sub(B, F3)), G = norm(add(B, F3));
+    fe kf;
+#pragma unroll
+    for (int j = 0; j < NL; j++) kf.v[j] = hi() ? py.v[j] : px3n.v[j];
+    const h lc = mulf(pick(widen<3>(XX), H), kf);                      // X^2 (-3 px) | 2YZ py
+    {
+        int32_t* o = rec + ((hi() ? 2 : 1) * 2 + (odd() ? 1 : 0)) * NL;
+#pragma unroll
+        for (int j = 0; j < NL; j++) o[j] = lc.v[j];
+    }
+    const h m = mul(left(pick(A2, widen<3>(B))), right(pick(BmF, z8)));   // X' | Z'
+    const h q = sqr(pick(G, E));                                       // G^2 | E^2
+    const h om = oth(m), oq = oth(q);
+    X = pick(m, om);
+    Z = pick(om, m);
+    Y = norm(sub(pick(q, oq), mulc_norm<12>(pick(oq, q))));            // G^2 - 12 E^2
+}
+}  // namespace sq
+
 // Two lanes per pair (lane 2p: real parts, lane 2p + 1: imaginary parts).  Same lines, flags and work list as k_ml_lines.
 #ifndef BLSGPU_ML_LINES2_WAVES
 #define BLSGPU_ML_LINES2_WAVES 2
@@ -374,6 +432,66 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines2(const 
     }
     ok = ok && !sp::is_zero2(Z);
     if (part == 0 && pr < n) {
+        bad[p] = ok ? 0 : 1;
+        if (!ok) {
+            const uint32_t at = atomicAdd(dg.count, 1u);
+            dg.blocks[at] = p;
+        }
+    }
+}
+#else
+;
+#endif
+
+// Four lanes per pair (round 4): for calls that leave SIMDs empty on lane pairs -- 8192 pairs are 256 wavefronts there, each
+// with the whole chain of 68 steps to itself (1.12 ms whatever the count) -- the two pairs of a quad share the tangent
+// step's levels (sq::tangent_step): about 0.6 of the depth.  Same records, flags and work list.
+__global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines4(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
+                                                                           int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t pr = t >> 2;
+    const uint32_t p = pr < n ? pr : n - 1u;                      // the last wavefront's spare lanes repeat the last pair
+    const uint32_t part = t & 1u;
+    const uint32_t* s1 = g1 + (size_t)p * 24;
+    const uint32_t* s2 = g2 + (size_t)p * 48 + part * 12;
+    fe px3n, pyv;
+    sp::h X, Y, Z;
+    bool ok = !q_flagged(dg, p);
+    {
+        const fe px = load_coord(s1), py = load_coord(s1 + 12);
+        px3n = r28::mulc_norm<3>(r28::neg(px));
+        pyv = py;
+        X = sp::load_part(s2);
+        Y = sp::load_part(s2 + 24);
+        const int32_t one[NL] = BLS28_ONE;
+#pragma unroll
+        for (int j = 0; j < NL; j++) Z.v[j] = part ? 0 : one[j];
+        // Q on the twist: y^2 - x^3 - 4 (1 + u) = 0
+        const sp::h yy = sp::sqr(Y), xx = sp::sqr(X);
+        const sp::h xxx = sp::mul(sp::left(xx), sp::right(X));
+        sp::S<4> four;
+#pragma unroll
+        for (int j = 0; j < NL; j++) four.v[j] = 4 * one[j];
+        const auto d = sp::sub(sp::sub(yy, xxx), four);              // S<6>
+        ok = ok && sp::is_zero2(sp::mulf(d, r28::fe_one()));
+    }
+    int32_t* rec = lines + (size_t)p * LINE_DW;
+    const size_t lstride = (size_t)n * LINE_DW;
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; bit--) {
+        sq::tangent_step(X, Y, Z, px3n, pyv, rec);
+        rec += lstride;
+        if ((ML_NX >> bit) & 1ull) {
+            const sp::h xq = sp::load_part(s2), yq = sp::load_part(s2 + 24);
+            const fe py3 = r28::mulc_norm<3>(load_coord(s1 + 12));
+            sp::chord_step(X, Y, Z, xq, yq, px3n, py3, rec);      // (five of 68 steps: both pairs run it whole and store the same record)
+            rec += lstride;
+        }
+    }
+    ok = ok && !sp::is_zero2(Z);
+    if ((t & 3u) == 0u && pr < n) {
         bad[p] = ok ? 0 : 1;
         if (!ok) {
             const uint32_t at = atomicAdd(dg.count, 1u);

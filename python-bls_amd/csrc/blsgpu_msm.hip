@@ -740,26 +740,10 @@ __device__ __forceinline__ void st_vm(const pt& r, uint32_t* __restrict__ p) {  
 // swaps, so it is used only while the batch does not fill the chip on pairs (blsgpu_api.hip h2c_quad_max).
 namespace sp4 {
 using namespace sp2;
-__device__ __forceinline__ bool hi() { return (threadIdx.x & 2u) != 0; }               // the second pair of the quad
-template <int M> __device__ __forceinline__ S<M> oth(const S<M>& x) {                    // the other pair's value
-    S<M> r;
-#pragma unroll
-    for (int j = 0; j < r28::NL; j++) r.v[j] = __builtin_amdgcn_update_dpp(0, x.v[j], 0x4E, 0xF, 0xF, true);
-    return r;
-}
-template <int M> __device__ __forceinline__ S<M> pick(const S<M>& a, const S<M>& b) {    // pair 0: a, pair 1: b
-    S<M> r;
-#pragma unroll
-    for (int j = 0; j < r28::NL; j++) r.v[j] = hi() ? b.v[j] : a.v[j];
-    return r;
-}
-template <int M> __device__ __forceinline__ S<2> wide(const S<M>& x) {                   // the same limbs under the looser bound
-    static_assert(M <= 2, "");
-    S<2> r;
-#pragma unroll
-    for (int j = 0; j < r28::NL; j++) r.v[j] = x.v[j];
-    return r;
-}
+using ml::sq::hi;
+using ml::sq::oth;
+using ml::sq::pick;
+template <int M> __device__ __forceinline__ S<2> wide(const S<M>& x) { return ml::sq::widen<2>(x); }
 // 2 P, Jacobian, a = 0 (sp2::pdblj): levels {A = X^2 | B = Y^2}, {C = B^2 | (X + B)^2}, {E^2}, {E (D - X3) | 2Y Z}
 __device__ __forceinline__ pt pdblj(const pt& P) {
     const h r1 = sqr(pick(P.X, P.Y)), o1 = oth(r1);
