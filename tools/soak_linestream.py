@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity soak of the round-3 register kernels (GPU box): the line-stream multi-pairing forced for every size
-(k_ml_lines2 -> k_ml_lines_exact -> k_ml_accum -> k_ml_merge -> k_ml_horner_wide), the small-group form (k_ml_small)
-and the batched final exponentiation (k_fexp_team), on random subsets of the seeded pairs with the degenerate inputs of
+(k_ml_lines2 / k_ml_lines4 -> k_ml_lines_exact -> k_ml_accum -> k_ml_merge / k_ml_merge_wide -> k_ml_horner_fexp), the small-group form
+(k_ml_small) and the final exponentiation six lanes per result (k_fexp_team) or one per wavefront (k_fexp_wide, fused
+with the Horner kernel where the call ends in it), on random subsets of the seeded pairs with the degenerate inputs of
 tools/soak_parity.py sprinkled in (zero coordinates, off-twist points, low-order points, flags), random chunking, every
 result against the CPU oracle.  usage: python tools/soak_linestream.py [trials]"""
 import json
