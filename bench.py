@@ -716,8 +716,39 @@ def run_c4(env, args):
     dt_v = device_timed(env, lambda: eng.pairing_multi_batch_dev(v1.data_ptr(), v2.data_ptr(), 2, groups, vout.data_ptr(), 0), reps)
     one = (1).to_bytes(48, "big") + bytes(48 * 11)
     ok_v = bytes(vout.cpu().numpy()) == one * groups
-    dt = env.max_over_ranks(dt_c + dt_v)
-    oks = env.gather_objects(ok_c and ok_v)
+    # The timed step: combine -> the combined signatures into the verifies' G2 operands (on the device) -> verify, with
+    # --streams steps in flight on contexts of their own (the Horner / small-group Miller / final-exponentiation kernels
+    # of 10 000 groups leave SIMDs empty; the next step's bucket sums fill them).  combine_s / verify_s above: each alone.
+    S = max(1, args.streams)
+    engs = [eng] + [_native.Engine(env.local_dev) for _ in range(S - 1)]
+    streams = [torch.cuda.Stream(device=env.dev) for _ in range(S)]
+    touts = [torch.zeros(groups * 192, dtype=torch.uint8, device=env.dev) for _ in range(S)]
+    tinfs = [torch.zeros(groups, dtype=torch.uint8, device=env.dev) for _ in range(S)]
+    v2s = [v2.clone() for _ in range(S)]
+    vouts = [torch.zeros(groups * 576, dtype=torch.uint8, device=env.dev) for _ in range(S)]
+    for j in range(S):
+        v2s[j].view(groups, 2, 192)[:, 0, :].zero_()
+
+    def step(i):
+        j = i % S
+        e, st = engs[j], streams[j]
+        e._check(e.lib.blsgpu_g2_msm_dev(e.h, tp.data_ptr(), ts.data_ptr(), k, groups, touts[j].data_ptr(), tinfs[j].data_ptr(), st.cuda_stream), "g2_msm_dev")
+        with torch.cuda.stream(st):
+            v2s[j].view(groups, 2, 192)[:, 0, :].copy_(touts[j].view(groups, 192))
+        e.pairing_multi_batch_dev(v1.data_ptr(), v2s[j].data_ptr(), 2, groups, vouts[j].data_ptr(), st.cuda_stream)
+    for i in range(S):
+        step(i)
+    torch.cuda.synchronize()
+    env.barrier()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        step(i)
+    torch.cuda.synchronize()
+    env.barrier()
+    dt_step = (time.perf_counter() - t0) / reps
+    ok_p = all(bytes(vo.cpu().numpy()) == one * groups for vo in vouts) and all(bytes(t.cpu().numpy()) == want for t in touts)
+    dt = env.max_over_ranks(dt_step)
+    oks = env.gather_objects(ok_c and ok_v and ok_p)
     if env.rank == 0:
         if not all(oks):
             raise SystemExit("result mismatch -- bench invalid")
@@ -731,11 +762,13 @@ def run_c4(env, args):
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: %d groups per GPU, G2 multi-scalar combine of 67 shares + 2-pair verify; "
                                    "bucket method with signed 4-bit digits, one (group, window) per lane PAIR (Fq2 split over two lanes), 8 buckets in HBM, complete mixed additions; verifies: point chains on lane pairs + one accumulator per group (k_ml_lines2, k_ml_small)" % groups, "name": "c4",
-                       "check": "combine == c_g x reference golden, every verify == 1"},
-            "combine_s": dt_c, "verify_s": dt_v,
+                       "steps_in_flight": S, "check": "combine == c_g x reference golden, every verify == 1 (alone and in the timed steps)"},
+            "combine_s": dt_c, "verify_s": dt_v, "one_step_alone_ms": (dt_c + dt_v) * 1e3,
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_msm_lane2x (+ k_lane_prep, windows, horner)", "peak": PEAK_TMACS, "unit": "TMAC/s",
                          "achieved": mac_combine * groups / dt_c / 1e12, "frac": mac_combine * groups / dt_c / 1e12 / PEAK_TMACS,
                          "verify_achieved": mac_verify * groups / dt_v / 1e12, "traffic": None,
+                         "whole_step_TMACs": (mac_combine + mac_verify) * groups / dt / 1e12,
+                         "whole_step_frac": (mac_combine + mac_verify) * groups / dt / 1e12 / PEAK_TMACS,
                          "algorithmic_bytes": groups * k * (192 + 32)}}
     return None
 
@@ -781,16 +814,41 @@ def run_c5(env, args):
             gath.copy_(torch.cat(host).to(env.dev))
         shard.msm_finish_dev(1, gath, env.world, tout, tinf)
     one()
+    torch.cuda.synchronize()
     env.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
         one()
+    torch.cuda.synchronize()
     env.barrier()
-    dtm = env.max_over_ranks((time.perf_counter() - t0) / reps)
+    dt_alone = (time.perf_counter() - t0) / reps
+    # the timed steps: --streams sums in flight on contexts of their own (one GPU: the bit sums / Horner of one sum, a few
+    # hundred wavefronts, run beside the next sum's list additions); with a process group the steps stay one after another
+    S = max(1, args.streams) if env.dist is None else 1
+    dt_step, ok_p = dt_alone, True
+    if S > 1:
+        shards = [shard] + [GpuShardBackend(_native.Engine(env.local_dev), env.dev) for _ in range(S - 1)]
+        streams = [torch.cuda.Stream(device=env.dev) for _ in range(S)]
+        outs = [torch.zeros(96, dtype=torch.uint8, device=env.dev) for _ in range(S)]
+        infs = [torch.zeros(4, dtype=torch.uint8, device=env.dev) for _ in range(S)]
+
+        def step(i):
+            with torch.cuda.stream(streams[i % S]):
+                shards[i % S]._msm_dev(1, tp, ts, n, 1, outs[i % S], infs[i % S])
+        for i in range(S):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            step(i)
+        torch.cuda.synchronize()
+        dt_step = (time.perf_counter() - t0) / reps
+        ok_p = all(bytes(o.cpu().numpy()) == bytes(tout.cpu().numpy()) for o in outs)
+    dtm = env.max_over_ranks(dt_step)
     got = bytes(tout.cpu().numpy())
     parts = env.gather_objects(sum(x * y for x, y in zip(a, t)) % N_ORDER)       # sum t_i (a_i G) = (sum t_i a_i) G
     want, _ = eng.g1_msm(gen1, [sum(parts) % N_ORDER], 1, 1)
-    oks = env.gather_objects(got == want)
+    oks = env.gather_objects(got == want and ok_p)
     if env.rank == 0:
         if not all(oks):
             raise SystemExit("result mismatch -- bench invalid")
@@ -807,7 +865,8 @@ def run_c5(env, args):
                                    "13-bit windows, counting sort of the (window, digit) keys, equal pieces of the sorted list per lane "
                                    "(complete mixed additions on 28-bit limbs in registers), bit sums of the buckets, Horner (DESIGN.md 2d)" % (total, n),
                        "name": "c5", "parallelism": "points split %d ways + all-gather of 100 B per rank" % env.world,
-                       "check": "sum t_i (a_i G) == (sum t_i a_i) G"},
+                       "steps_in_flight": S, "check": "sum t_i (a_i G) == (sum t_i a_i) G"},
+            "one_step_alone_ms": dt_alone * 1e3,
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_srt_accum (+ k_lane_prep, k_srt_count/scan/scatter/fix/bits, fold, windows, horner)",
                          "peak": PEAK_TMACS, "unit": "TMAC/s", "achieved": mac / dtm / 1e12 / env.world, "frac": mac / dtm / 1e12 / PEAK_TMACS / env.world,
                          "traffic": None,

@@ -71,6 +71,8 @@ struct blsgpu_ctx {
     size_t h2c_ws_cap = 0;
     size_t msm_sort_threshold = 16384;  // points from which one G1 sum with scalars uses sorted buckets (k_srt_*)
     size_t horner_np_threshold = 1024; // G2 sums per call from which the window Horner runs several sums per team
+    size_t horner_quads_threshold = 2; // G2 sums per call (lane-pair bucket kernel) from which the window Horner runs one sum per lane quad
+    size_t wg256_max_waves = 4096;     // register kernels: launches of up to this many wavefronts go out as 256-thread workgroups (blsgpu_tu.h)
     size_t msm_lane_threshold = 65536; // points from which the bucket sums run one (group, chunk, window) per lane
     bool msm_lane_pairs = true;        // G2: every (group, chunk, window) on a lane PAIR (k_msm_lane2x) instead of one lane
     uint32_t* d_buckets = nullptr;     // their buckets (HBM)
@@ -151,6 +153,13 @@ static bool use_mp(const blsgpu_ctx* c, size_t n) { return n >= c->mp_threshold;
 static bool use_mp2(const blsgpu_ctx* c, size_t n) {
     if (c->mp3_threshold != (size_t)-1) return n < c->mp3_threshold;
     return n <= 8704 || (n > 9728 && n <= 11264) || (n > 14336 && n <= 18432);
+}
+// Grid and workgroup size for `waves` independent wavefronts of a register kernel (blsgpu_tu.h: wave_index()): four
+// wavefronts per workgroup -- one per SIMD of a CU -- while the launch does not fill the chip several times over.
+struct WaveShape { unsigned blocks, threads; };
+static WaveShape wave_shape(const blsgpu_ctx* c, size_t waves) {
+    const unsigned per = (waves <= c->wg256_max_waves) ? 4u : 1u;
+    return {(unsigned)((waves + per - 1) / per), per * 64u};
 }
 // grow-only (see blsgpu_ctx::retired): *p gets at least `bytes`; contents are scratch, not copied
 static int grow_buffer(blsgpu_ctx* c, void** p, size_t* cap_bytes, size_t bytes) {
@@ -382,15 +391,24 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
             const size_t lanes = groups * chunks * blsgpu::PIP_W;
             const size_t bneed = lanes * (blsgpu::PIP_NB - 1) * PJ28 + fold_n * groups * blsgpu::PIP_W * 36 * DEG;
             if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, bneed)) return rc_;
+            // a batch of G2 sums (one chunk each): the window sums stay in the L28 form and the Horner runs one sum per lane quad
+            const bool horner_quads = DEG == 2 && c->msm_lane_pairs && chunks == 1 && groups >= c->horner_quads_threshold;
             if (DEG == 2 && c->msm_lane_pairs)
                 hipLaunchKernelGGL(blsgpu::k_msm_lane2x, dim3((unsigned)((2 * lanes + 63) / 64)), dim3(64), 0, st, d_prep, d_live,
                                    (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, (uint32_t)chunks, (uint32_t)lanes, c->d_buckets,
-                                   c->d_msm_part, fold_n ? 0u : 1u);
+                                   c->d_msm_part, (fold_n || horner_quads) ? 0u : 1u);
             else
                 hipLaunchKernelGGL(blsgpu::k_msm_lane<DEG>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, d_prep, d_live,
                                    (const uint32_t*)d_scalars, (uint32_t)k, (uint32_t)chunk, (uint32_t)chunks, (uint32_t)lanes, c->d_buckets,
                                    c->d_msm_part, fold_n ? 0u : 1u);
             HIP_TRY(hipGetLastError());
+            if (horner_quads) {
+                const WaveShape ws = wave_shape(c, (4 * groups + 63) / 64);
+                hipLaunchKernelGGL(blsgpu::k_msm_horner_quads, dim3(ws.blocks), dim3(ws.threads), 0, st, c->d_msm_part,
+                                   (uint32_t)blsgpu::PIP_W, (uint32_t)blsgpu::PIP_C, (uint32_t)groups, (uint32_t*)d_out, (uint8_t*)d_out_inf);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            }
             const uint32_t* winsrc = c->d_msm_part;
             size_t wchunks = chunks;
             if (fold_n) {                                    // many chunks: fold runs of 64 partials per lane first
@@ -522,6 +540,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_H2C_LANE_THRESHOLD")) c->h2c_lane_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_NP_THRESHOLD")) c->horner_np_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_HORNER_QUADS_THRESHOLD")) c->horner_quads_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_WG256_MAX_WAVES")) c->wg256_max_waves = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_LANE_THRESHOLD")) c->msm_lane_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_LANE_PAIRS")) c->msm_lane_pairs = atoi(e) != 0;
     // pack all tables into one device allocation (16-byte aligned pieces)
@@ -783,10 +803,11 @@ static bool use_fexp_team(const blsgpu_ctx* c, size_t m, size_t groups) { return
 static int launch_fexp_team(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_t istride, size_t gstride, size_t groups, void* d_out_bytes,
                             hipStream_t st) {
     using namespace blsgpu;
-    const size_t blocks = (groups + ml::TEAMS - 1) / ml::TEAMS;
-    if (int rc = grow_buffer(c, &c->d_fexp_ws, &c->fexp_ws_cap, blocks * (ml::TEAMS + 1) * BLS28_FEXP_NSLOTS * ml::DENSE_DW * 4)) return rc;
+    const WaveShape ws = wave_shape(c, (groups + ml::TEAMS - 1) / ml::TEAMS);
+    const size_t waves = (size_t)ws.blocks * (ws.threads / 64);                 // every launched wavefront owns rows of the workspace
+    if (int rc = grow_buffer(c, &c->d_fexp_ws, &c->fexp_ws_cap, waves * (ml::TEAMS + 1) * BLS28_FEXP_NSLOTS * ml::DENSE_DW * 4)) return rc;
     KernelTimer kt(c, st, 2);
-    hipLaunchKernelGGL(fx::k_fexp_team, dim3((unsigned)blocks), dim3(64), 0, st, d_in, (uint32_t)m, (uint32_t)istride, (uint32_t)gstride,
+    hipLaunchKernelGGL(fx::k_fexp_team, dim3(ws.blocks), dim3(ws.threads), 0, st, d_in, (uint32_t)m, (uint32_t)istride, (uint32_t)gstride,
                        (uint32_t)groups, (int32_t*)c->d_fexp_ws, (uint32_t*)d_out_bytes, (uint32_t*)c->d_fexp_dbg);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -949,12 +970,15 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
         if (c->ls_lines_form == 1)
             hipLaunchKernelGGL(ml::k_ml_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1, (const uint32_t*)d_g2,
                                (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
-        else if (n <= c->ls_quad_max)                         // few pairs: four lanes each, the tangent step's levels shared by the two pairs
-            hipLaunchKernelGGL(ml::k_ml_lines4, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1,
+        else if (n <= c->ls_quad_max) {                       // few pairs: four lanes each, the tangent step's levels shared by the two pairs
+            const WaveShape ws = wave_shape(c, (4 * n + 63) / 64);
+            hipLaunchKernelGGL(ml::k_ml_lines4, dim3(ws.blocks), dim3(ws.threads), 0, st, (const uint32_t*)d_g1,
                                (const uint32_t*)d_g2, (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
-        else
-            hipLaunchKernelGGL(ml::k_ml_lines2, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1,
+        } else {
+            const WaveShape ws = wave_shape(c, (2 * n + 63) / 64);
+            hipLaunchKernelGGL(ml::k_ml_lines2, dim3(ws.blocks), dim3(ws.threads), 0, st, (const uint32_t*)d_g1,
                                (const uint32_t*)d_g2, (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
+        }
     }
     HIP_TRY(hipGetLastError());
     {   // the listed pairs once more with the reference's own formulas: their line records are rewritten (leaves at once
@@ -967,7 +991,8 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     if (small) {
         {
             KernelTimer kt(c, st, 5);
-            hipLaunchKernelGGL(ml::k_ml_small, dim3((unsigned)((groups + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st, (const int32_t*)c->d_lines,
+            const WaveShape ws = wave_shape(c, (groups + ml::TEAMS - 1) / ml::TEAMS);
+            hipLaunchKernelGGL(ml::k_ml_small, dim3(ws.blocks), dim3(ws.threads), 0, st, (const int32_t*)c->d_lines,
                                (const uint8_t*)c->d_bad, (uint32_t)n, (uint32_t)gsz, (uint32_t)groups, d_partials, 144u,
                                (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         }
@@ -978,7 +1003,8 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     size_t teams = groups * cpg * ml::LINES;
     {
         KernelTimer kt(c, st, 5);
-        hipLaunchKernelGGL(ml::k_ml_accum, dim3((unsigned)((teams + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st, (const int32_t*)c->d_lines,
+        const WaveShape ws = wave_shape(c, (teams + ml::TEAMS - 1) / ml::TEAMS);
+        hipLaunchKernelGGL(ml::k_ml_accum, dim3(ws.blocks), dim3(ws.threads), 0, st, (const int32_t*)c->d_lines,
                            (const uint8_t*)c->d_bad, (uint32_t)n, (uint32_t)gsz, (uint32_t)chunk, (uint32_t)cpg, (uint32_t)teams,
                            (int32_t*)c->d_lsp[0]);
     }
@@ -991,10 +1017,12 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
         if (c->ls_horner_form == 3 && teams <= c->ls_merge_wide_max)       // few outputs: one wavefront each, a product per lane
             hipLaunchKernelGGL(fxw::k_ml_merge_wide, dim3((unsigned)teams), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur], (uint32_t)cpg,
                                (uint32_t)FAN, (uint32_t)cpo, (int32_t*)c->d_lsp[cur ^ 1]);
-        else
-            hipLaunchKernelGGL(ml::k_ml_merge, dim3((unsigned)((teams + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st,
+        else {
+            const WaveShape ws = wave_shape(c, (teams + ml::TEAMS - 1) / ml::TEAMS);
+            hipLaunchKernelGGL(ml::k_ml_merge, dim3(ws.blocks), dim3(ws.threads), 0, st,
                                (const int32_t*)c->d_lsp[cur], (uint32_t)cpg, (uint32_t)FAN, (uint32_t)cpo, (uint32_t)teams,
                                (int32_t*)c->d_lsp[cur ^ 1]);
+        }
         HIP_TRY(hipGetLastError());
         cpg = cpo;
         cur ^= 1;
@@ -1399,20 +1427,21 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
     const bool lanes = n >= c->h2c_lane_threshold;         // the three encoding stages one encoding per lane (k_h2c_sw*)
     const uint32_t total = (uint32_t)(teams * BLSVM_H1_NE);
     const unsigned lgrid = (unsigned)((total + 63) / 64);
+    const WaveShape lsh = wave_shape(c, lgrid);            // the division-step kernels (k_h2c_swj*): any workgroup size
     if (from_hashes) {
         uint32_t* d_dig = img + teams * blsgpu::H1_IMG * 12;
         hipLaunchKernelGGL(blsgpu::k_h2c_hash, dim3((unsigned)((8 * n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_in,
                            (uint32_t)n, d_dig);
         HIP_TRY(hipGetLastError());
         if (lanes && c->h2c_jacobi && n >= c->h2c_jacobi_threshold)
-            hipLaunchKernelGGL(blsgpu::k_h2c_swj0<1>, dim3(lgrid), dim3(64), 0, st, (const uint32_t*)d_dig, (uint32_t)(2 * n), total, img);
+            hipLaunchKernelGGL(blsgpu::k_h2c_swj0<1>, dim3(lsh.blocks), dim3(lsh.threads), 0, st, (const uint32_t*)d_dig, (uint32_t)(2 * n), total, img);
         else if (lanes)
             hipLaunchKernelGGL(blsgpu::k_h2c_sw0<1>, dim3(lgrid), dim3(64), 0, st, (const uint32_t*)d_dig, (uint32_t)(2 * n), total, img);
         else
             hipLaunchKernelGGL((blsgpu::k_h2c_stage<0, 1>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)d_dig,
                                (uint32_t)(2 * n), img);
     } else if (lanes && c->h2c_jacobi && n >= c->h2c_jacobi_threshold) {
-        hipLaunchKernelGGL(blsgpu::k_h2c_swj0<0>, dim3(lgrid), dim3(64), 0, st, (const uint32_t*)d_in, (uint32_t)(2 * n), total, img);
+        hipLaunchKernelGGL(blsgpu::k_h2c_swj0<0>, dim3(lsh.blocks), dim3(lsh.threads), 0, st, (const uint32_t*)d_in, (uint32_t)(2 * n), total, img);
     } else if (lanes) {
         hipLaunchKernelGGL(blsgpu::k_h2c_sw0<0>, dim3(lgrid), dim3(64), 0, st, (const uint32_t*)d_in, (uint32_t)(2 * n), total, img);
     } else {
@@ -1424,7 +1453,7 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
     int rc = launch_pow(c, img, blsgpu::H1_IMG, BASE, ACC, teams, (jac ? 1 : 3) * BLSVM_H1_NE, st);
     if (rc) return rc;
     if (jac)
-        hipLaunchKernelGGL(blsgpu::k_h2c_swj1, dim3(lgrid), dim3(64), 0, st, total, img);
+        hipLaunchKernelGGL(blsgpu::k_h2c_swj1, dim3(lsh.blocks), dim3(lsh.threads), 0, st, total, img);
     else if (lanes)
         hipLaunchKernelGGL(blsgpu::k_h2c_sw1, dim3(lgrid), dim3(64), 0, st, total, img);
     else
@@ -1434,7 +1463,7 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
     rc = launch_pow(c, img, blsgpu::H1_IMG, BASE, ACC, teams, (jac ? 1 : 2) * BLSVM_H1_NE, st);
     if (rc) return rc;
     if (jac)
-        hipLaunchKernelGGL(blsgpu::k_h2c_swj2, dim3(lgrid), dim3(64), 0, st, total, img);
+        hipLaunchKernelGGL(blsgpu::k_h2c_swj2, dim3(lsh.blocks), dim3(lsh.threads), 0, st, total, img);
     else if (lanes)
         hipLaunchKernelGGL(blsgpu::k_h2c_sw2, dim3(lgrid), dim3(64), 0, st, total, img);
     else
@@ -1446,12 +1475,14 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
         hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)d_out);
     } else if (c->h2c_reg_pairs && n <= c->h2c_quad_max) {   // a batch that leaves SIMDs empty on lane pairs: one message per lane QUAD
-        if (int rc2 = grow_buffer(c, &c->d_h2c_ws, &c->h2c_ws_cap, (4 * n + 64) * BLS28_H2C_NSLOTS * 3 * blsgpu::r28::NL * 4)) return rc2;
-        hipLaunchKernelGGL(blsgpu::k_h2c_clear_quads, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, st, c->tabs, img, (uint32_t)n,
+        const WaveShape ws = wave_shape(c, (4 * n + 63) / 64);                   // every launched lane owns rows of the workspace
+        if (int rc2 = grow_buffer(c, &c->d_h2c_ws, &c->h2c_ws_cap, (size_t)ws.blocks * ws.threads * BLS28_H2C_NSLOTS * 3 * blsgpu::r28::NL * 4)) return rc2;
+        hipLaunchKernelGGL(blsgpu::k_h2c_clear_quads, dim3(ws.blocks), dim3(ws.threads), 0, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)c->d_h2c_ws, (uint32_t*)d_out);
     } else if (c->h2c_reg_pairs) {         // one message per lane pair, the point operations as a script
-        if (int rc2 = grow_buffer(c, &c->d_h2c_ws, &c->h2c_ws_cap, (2 * n + 64) * BLS28_H2C_NSLOTS * 3 * blsgpu::r28::NL * 4)) return rc2;
-        hipLaunchKernelGGL(blsgpu::k_h2c_clear_pairs, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, c->tabs, img, (uint32_t)n,
+        const WaveShape ws = wave_shape(c, (2 * n + 63) / 64);
+        if (int rc2 = grow_buffer(c, &c->d_h2c_ws, &c->h2c_ws_cap, (size_t)ws.blocks * ws.threads * BLS28_H2C_NSLOTS * 3 * blsgpu::r28::NL * 4)) return rc2;
+        hipLaunchKernelGGL(blsgpu::k_h2c_clear_pairs, dim3(ws.blocks), dim3(ws.threads), 0, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)c->d_h2c_ws, (uint32_t*)d_out);
     } else {
         hipLaunchKernelGGL(blsgpu::k_h2c_clear_reg, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->tabs, img, (uint32_t)n,

@@ -143,13 +143,13 @@ __device__ __forceinline__ void tinv(int32_t* __restrict__ fre, int32_t* __restr
 
 // Team g: product of the partials in[(i * istride + g * gstride) * 144], i < m (the wavefront VM's form), then the final
 // exponentiation; 576 canonical big-endian bytes to out_bytes[g].  ws: NSLOTS x 168 dwords per team.
-__global__ void __launch_bounds__(64, 2) k_fexp_team(const uint32_t* __restrict__ in, uint32_t m, uint32_t istride, uint32_t gstride,
+__global__ void __launch_bounds__(256, 2) k_fexp_team(const uint32_t* __restrict__ in, uint32_t m, uint32_t istride, uint32_t gstride,
                                                      uint32_t groups, int32_t* __restrict__ ws, uint32_t* __restrict__ out_bytes,
                                                      uint32_t* __restrict__ dbg)
 #if BLSGPU_EMIT(BLSGPU_TU_FX)
 {
     const Team t = ml::team_of_lane();
-    const uint32_t g = blockIdx.x * ml::TEAMS + t.slot;
+    const uint32_t g = wave_index() * ml::TEAMS + t.slot;
     const bool valid = t.slot < (uint32_t)ml::TEAMS && g < groups;
     const uint32_t gc = valid ? g : 0u;
     const uint32_t flat = (t.c & 1u) ? 3u + (t.c >> 1) : (t.c >> 1);           // w-powers 0,2,4,1,3,5 in the flat order
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(64, 2) k_fexp_team(const uint32_t* __restrict_
             ml::mul_dense(fre, fim, t, ml::TeamRec{yre, yim, t.base4});
         }
     }
-    int32_t* slots = ws + (size_t)(blockIdx.x * (ml::TEAMS + 1) + t.slot) * BLS28_FEXP_NSLOTS * ml::DENSE_DW;
+    int32_t* slots = ws + (size_t)(wave_index() * (ml::TEAMS + 1) + t.slot) * BLS28_FEXP_NSLOTS * ml::DENSE_DW;
 #pragma unroll 1
     for (uint32_t pc = 0; pc < (uint32_t)BLS28_FEXP_NOPS; pc++) {
         const uint32_t op = BLS28_FEXP_OPS[pc][0], arg = BLS28_FEXP_OPS[pc][1];

@@ -328,7 +328,7 @@ template <int A, int B> __device__ __forceinline__ int chi(const r28::F<A, B>& v
 // stage 0 with the choice of the candidate inside: X[6i..] = x, U[6i] = u0, A1 = u1, N[3i] = n' (0 for a real u),
 // BASE[i] = ACC[i] = N(u) of the chosen candidate -> ONE power per encoding
 template <int WIDE>
-__global__ void __launch_bounds__(64) k_h2c_swj0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img)
+__global__ void __launch_bounds__(256) k_h2c_swj0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img)
 #if BLSGPU_EMIT(BLSGPU_TU_H2C)
 {
     using namespace swl;
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(64) k_h2c_swj0(const uint32_t* __restrict__ t,
 ;
 #endif
 // after z = n^E: r = z n', delta+- = (u0 +- r)/2, the square one of them -> BASE[i] = ACC[i]; its character -> N[3i + 1]
-__global__ void __launch_bounds__(64) k_h2c_swj1(uint32_t total, uint32_t* __restrict__ img)
+__global__ void __launch_bounds__(256) k_h2c_swj1(uint32_t total, uint32_t* __restrict__ img)
 #if BLSGPU_EMIT(BLSGPU_TU_H2C)
 {
     using namespace swl;
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(64) k_h2c_swj1(uint32_t total, uint32_t* __res
 ;
 #endif
 // after z = d^E: x0 = z d (halved when delta+ was zero: the VM's (1 + chi)/2 selection with chi = 0), then h1_c as k_h2c_sw2
-__global__ void __launch_bounds__(64) k_h2c_swj2(uint32_t total, uint32_t* __restrict__ img)
+__global__ void __launch_bounds__(256) k_h2c_swj2(uint32_t total, uint32_t* __restrict__ img)
 #if BLSGPU_EMIT(BLSGPU_TU_H2C)
 {
     using namespace swl;
@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(64) k_h2c_clear_reg(VmTables T, const uint32_t
 // every coordinate (256 registers, two wavefronts per SIMD), the point operations exist ONCE in the code -- the
 // clearing is a script (fexp_tables_gfx950.h BLS28_H2C_OPS, vmgen/gen_fexp.h2c_clear_script) over one point in
 // registers and five lane-private slots in HBM -- and 16 384 messages already give 512 wavefronts.
-__global__ void __launch_bounds__(64, 2) k_h2c_clear_pairs(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg, uint32_t* __restrict__ ws,
+__global__ void __launch_bounds__(256, 2) k_h2c_clear_pairs(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg, uint32_t* __restrict__ ws,
                                                            uint32_t* __restrict__ out)
 #if BLSGPU_EMIT(BLSGPU_TU_H2C)
 {
@@ -842,7 +842,7 @@ __global__ void __launch_bounds__(64, 2) k_h2c_clear_pairs(VmTables T, const uin
 // independent Fq2 products of every point operation, so the script is about half as deep -- what counts while the batch
 // leaves SIMDs empty on lane pairs (16 384 messages: 512 wavefronts for 1024 SIMDs).  Same script, same slots (written
 // lane-private like the pair kernel's), same results.
-__global__ void __launch_bounds__(64, 2) k_h2c_clear_quads(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg, uint32_t* __restrict__ ws,
+__global__ void __launch_bounds__(256, 2) k_h2c_clear_quads(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg, uint32_t* __restrict__ ws,
                                                            uint32_t* __restrict__ out)
 #if BLSGPU_EMIT(BLSGPU_TU_H2C)
 {

@@ -386,11 +386,11 @@ __device__ __forceinline__ void tangent_step(h& X, h& Y, h& Z, const fe& px3n, c
 #ifndef BLSGPU_ML_LINES2_WAVES
 #define BLSGPU_ML_LINES2_WAVES 2
 #endif
-__global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines2(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
+__global__ void __launch_bounds__(256, BLSGPU_ML_LINES2_WAVES) k_ml_lines2(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
                                                                            int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg)
 #if BLSGPU_EMIT(BLSGPU_TU_ML)
 {
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t pr = t >> 1;
     const uint32_t p = pr < n ? pr : n - 1u;                      // the last wavefront's spare lanes repeat the last pair
     const uint32_t part = t & 1u;
@@ -446,11 +446,11 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines2(const 
 // Four lanes per pair (round 4): for calls that leave SIMDs empty on lane pairs -- 8192 pairs are 256 wavefronts there, each
 // with the whole chain of 68 steps to itself (1.12 ms whatever the count) -- the two pairs of a quad share the tangent
 // step's levels (sq::tangent_step): about 0.6 of the depth.  Same records, flags and work list.
-__global__ void __launch_bounds__(64, BLSGPU_ML_LINES2_WAVES) k_ml_lines4(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
+__global__ void __launch_bounds__(256, BLSGPU_ML_LINES2_WAVES) k_ml_lines4(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
                                                                            int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg)
 #if BLSGPU_EMIT(BLSGPU_TU_ML)
 {
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t pr = t >> 2;
     const uint32_t p = pr < n ? pr : n - 1u;                      // the last wavefront's spare lanes repeat the last pair
     const uint32_t part = t & 1u;
@@ -814,13 +814,13 @@ __device__ __forceinline__ void set_one(int32_t* __restrict__ fre, int32_t* __re
 #ifndef BLSGPU_ML_ACCUM_WAVES
 #define BLSGPU_ML_ACCUM_WAVES 2
 #endif
-__global__ void __launch_bounds__(64, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad, uint32_t n,
+__global__ void __launch_bounds__(256, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad, uint32_t n,
                                                                          uint32_t gsz, uint32_t chunk, uint32_t cpg, uint32_t nteams,
                                                                          int32_t* __restrict__ out)
 #if BLSGPU_EMIT(BLSGPU_TU_ML)
 {
     const Team t = team_of_lane();
-    const uint32_t id = blockIdx.x * TEAMS + t.slot;
+    const uint32_t id = wave_index() * TEAMS + t.slot;
     const bool valid = t.slot < (uint32_t)TEAMS && id < nteams;
     const uint32_t idc = valid ? id : 0u;
     const uint32_t L = idc % LINES, gj = idc / LINES, j = gj % cpg, g = gj / cpg;
@@ -868,12 +868,12 @@ __global__ void __launch_bounds__(64, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const in
 
 // One level of the product tree over the chunks: team (g, j', L) multiplies the records (g, j, L), j in
 // [j' * fan, min(cpg_in, (j' + 1) * fan)), of `in` (indexed as k_ml_accum's output with cpg_in) -> out (cpg_out).
-__global__ void __launch_bounds__(64, 2) k_ml_merge(const int32_t* __restrict__ in, uint32_t cpg_in, uint32_t fan, uint32_t cpg_out,
+__global__ void __launch_bounds__(256, 2) k_ml_merge(const int32_t* __restrict__ in, uint32_t cpg_in, uint32_t fan, uint32_t cpg_out,
                                                     uint32_t nteams, int32_t* __restrict__ out)
 #if BLSGPU_EMIT(BLSGPU_TU_ML)
 {
     const Team t = team_of_lane();
-    const uint32_t id = blockIdx.x * TEAMS + t.slot;
+    const uint32_t id = wave_index() * TEAMS + t.slot;
     const bool valid = t.slot < (uint32_t)TEAMS && id < nteams;
     const uint32_t idc = valid ? id : 0u;
     const uint32_t L = idc % LINES, gj = idc / LINES, jo = gj % cpg_out, g = gj / cpg_out;
@@ -964,7 +964,7 @@ struct TeamRec {                                   // the team's own f as the de
 // List mode (count != nullptr; the wavefront-VM kernels' degenerate blocks): group g is entry g of the work list, its
 // pairs the virtual pairs [g * gsz, (g + 1) * gsz) of k_ml_lines_exact's block mode (flag 255: no pair), and its partial
 // goes to partials[index[g] * pstride].
-__global__ void __launch_bounds__(64, 2) k_ml_small(const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad, uint32_t n, uint32_t gsz,
+__global__ void __launch_bounds__(256, 2) k_ml_small(const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad, uint32_t n, uint32_t gsz,
                                                     uint32_t groups, uint32_t* __restrict__ partials, uint32_t pstride,
                                                     const uint32_t* __restrict__ count, const uint32_t* __restrict__ index)
 #if BLSGPU_EMIT(BLSGPU_TU_ML)
@@ -972,9 +972,9 @@ __global__ void __launch_bounds__(64, 2) k_ml_small(const int32_t* __restrict__ 
     const Team t = team_of_lane();
     if (count != nullptr) {
         groups = min(groups, __builtin_amdgcn_readfirstlane(*(volatile const uint32_t*)count));
-        if (blockIdx.x * TEAMS >= groups) return;
+        if (wave_index() * TEAMS >= groups) return;
     }
-    const uint32_t g = blockIdx.x * TEAMS + t.slot;
+    const uint32_t g = wave_index() * TEAMS + t.slot;
     const bool valid = t.slot < (uint32_t)TEAMS && g < groups;
     const size_t first = (size_t)(valid ? g : 0u) * gsz;
     int32_t fre[NL], fim[NL];

@@ -830,6 +830,65 @@ __device__ __forceinline__ pt to_homogeneous(const pt& P) {
 }
 }  // namespace sp4
 
+// The window Horner of a BATCH of G2 sums with ONE SUM PER LANE QUAD (round 4): result_g = sum_w 2^(cbits w) W_{g,w} from the
+// top window down, 252 complete doublings and 63 complete additions deep for the threshold combine (64 windows of 4 bits).
+// k_msm_horner_np runs five sums per wavefront on the wavefront VM (10 000 groups: 2000 wavefronts x 1 M instructions);
+// here the point operations are sp4's (both pairs of a quad share each level of independent Fq2 products), the window
+// sums are read in the L28 form k_msm_lane2x leaves them in (no copy through the VM's form), and the affine conversion
+// is the hash's (one safegcd inversion of the norm of Z per lane).  out: groups x 192 bytes, (0, 0) + flag for infinity.
+__global__ void __launch_bounds__(256, 2) k_msm_horner_quads(const uint32_t* __restrict__ winsums, uint32_t nwin, uint32_t cbits, uint32_t groups,
+                                                            uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
+    using namespace sp2;
+    constexpr uint32_t PJ_DW = L28_PJ * 2;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = min(tid >> 2, groups - 1u), part = tid & 1u;          // spare quads of the last wavefront repeat the last sum
+    const bool store = (tid >> 2) < groups && (tid & 2u) == 0u;
+    const uint32_t* W = winsums + (size_t)g * nwin * PJ_DW;
+    pt acc = pt_ld(W + (size_t)(nwin - 1u) * PJ_DW);
+#pragma unroll 1
+    for (int w = (int)nwin - 2; w >= 0; w--) {
+#pragma unroll 1
+        for (uint32_t s = 0; s < cbits; s++) acc = sp4::pdbl(acc);
+        const pt Q = pt_ld(W + (size_t)w * PJ_DW);
+        acc = sp4::padd(acc, Q);
+    }
+    // affine: (X, Y) / Z with 1 / Z = conj(Z) / N(Z); Z = 0 gives (0, 0)
+    const h zp = swp(acc.Z);
+    r28::fe n;
+    bls28::fp28_dot2(n.v, acc.Z.v, acc.Z.v, zp.v, zp.v);
+    uint32_t nv[12], niv[12];
+    r28::to_vm(nv, n);
+    bls::fq_inv(niv, nv);
+    const r28::fe ninv = r28::from_vm(niv);
+    S<1> zc;
+#pragma unroll
+    for (int j = 0; j < r28::NL; j++) zc.v[j] = part ? -acc.Z.v[j] : acc.Z.v[j];
+    const h zi = mulf(zc, ninv);
+    const Rop<1> rzi = right(zi);
+    const h xa = mul(left(acc.X), rzi), ya = mul(left(acc.Y), rzi);
+    const h* o[2] = {&xa, &ya};
+    uint32_t any = 0;
+    for (int k = 0; k < 2; k++) {
+        r28::fe t;
+#pragma unroll
+        for (int j = 0; j < r28::NL; j++) t.v[j] = o[k]->v[j];
+        uint32_t y[12];
+        r28::to_raw(y, t);
+#pragma unroll
+        for (int w = 0; w < 12; w++) {
+            any |= y[w];
+            if (store) out[(size_t)g * 48 + (2 * k + part) * 12 + w] = bswap32(y[11 - w]);
+        }
+    }
+    any |= (uint32_t)__shfl_xor((int)any, 1);
+    if (out_inf && store && part == 0u) out_inf[g] = any ? 0 : 1;
+}
+#else
+;
+#endif
+
 #ifndef BLSGPU_MSM_LANE2X_WAVES
 #define BLSGPU_MSM_LANE2X_WAVES 2
 #endif

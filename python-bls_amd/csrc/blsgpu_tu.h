@@ -17,3 +17,16 @@
 #define BLSGPU_TU 0
 #endif
 #define BLSGPU_EMIT(g) (BLSGPU_TU == 0 || BLSGPU_TU == (g))
+
+
+// Workgroup shape of the register kernels (one unit of work per lane or lane team, nothing shared between wavefronts).
+// Measured (tools/microbench/wg_placement.hip, profiles/r04_workgroup_shape.txt): a launch of fewer wavefronts than the
+// chip holds, issued as 64-thread workgroups of a kernel with a large register allocation, gets wavefronts stacked two
+// to a SIMD while other SIMDs stay empty (k_msm_horner_quads, 625 wavefronts: 4.2 ms; as 157 workgroups of 256 threads
+// -- four wavefronts, one per SIMD of a CU -- 2.4 ms).  Such kernels index by wave_index() / the global thread index
+// and are launched through blsgpu_api.hip's wave_shape().
+#if defined(__HIPCC__)
+namespace blsgpu {
+__device__ __forceinline__ unsigned wave_index() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
+}
+#endif

@@ -286,6 +286,55 @@ def test_batch_horner_vs_oracle(horner_engine, oracle, seeded_pairs, k, groups):
         assert inf[2]
 
 
+def _engine_with_values(values):
+    import os
+    from bls_py import _native
+    old = {k: os.environ.get(k) for k in values}
+    os.environ.update(values)
+    try:
+        e = _native.Engine(0)
+    finally:
+        for k in values:
+            if old[k] is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = old[k]
+    return e
+
+
+@pytest.fixture(scope="module")
+def lane_np_engine():
+    """The lane-pair bucket kernel with the window Horner of round 3 (VM form, k_msm_pip_windows + k_msm_horner_np /
+    k_msm_pip_horner): what the lane path ran before the Horner on lane quads, kept under test as the unselected form."""
+    return _engine_with_values({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_LANE_THRESHOLD": "1",
+                                "BLSGPU_HORNER_NP_THRESHOLD": "1", "BLSGPU_HORNER_QUADS_THRESHOLD": "1000000000"})
+
+
+@pytest.mark.parametrize("k,groups", [(3, 2), (5, 4), (4, 16), (3, 17), (2, 33), (67, 7)])
+def test_batch_horner_on_lane_quads_vs_oracle(lane_engine, lane_np_engine, oracle, seeded_pairs, k, groups):
+    """k_msm_horner_quads (a batch of G2 sums on the lane-pair bucket kernel: one sum per lane quad, window sums read in
+    the L28 form): ragged quad counts (16 sums per wavefront), a sum that is the point at infinity (flag and (0, 0)),
+    zero / short / extreme scalars -- against the oracle and the VM-form Horner."""
+    _, g2 = seeded_pairs
+    rnd = random.Random(k * 19 + groups)
+    n = k * groups
+    pts = bytearray((g2 * 3)[192 * 5:192 * (5 + n)])
+    sc = [rnd.choice([rnd.randrange(N), rnd.randrange(1 << 40), 0, N - 1, 1, (1 << 256) - 1]) for _ in range(n)]
+    if groups >= 4:                                             # sum number 2: P, -P and zeros -> infinity
+        P = bytes(pts[192 * 2 * k:192 * 2 * k + 192])
+        negP = P[:96] + b"".join(((Q - int.from_bytes(P[96 + 48 * j:144 + 48 * j], "big")) % Q).to_bytes(48, "big") for j in range(2))
+        pts[192 * (2 * k + 1):192 * (2 * k + 2)] = negP
+        for i in range(k):
+            sc[2 * k + i] = 9 if i < 2 else 0
+    out, inf = lane_engine.g2_msm(bytes(pts), sc, k, groups)
+    assert (out, inf) == lane_np_engine.g2_msm(bytes(pts), sc, k, groups)
+    for g in range(groups if groups <= 17 else 6):
+        want, _ = oracle.g2_msm(bytes(pts[192 * k * g:192 * k * (g + 1)]), sc[k * g:k * (g + 1)], k)
+        assert out[192 * g:192 * (g + 1)] == want and inf[g] == (want == bytes(192)), g
+    if groups >= 4:
+        assert inf[2] and out[192 * 2:192 * 3] == bytes(192)
+
+
 @pytest.fixture(scope="module")
 def sorted_engine():
     """An engine whose single G1 sums with scalars use the sorted buckets (k_srt_*) from 1 point on."""

@@ -4,12 +4,18 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 so = os.path.join(ROOT, "python-bls_amd", "csrc", "libblsgpu.so")
+filt = ""
 with tempfile.TemporaryDirectory() as td:
-    fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "lib.co")
+    fat = os.path.join(td, "fat.bin")
     subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", so, fat])
-    subprocess.check_call([LLVM + "/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co, "--unbundle"])
-    notes = subprocess.check_output([LLVM + "/llvm-readelf", "--notes", co], text=True)
-    filt = subprocess.check_output(["c++filt"], input=notes, text=True)
+    blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]      # one bundle per translation unit
+    for i, a in enumerate(starts):
+        part, co = os.path.join(td, "fat%d.bin" % i), os.path.join(td, "lib%d.co" % i)
+        open(part, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        subprocess.check_call([LLVM + "/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + part, "--output=" + co, "--unbundle"])
+        notes = subprocess.check_output([LLVM + "/llvm-readelf", "--notes", co], text=True)
+        filt += subprocess.check_output(["c++filt"], input=notes, text=True)
 for m in re.finditer(r"\.name:\s+(.+?)\n(.*?)(?=\.name:|\Z)", filt, re.S):
     n, b = m.group(1).strip(), m.group(2)
     if sys.argv[1:] and not any(k in n for k in sys.argv[1:]):
