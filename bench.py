@@ -822,9 +822,9 @@ def run_c5(env, args):
     torch.cuda.synchronize()
     env.barrier()
     dt_alone = (time.perf_counter() - t0) / reps
-    # the timed steps: --streams sums in flight on contexts of their own (one GPU: the bit sums / Horner of one sum, a few
+    # the timed steps: three (or --streams) sums in flight on contexts of their own (one GPU: the bit sums / Horner of one sum, a few
     # hundred wavefronts, run beside the next sum's list additions); with a process group the steps stay one after another
-    S = max(1, args.streams) if env.dist is None else 1
+    S = max(3, args.streams) if env.dist is None else 1    # (a sum's tail is a third of its length: three keep the chip busy)
     dt_step, ok_p = dt_alone, True
     if S > 1:
         shards = [shard] + [GpuShardBackend(_native.Engine(env.local_dev), env.dev) for _ in range(S - 1)]
