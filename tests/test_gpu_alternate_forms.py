@@ -10,6 +10,8 @@ creation (csrc/blsgpu_api.hip), so each gets the reference's vectors.
                             (default: k_ml_lines_exact in block mode + k_ml_small in list mode)
   BLSGPU_TEST_LS_NOMEM=1    test hook: launch_miller_ls reports -ENOMEM before touching the device, the call must go
                             through the wavefront-VM kernels and return the same bytes
+  BLSGPU_WG256_MAX_WAVES=0  the register kernels launched as 64-thread workgroups whatever the size (default: launches of
+                            up to 4096 wavefronts as 256-thread workgroups, csrc/blsgpu_tu.h wave_index())
 
 Expected values: tests/golden/pairing.json (1025-pair seeded batch, edge cases) and pairing_degenerate.json -- generated
 by importing the reference -- and the CPU oracle for spliced batches."""
@@ -30,6 +32,7 @@ FORMS = {
     "both_old_forms": ({"BLSGPU_LS_LINES_FORM": "1", "BLSGPU_LS_HORNER_FORM": "1"}, True),
     "vm_slow_program_for_degenerate_blocks": ({"BLSGPU_VM_EXACT_LANES": "0"}, False),
     "line_stream_workspace_unavailable": ({"BLSGPU_TEST_LS_NOMEM": "1"}, True),
+    "workgroups_of_64_threads": ({"BLSGPU_WG256_MAX_WAVES": "0"}, True),                    # round 3's launch shape for every size
 }
 _cache = {}
 
@@ -94,3 +97,32 @@ def test_fallback_engine_really_refuses_the_line_stream_path(seeded_pairs):
     assert hooked.workspace_bytes()["line_products"] == 0 and plain.workspace_bytes()["line_products"] >= 68 * 168 * 4
     ws = plain.workspace_bytes()
     assert ws["total"] == sum(v for k, v in ws.items() if k != "total")
+
+
+def test_workgroup_shapes_agree_beyond_the_pairing(golden, seeded_pairs):
+    """The other kernels that index by wave_index() / the global thread index -- hash to G2 (division-step encodings,
+    clearing on lane pairs and quads), batches of G2 sums (window Horner on lane quads), batched final exponentiations
+    (six lanes per result), small-group Miller loops -- with 64-thread workgroups against the reference's digests and
+    against the default shapes, at sizes that leave the last workgroup ragged."""
+    import hashlib
+    from bls_py import _native
+    e64 = form_engine("workgroups_of_64_threads")
+    dflt = _native.Engine(0)
+    rec = golden("h2c_20000.json")
+    msgs = b"".join(hashlib.sha256(b"bench-h2c-0-%d" % i).digest() for i in range(rec["n"]))
+    out = e64.hash_to_g2(msgs)                                   # lanes + symbols + quads (20 000 <= 20 480)
+    assert hashlib.sha256(out).hexdigest() == rec["outputs_sha256"]
+    assert e64.hash_to_g2(msgs[:32 * 16389]) == out[:192 * 16389] == dflt.hash_to_g2(msgs[:32 * 16389])
+    g1, g2 = seeded_pairs
+    # 333 groups of 3 pairs: k_ml_lines4 + k_ml_small (34 wavefronts of ten groups), then 333 final exponentiations
+    n = 999
+    a, b = (g1 * 2)[:96 * n], (g2 * 2)[:192 * n]
+    for eng in (e64, dflt):
+        eng.set_ls_threshold(1, 64)
+    want = dflt.pairing_multi_batch(a, b, 3, 333)
+    assert e64.pairing_multi_batch(a, b, 3, 333) == want
+    for eng in (e64, dflt):
+        eng.set_fexp_team_threshold(1)                           # six lanes per result from one result on
+    assert e64.pairing_multi_batch(a, b, 3, 333) == want == dflt.pairing_multi_batch(a, b, 3, 333)
+    v = golden("pairing.json")["small4"]
+    assert e64.pairing_multi(cat(v["g1"]), cat(v["g2"]), 4).hex() == v["out"]

@@ -335,6 +335,20 @@ def test_batch_horner_on_lane_quads_vs_oracle(lane_engine, lane_np_engine, oracl
         assert inf[2] and out[192 * 2:192 * 3] == bytes(192)
 
 
+def test_batch_horner_on_lane_quads_workgroup_shapes(lane_engine, seeded_pairs):
+    """k_msm_horner_quads as 64-thread workgroups (BLSGPU_WG256_MAX_WAVES=0) and as the default 256-thread ones: the same
+    bytes, ragged quad counts"""
+    e64 = _engine_with_values({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_LANE_THRESHOLD": "1",
+                               "BLSGPU_WG256_MAX_WAVES": "0"})
+    _, g2 = seeded_pairs
+    rnd = random.Random(77)
+    for k, groups in ((3, 17), (2, 67), (67, 7)):
+        n = k * groups
+        pts = (g2 * 3)[192 * 9:192 * (9 + n)]
+        sc = [rnd.choice([rnd.randrange(N), rnd.randrange(1 << 40), 0, N - 1]) for _ in range(n)]
+        assert e64.g2_msm(pts, sc, k, groups) == lane_engine.g2_msm(pts, sc, k, groups)
+
+
 @pytest.fixture(scope="module")
 def sorted_engine():
     """An engine whose single G1 sums with scalars use the sorted buckets (k_srt_*) from 1 point on."""
