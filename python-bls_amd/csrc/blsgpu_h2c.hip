@@ -328,7 +328,7 @@ template <int A, int B> __device__ __forceinline__ int chi(const r28::F<A, B>& v
 // stage 0 with the choice of the candidate inside: X[6i..] = x, U[6i] = u0, A1 = u1, N[3i] = n' (0 for a real u),
 // BASE[i] = ACC[i] = N(u) of the chosen candidate -> ONE power per encoding
 template <int WIDE>
-__global__ void __launch_bounds__(256) k_h2c_swj0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img)
+__global__ void __launch_bounds__(256, 2) k_h2c_swj0(const uint32_t* __restrict__ t, uint32_t n_enc, uint32_t total, uint32_t* __restrict__ img)
 #if BLSGPU_EMIT(BLSGPU_TU_H2C)
 {
     using namespace swl;
