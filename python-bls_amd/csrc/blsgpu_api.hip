@@ -65,7 +65,7 @@ struct blsgpu_ctx {
     bool h2c_jacobi = true;            // ... with the quadratic characters decided by a Jacobi-symbol routine: two powers per encoding, not five
     size_t h2c_jacobi_threshold = 16384;   // ... from this many messages (below, five parallel powers finish sooner than three serial symbol loops)
     bool h2c_reg_pairs = true;         // ... on lane pairs (k_h2c_clear_pairs); false: one message per lane (k_h2c_clear_reg)
-    size_t h2c_quad_max = 20480;       // ... on lane QUADS up to this many messages (k_h2c_clear_quads: half the depth while the chip is not full)
+    size_t h2c_quad_max = 16384;       // ... on lane QUADS up to this many messages (k_h2c_clear_quads: half the depth while the chip is not full)
     bool test_ls_nomem = false;        // test hook (BLSGPU_TEST_LS_NOMEM=1): the line-stream workspace "cannot be allocated"
     void* d_h2c_ws = nullptr;          // the lane-private point slots of k_h2c_clear_pairs
     size_t h2c_ws_cap = 0;

@@ -110,9 +110,9 @@ def test_workgroup_shapes_agree_beyond_the_pairing(golden, seeded_pairs):
     dflt = _native.Engine(0)
     rec = golden("h2c_20000.json")
     msgs = b"".join(hashlib.sha256(b"bench-h2c-0-%d" % i).digest() for i in range(rec["n"]))
-    out = e64.hash_to_g2(msgs)                                   # lanes + symbols + quads (20 000 <= 20 480)
+    out = e64.hash_to_g2(msgs)                                   # lanes + symbols + clearing on lane pairs (20 000 > 16 384)
     assert hashlib.sha256(out).hexdigest() == rec["outputs_sha256"]
-    assert e64.hash_to_g2(msgs[:32 * 16389]) == out[:192 * 16389] == dflt.hash_to_g2(msgs[:32 * 16389])
+    assert e64.hash_to_g2(msgs[:32 * 16381]) == out[:192 * 16381] == dflt.hash_to_g2(msgs[:32 * 16381])     # ... on lane quads, ragged
     g1, g2 = seeded_pairs
     # 333 groups of 3 pairs: k_ml_lines4 + k_ml_small (34 wavefronts of ten groups), then 333 final exponentiations
     n = 999

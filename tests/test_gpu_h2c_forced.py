@@ -2,7 +2,7 @@
 
 The engine picks its kernels by batch size (csrc/blsgpu_api.hip map_to_g2_impl): encodings on the wavefront VM below
 2048 messages, one encoding per lane (k_h2c_sw0/1/2) from there, the quadratic characters by the binary symbol routine
-(k_h2c_swj0/1/2) from 16 384; cofactor clearing on the VM below 8192, on lane QUADS (k_h2c_clear_quads) up to 20 480
+(k_h2c_swj0/1/2) from 16 384; cofactor clearing on the VM below 8192, on lane QUADS (k_h2c_clear_quads) up to 16 384
 messages, on lane pairs (k_h2c_clear_pairs) above, one message per lane (k_h2c_clear_reg) as an alternative.  No committed fixture is that large except h2c_20000.json, so
 here the thresholds are moved (BLSGPU_H2C_* read at context creation) and EVERY combination runs
 
