@@ -16,8 +16,12 @@ with tempfile.TemporaryDirectory() as td:
         subprocess.check_call([LLVM + "/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + part, "--output=" + co, "--unbundle"])
         notes = subprocess.check_output([LLVM + "/llvm-readelf", "--notes", co], text=True)
         filt += subprocess.check_output(["c++filt"], input=notes, text=True)
-for m in re.finditer(r"\.name:\s+(.+?)\n(.*?)(?=\.name:|\Z)", filt, re.S):
-    n, b = m.group(1).strip(), m.group(2)
+# one "- .key: ..." list entry per kernel under amdhsa.kernels; its keys are sorted, so .name sits in the middle of the entry
+for entry in re.split(r"\n\s*- (?=\.)", filt):
+    m = re.search(r"\.name:\s+(.+?)\n", entry)
+    if not m or ".vgpr_count" not in entry:
+        continue
+    n, b = m.group(1).strip(), entry
     if sys.argv[1:] and not any(k in n for k in sys.argv[1:]):
         continue
     g = lambda k: (re.search(k + r":\s+(\d+)", b) or [0, "-"])[1]
