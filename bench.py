@@ -217,6 +217,7 @@ class Env:
         torch.cuda.set_device(self.local_dev)
         self.dev = torch.device("cuda", self.local_dev)
         self.dist = None
+        self.clock = None
         self.backend = args.backend
         if self.world > 1 or args.force_process_group:
             import torch.distributed as dist
@@ -287,6 +288,59 @@ def seeded_points(eng, gen1, gen2, idx):
     return g1, g2, a, b
 
 
+class ClockWatch:
+    """Engine clock and package power of this rank's GPU while the timed steps run: the hwmon files of the card whose PCI
+    address torch reports (freq1_input in Hz, power1_input in uW), read every 50 ms by a thread -- sysfs reads only, no
+    child process.  The roof this bench prices against is a power-limited one ("Clock and power"),
+    so the line carries the clock the step ran at."""
+
+    def __init__(self, torch, index):
+        import glob
+        self.files, self.samples, self._stop, self._t = None, [], False, None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.realpath(d).endswith(addr):
+                    f = glob.glob(os.path.join(d, "hwmon", "hwmon*", "freq1_input"))
+                    w = glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_input")) or glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_average"))
+                    if f:
+                        self.files = (f[0], w[0] if w else None)
+        except Exception:
+            self.files = None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                with open(self.files[0]) as f:
+                    hz = int(f.read().split()[0])
+                uw = None
+                if self.files[1]:
+                    with open(self.files[1]) as f:
+                        uw = int(f.read().split()[0])
+                self.samples.append((hz / 1e6, None if uw is None else uw / 1e6))
+            except (OSError, ValueError, IndexError):
+                pass
+            time.sleep(0.05)
+
+    def start(self):
+        if self.files:
+            import threading
+            self._t = threading.Thread(target=self._run, daemon=True)
+            self._t.start()
+
+    def stop(self):
+        self._stop = True
+        if self._t:
+            self._t.join(timeout=1.0)
+        mhz = sorted(s[0] for s in self.samples)
+        wat = sorted(s[1] for s in self.samples if s[1] is not None)
+        if not mhz:
+            return None
+        return {"sclk_mhz_median": mhz[len(mhz) // 2], "sclk_mhz_min": mhz[0], "sclk_mhz_max": mhz[-1],
+                "package_power_w_median": wat[len(wat) // 2] if wat else None, "samples": len(mhz)}
+
+
 def timed_steps(env, args, step, engs, streams):
     """W warm-up steps, barrier, K timed steps, barrier: (seconds max over ranks, per-step ms, kernel times)"""
     torch = env.torch
@@ -298,6 +352,8 @@ def timed_steps(env, args, step, engs, streams):
     for e in engs:
         e.timing_enable(True)         # HIP events around every kernel, on the stream it runs on
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    watch = ClockWatch(torch, env.local_dev)
+    watch.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record(streams[i % S])
@@ -305,6 +361,7 @@ def timed_steps(env, args, step, engs, streams):
         ev[i][1].record(streams[i % S])
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
+    env.clock = watch.stop()
     step_ms = sorted(a.elapsed_time(b) for a, b in ev)
     ktimes = [t for e in engs for t in e.timing_read()]
     for e in engs:
@@ -548,7 +605,10 @@ def run_pairing(env, args):
                          "whole_step_TMACs": (MAC_PER_PAIRING * n + MAC_PER_FINAL_EXP) * B * world / (dt / args.steps) / 1e12,
                          "step_latency_ms_avg": sum(step_ms) / len(step_ms), "step_latency_ms_min": step_ms[0],
                          "hbm_GBps_algorithmic": alg_bytes / (miller_avg * 1e-3) / 1e9,
-                         "hbm_peak_GBps": PEAK_HBM_GBS},
+                         "hbm_peak_GBps": PEAK_HBM_GBS,
+                         # the engine clock / package power rank 0's GPU ran the timed steps at (sysfs samples): `peak` is the
+                         # multiply-add rate measured at the power-limited clock (65 536 lanes x 2.115 GHz / 4), not at 2.4 GHz
+                         "gpu_clock_during_timed_steps": getattr(env, "clock", None)},
             "per_rank": [{"rank": i["rank"], "device": i["device"], "k_miller_ms_avg": i["k_miller_ms_avg"]} for i in info],
             "single_call_latency": lat,
         }
