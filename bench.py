@@ -608,7 +608,11 @@ def run_pairing(env, args):
                          "hbm_peak_GBps": PEAK_HBM_GBS,
                          # the engine clock / package power rank 0's GPU ran the timed steps at (sysfs samples): `peak` is the
                          # multiply-add rate measured at the power-limited clock (65 536 lanes x 2.115 GHz / 4), not at 2.4 GHz
-                         "gpu_clock_during_timed_steps": getattr(env, "clock", None)},
+                         "gpu_clock_during_timed_steps": getattr(env, "clock", None),
+                         # the same achieved rate against the multiply-add issue rate AT THAT CLOCK (65 536 lanes, one
+                         # v_mad_i64_i32 per 4 cycles): what the kernels do with the cycles the power limit leaves them
+                         "frac_of_issue_rate_at_measured_clock": (ach / (65536 * env.clock["sclk_mhz_median"] * 1e6 / 4 / 1e12))
+                         if getattr(env, "clock", None) else None},
             "per_rank": [{"rank": i["rank"], "device": i["device"], "k_miller_ms_avg": i["k_miller_ms_avg"]} for i in info],
             "single_call_latency": lat,
         }
