@@ -335,6 +335,23 @@ def test_batch_horner_on_lane_quads_vs_oracle(lane_engine, lane_np_engine, oracl
         assert inf[2] and out[192 * 2:192 * 3] == bytes(192)
 
 
+def test_batch_of_plain_g2_sums_on_the_lane_kernels(lane_engine, oracle, seeded_pairs):
+    """no scalars (the sums of aggregate_sigs): every window but the lowest sums to infinity, so the window Horner on
+    lane quads doubles and adds infinities 63 times before the one real window; a group of P, -P sums to infinity"""
+    _, g2 = seeded_pairs
+    k, groups = 3, 9
+    pts = bytearray((g2 * 2)[192 * 11:192 * (11 + k * groups)])
+    P = bytes(pts[192 * 4 * k:192 * 4 * k + 192])
+    negP = P[:96] + b"".join(((Q - int.from_bytes(P[96 + 48 * j:144 + 48 * j], "big")) % Q).to_bytes(48, "big") for j in range(2))
+    pts[192 * (4 * k + 1):192 * (4 * k + 2)] = negP
+    pts[192 * (4 * k + 2):192 * (4 * k + 3)] = bytes(192)           # group 4: P, -P, infinity
+    out, inf = lane_engine.g2_msm(bytes(pts), None, k, groups)
+    for g in range(groups):
+        want, _ = oracle.g2_msm(bytes(pts[192 * k * g:192 * k * (g + 1)]), None, k)
+        assert out[192 * g:192 * (g + 1)] == want and inf[g] == (want == bytes(192)), g
+    assert inf[4]
+
+
 def test_batch_horner_on_lane_quads_workgroup_shapes(lane_engine, seeded_pairs):
     """k_msm_horner_quads as 64-thread workgroups (BLSGPU_WG256_MAX_WAVES=0) and as the default 256-thread ones: the same
     bytes, ragged quad counts"""
