@@ -3,6 +3,8 @@ workspace cannot be allocated (VERDICT r3 item 1 d / e): each is reachable throu
 creation (csrc/blsgpu_api.hip), so each gets the reference's vectors.
 
   BLSGPU_LS_LINES_FORM=1    k_ml_lines: the point chains with one pair per lane (default: k_ml_lines2, lane pairs)
+  BLSGPU_LS_QUAD_MAX=0      k_ml_lines2 (one pair per lane PAIR) for calls of every size: the kernel of bench.py's 524 800-pair
+                            step, which calls of up to 20 480 pairs -- every vector here -- otherwise leave to k_ml_lines4
   BLSGPU_LS_HORNER_FORM=1   k_ml_horner: ten groups per wavefront; =2 k_ml_horner_wide: a product over 36 lanes
                             (default since round 4: k_ml_horner_fexp, a product per lane, and k_ml_merge_wide for merge
                             levels with few outputs -- BLSGPU_LS_MERGE_WIDE_MAX=0 keeps k_ml_merge for all of them)
@@ -19,12 +21,13 @@ import os
 
 import pytest
 
-from conftest import cat
+from conftest import cat, engine_with_env
 from test_gpu_linestream import EDGE, _spliced, flags
 
 pytestmark = pytest.mark.gpu
 
 FORMS = {
+    "point_chains_on_lane_pairs": ({"BLSGPU_LS_QUAD_MAX": "0"}, True),                       # k_ml_lines2 at these sizes
     "lines_one_pair_per_lane": ({"BLSGPU_LS_LINES_FORM": "1"}, True),
     "horner_ten_groups_per_wavefront": ({"BLSGPU_LS_HORNER_FORM": "1"}, True),
     "horner_product_over_36_lanes": ({"BLSGPU_LS_HORNER_FORM": "2"}, True),                # round 3's default
@@ -41,16 +44,7 @@ def form_engine(name):
     from bls_py import _native
     if name not in _cache:
         env, force_ls = FORMS[name]
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            e = _native.Engine(0)
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    del os.environ[k]
-                else:
-                    os.environ[k] = v
+        e = engine_with_env(env)
         if force_ls:
             e.set_ls_threshold(1, 1)          # every multi-pairing asks for the line-stream kernels
         _cache[name] = e

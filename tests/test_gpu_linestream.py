@@ -8,7 +8,7 @@ import os
 
 import pytest
 
-from conftest import GOLDEN, cat
+from conftest import GOLDEN, cat, engine_with_env
 
 pytestmark = pytest.mark.gpu
 
@@ -17,11 +17,15 @@ def flags(v):
     return bytes(int(b) for pr in v["inf"] for b in pr)
 
 
-@pytest.fixture(scope="module")
-def ls():
+# The point chains have two forms chosen by the size of the call (csrc/blsgpu_api.hip launch_miller_ls): up to
+# BLSGPU_LS_QUAD_MAX = 20 480 pairs one pair per lane QUAD (k_ml_lines4), above it one pair per lane PAIR (k_ml_lines2 -- the
+# kernel of bench.py's 524 800-pair step).  Every test below that takes `ls` runs once per form: "lane_pairs" creates the
+# context with BLSGPU_LS_QUAD_MAX=0, so k_ml_lines2's own flagging path (Q flagged / off the twist / final Z = 0 behind
+# sp::tangent_step) meets the edge and degenerate vectors at these sizes too.
+@pytest.fixture(scope="module", params=["lane_quads", "lane_pairs"])
+def ls(request):
     """an engine of its own whose every multi-pairing runs the line-stream kernels"""
-    from bls_py import _native
-    e = _native.Engine(0)
+    e = engine_with_env({"BLSGPU_LS_QUAD_MAX": "0"} if request.param == "lane_pairs" else {})
     e.set_ls_threshold(1, 1)
     return e
 
@@ -132,8 +136,10 @@ def test_chunking_and_merge_levels(golden, seeded_pairs, teams):
     assert e.pairing_multi(g1, g2, 1025).hex() == golden("pairing.json")["seeded"]["1025"]["out"]
     # ragged groups: 5 groups of 205
     out = e.pairing_multi_batch(g1, g2, 205, 5)
-    e.set_ls_threshold(None)
-    assert out == e.pairing_multi_batch(g1, g2, 205, 5)
+    vm = engine_with_env({"BLSGPU_FEXP_WIDE": "0"})       # the wavefront VM end to end (its own final exponentiation too)
+    vm.set_ls_threshold(None)
+    vm.set_fexp_team_threshold(None)
+    assert out == vm.pairing_multi_batch(g1, g2, 205, 5)
 
 
 def test_full_size_reference_digests(ls, engine):
@@ -170,11 +176,11 @@ def test_miller_product_partials_compose(ls, seeded_pairs, golden):
     assert bytes(out.cpu().numpy()).hex() == golden("pairing.json")["seeded"]["1025"]["out"]
 
 
-def test_small_groups_one_accumulator_per_group(golden, seeded_pairs, oracle):
+@pytest.mark.parametrize("chains", ["lane_quads", "lane_pairs"])
+def test_small_groups_one_accumulator_per_group(golden, seeded_pairs, oracle, chains):
     """k_ml_small: batches of groups of 1, 2, 3, 7 and 27 pairs (threshold verifies, single signatures), with degenerate
     pairs spliced in, against the oracle group by group"""
-    from bls_py import _native
-    e = _native.Engine(0)
+    e = engine_with_env({"BLSGPU_LS_QUAD_MAX": "0"} if chains == "lane_pairs" else {})
     e.set_ls_threshold(1, 1 << 30)                     # every group is "small"
     a, b, inf = _spliced(golden, seeded_pairs, count=220, every=13)
     n = len(a) // 96
@@ -191,6 +197,21 @@ def test_small_groups_one_accumulator_per_group(golden, seeded_pairs, oracle):
     assert e.pairing_multi(g1[:96 * 65], g2[:192 * 65], 65).hex() == golden("pairing.json")["seeded"]["65"]["out"]
 
 
+def test_default_selection_above_the_quad_threshold_meets_degenerate_pairs(engine, golden, seeded_pairs, oracle):
+    """DEFAULT thresholds, one call of 64 x 333 = 21 312 pairs (> BLSGPU_LS_QUAD_MAX = 20 480: the point chains run on
+    k_ml_lines2) in which every 333-pair run carries the six spliced degenerate picks: 384 flagged pairs among ordinary
+    ones, rewritten by k_ml_lines_exact.  The multi-pairing of 64 copies of a batch is the batch's value to the 64th
+    power; the batch's value is the oracle's (pinned to the reference's vectors).  Also as 64 groups of a batch call."""
+    a, b, inf = _spliced(golden, seeded_pairs)
+    n = len(a) // 96
+    assert n == 333
+    one = oracle.pairing_multi(a, b, n, threads=8, inf=inf)
+    k = 64
+    assert k * n > 20480
+    assert engine.pairing_multi(a * k, b * k, n * k, inf * k) == oracle.fq12_pow(one, k)
+    assert engine.pairing_multi_batch(a * k, b * k, n, k, inf * k) == one * k
+
+
 def test_default_selection_for_a_batch_of_two_pair_verifications(engine, seeded_pairs, oracle):
     """10 000 groups of 2 pairs (BASELINE configs[3]'s verifies) take the small-group line-stream kernels by default:
     every 97th group against the oracle, and the whole output against the VM kernels"""
@@ -202,8 +223,9 @@ def test_default_selection_for_a_batch_of_two_pair_verifications(engine, seeded_
     out = engine.pairing_multi_batch(a, b, 2, groups)
     for g in range(0, groups, 97):
         assert out[576 * g:576 * (g + 1)] == oracle.pairing_multi(a[96 * 2 * g:96 * 2 * (g + 1)], b[192 * 2 * g:192 * 2 * (g + 1)], 2), g
-    vm = _native.Engine(0)
+    vm = engine_with_env({"BLSGPU_FEXP_WIDE": "0"})       # the wavefront VM end to end: Miller kernels AND its own final exponentiation
     vm.set_ls_threshold(None)
+    vm.set_fexp_team_threshold(None)
     assert vm.pairing_multi_batch(a, b, 2, groups) == out
 
 
@@ -228,7 +250,7 @@ def test_many_single_pair_groups_by_default(engine, seeded_pairs, oracle):
     for g in (0, 1, 1024, 1025, 39999):
         assert out[576 * g:576 * (g + 1)] == oracle.pairing_multi(a[96 * g:96 * (g + 1)], b[192 * g:192 * (g + 1)], 1), g
     assert out[:576 * 1025] == out[576 * 1025:576 * 2050]           # the inputs repeat with period 1025
-    vm = _native.Engine(0)
+    vm = engine_with_env({"BLSGPU_FEXP_WIDE": "0"})       # (an independent path: no register kernel anywhere in it)
     vm.set_ls_threshold(None)
     vm.set_fexp_team_threshold(None)
     assert vm.pairing_multi_batch(a[:96 * 3000], b[:192 * 3000], 1, 3000) == out[:576 * 3000]

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Randomised parity soak of the round-3 register kernels (GPU box): the line-stream multi-pairing forced for every size
-(k_ml_lines2 / k_ml_lines4 -> k_ml_lines_exact -> k_ml_accum -> k_ml_merge / k_ml_merge_wide -> k_ml_horner_fexp), the small-group form
+(point chains: k_ml_lines4 on lane quads -- what calls of these sizes take by default -- or, on the QUAD_MAX = 0 axis,
+k_ml_lines2 on lane pairs, the kernel of bench.py's step; then k_ml_lines_exact -> k_ml_accum -> k_ml_merge / k_ml_merge_wide -> k_ml_horner_fexp), the small-group form
 (k_ml_small) and the final exponentiation six lanes per result (k_fexp_team) or one per wavefront (k_fexp_wide, fused
 with the Horner kernel where the call ends in it), on random subsets of the seeded pairs with the degenerate inputs of
 tools/soak_parity.py sprinkled in (zero coordinates, off-twist points, low-order points, flags), random chunking, every
-result against the CPU oracle.  usage: python tools/soak_linestream.py [trials]"""
+result against the CPU oracle.  usage: python tools/soak_linestream.py [trials] [pairs|quads]  (default: both forms at random)"""
 import json
 import os
 import random
@@ -18,6 +19,11 @@ for p in (os.path.join(ROOT, "python-bls_amd"), os.path.join(ROOT, "oracle")):
 
 def main():
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    only_chains = {"pairs": 0, "quads": None}.get(sys.argv[2], "bad") if len(sys.argv) > 2 else None
+    if only_chains == "bad":
+        sys.exit("second argument: pairs | quads")
+    if len(sys.argv) > 2 and sys.argv[2] == "quads":
+        only_chains = "default"
     import oracle as O
     from bls_py import _native
     O.build()
@@ -66,10 +72,15 @@ def main():
 
     engines = {}
 
-    def engine(min_group, teams, fexp):
-        key = (min_group, teams, fexp)
+    def engine(min_group, teams, fexp, quad_max):
+        key = (min_group, teams, fexp, quad_max)
         if key not in engines:
+            if quad_max is None:
+                os.environ.pop("BLSGPU_LS_QUAD_MAX", None)
+            else:
+                os.environ["BLSGPU_LS_QUAD_MAX"] = str(quad_max)       # read at context creation (csrc/blsgpu_api.hip)
             e = _native.Engine(0)
+            os.environ.pop("BLSGPU_LS_QUAD_MAX", None)
             e.set_ls_threshold(1, min_group)
             e.set_ls_teams(teams)
             e.set_fexp_team_threshold(fexp)
@@ -80,10 +91,12 @@ def main():
     for t in range(trials):
         rate = rng.choice([0.0, 0.05, 0.3, 1.0])
         fexp = rng.choice([1, None])
+        quad_max = rng.choice([0, None]) if only_chains is None else (None if only_chains == "default" else only_chains)
+        form = "lane pairs" if quad_max == 0 else "lane quads"
         if t % 2 == 0:                                  # one multi-pairing through the per-line products
             n = rng.choice([1, 2, 5, 16, 17, 63, 64, 65, 200, 257, 600, 1025])
             a, b, f = pick(n, rate)
-            e = engine(1, rng.choice([1, 300, 5000, 10 ** 9]), fexp)
+            e = engine(1, rng.choice([1, 300, 5000, 10 ** 9]), fexp, quad_max)
             got = e.pairing_multi(a, b, n, f)
             ok = got == O.pairing_multi(a, b, n, threads=16, inf=f)
             what = "one call"
@@ -91,14 +104,14 @@ def main():
             gsz, groups = rng.choice([(1, 40), (2, 33), (3, 21), (5, 17), (23, 9), (40, 7), (67, 5), (130, 3)])
             n = gsz * groups
             a, b, f = pick(n, rate)
-            e = engine(rng.choice([1, 1 << 30]), rng.choice([1, 2000, 10 ** 9]), fexp)
+            e = engine(rng.choice([1, 1 << 30]), rng.choice([1, 2000, 10 ** 9]), fexp, quad_max)
             got = e.pairing_multi_batch(a, b, gsz, groups, f)
             want = b"".join(O.pairing_multi(a[96 * gsz * g:96 * gsz * (g + 1)], b[192 * gsz * g:192 * gsz * (g + 1)], gsz, threads=16,
                                             inf=f[2 * gsz * g:2 * gsz * (g + 1)]) for g in range(groups))
             ok = got == want
             what = "%d x %d" % (groups, gsz)
         bad += 0 if ok else 1
-        print("trial %d %s pairs %d degenerate %.2f fexp-team %s %s  (%.0f s)" % (t, what, n, rate, fexp, "ok" if ok else "MISMATCH", time.time() - t0), flush=True)
+        print("trial %d %s pairs %d degenerate %.2f fexp-team %s chains on %s %s  (%.0f s)" % (t, what, n, rate, fexp, form, "ok" if ok else "MISMATCH", time.time() - t0), flush=True)
     print("line-stream soak: %d trials, %d mismatches" % (trials, bad))
     sys.exit(1 if bad else 0)
 
