@@ -80,6 +80,11 @@ int blsgpu_ctx_trim(blsgpu_ctx *ctx);
  * latency-oriented one (one pair per wavefront).  Default 4096; 0 = always the
  * throughput kernel.  Results are identical either way. */
 int blsgpu_ctx_set_mp_threshold(blsgpu_ctx *ctx, size_t pairs);
+/* Calls of at most `pairs` pairs (below the line-stream threshold) run the WIDE Miller loop (csrc/blsgpu_mlw.hip): one pair
+ * per workgroup of two wavefronts with a field product per lane -- the loop of fq_miller_loop (fields_t.py:1091-1111) at
+ * the depth of one wavefront's instruction stream, the latency form for BLS.verify of a few signatures
+ * (bls.py:197-201).  Default 2048; 0 = never (the wavefront-VM kernels).  Results are identical either way. */
+int blsgpu_ctx_set_miller_wide_max(blsgpu_ctx *ctx, size_t pairs);
 /* The throughput kernel runs three pairs per wavefront from `pairs` pairs per call on and two pairs per
  * wavefront below (a call of a few thousand pairs fills the chip with teams of two and each finishes sooner).
  * 0 = always three; (size_t)-1 = the measured schedule (default: two up to ~8.7 k pairs and in the pockets

@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libblsgpu.so")
 
 SYMBOLS = (
     "blsgpu_version", "blsgpu_last_error", "blsgpu_ctx_create", "blsgpu_ctx_destroy",
-    "blsgpu_ctx_reserve", "blsgpu_ctx_set_mp_threshold", "blsgpu_pairing_multi", "blsgpu_pairing_multi_dev",
+    "blsgpu_ctx_reserve", "blsgpu_ctx_set_mp_threshold", "blsgpu_ctx_set_miller_wide_max", "blsgpu_pairing_multi", "blsgpu_pairing_multi_dev",
     "blsgpu_miller_product_dev", "blsgpu_final_exp_product_dev", "blsgpu_final_exp",
     "blsgpu_timing_enable", "blsgpu_timing_read",
     "blsgpu_g1_msm", "blsgpu_g2_msm", "blsgpu_g1_msm_dev", "blsgpu_g2_msm_dev",
@@ -64,6 +64,7 @@ def load_library(path=None):
         L.blsgpu_ctx_reserve.argtypes = [vp, sz]
         L.blsgpu_ctx_set_mp_threshold.argtypes = [vp, sz]
         L.blsgpu_ctx_set_mp3_threshold.argtypes = [vp, sz]
+        L.blsgpu_ctx_set_miller_wide_max.argtypes = [vp, sz]
         L.blsgpu_ctx_set_ls_threshold.argtypes = [vp, sz, sz]
         L.blsgpu_ctx_set_ls_teams.argtypes = [vp, sz]
         L.blsgpu_ctx_set_bulk_event.argtypes = [vp, vp]
@@ -142,6 +143,10 @@ class Engine:
     def set_mp_threshold(self, pairs):
         """Batches >= pairs use the throughput kernel (several pairs per wavefront)."""
         self._check(self.lib.blsgpu_ctx_set_mp_threshold(self.h, pairs), "blsgpu_ctx_set_mp_threshold")
+
+    def set_miller_wide_max(self, pairs):
+        """Calls of at most `pairs` pairs run the wide Miller loop (one pair per two-wavefront workgroup); 0: never."""
+        self._check(self.lib.blsgpu_ctx_set_miller_wide_max(self.h, pairs), "blsgpu_ctx_set_miller_wide_max")
 
     def set_mp3_threshold(self, pairs):
         """Throughput kernel: three pairs per wavefront from `pairs` pairs per call on, two below."""

@@ -18,6 +18,7 @@
 #include "blsgpu_ml.hip"
 #include "blsgpu_fexp.hip"
 #include "blsgpu_fexpw.hip"
+#include "blsgpu_mlw.hip"
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
 
@@ -56,6 +57,7 @@ struct blsgpu_ctx {
     uint32_t* d_out = nullptr;         // 576-byte result staging
     uint32_t* d_degen = nullptr;       // [0] count, [1 ..] block indices of degenerate pairs (k_miller_slow's work list)
     size_t degen_cap = 0;
+    size_t miller_wide_max = 2048;     // calls of at most this many pairs run the wide Miller loop (blsgpu_mlw.hip: one pair per two-wavefront workgroup, a product per lane); 0: never
     size_t mp_threshold = 4096;        // pairs from which k_miller_mp is used
     size_t mp3_threshold = (size_t)-1; // ... with three pairs per wavefront from here on, two below; -1: the measured schedule
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
@@ -517,6 +519,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     blsgpu_ctx* c = new blsgpu_ctx();
     c->device = device;
     c->mp_threshold = default_mp_threshold();
+    if (const char* e = getenv("BLSGPU_MILLER_WIDE_MAX")) c->miller_wide_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MP3_THRESHOLD")) c->mp3_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_THRESHOLD")) c->ls_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_MIN_GROUP")) c->ls_min_group = (size_t)strtoull(e, nullptr, 10);
@@ -744,6 +747,12 @@ BLSGPU_EXPORT int blsgpu_ctx_set_ls_teams(blsgpu_ctx* c, size_t teams) {
     c->ls_teams = teams;
     return 0;
 }
+// Calls of at most `pairs` pairs (that do not take the line-stream kernels) run the wide Miller loop; 0: never.
+BLSGPU_EXPORT int blsgpu_ctx_set_miller_wide_max(blsgpu_ctx* c, size_t pairs) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    c->miller_wide_max = pairs;
+    return 0;
+}
 BLSGPU_EXPORT int blsgpu_ctx_set_mp3_threshold(blsgpu_ctx* c, size_t pairs) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
     c->mp3_threshold = pairs;
@@ -880,16 +889,23 @@ constexpr unsigned SLOW_GRID = 3072;           // three wavefronts per SIMD (166
 // per group, the group's product comes out of the Miller kernel)
 static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, const void* d_inf, size_t gsz, size_t groups, bool one_per_block,
                          uint32_t* d_partials, hipStream_t st, size_t* bpg_out, int team = 0) {
-    const bool mp = team ? true : (!one_per_block && use_mp(c, gsz * groups));
+    // a few pairs: one pair per two-wavefront workgroup with a product per lane (blsgpu_mlw.hip), every pair its own partial
+    // (where the one-pair-per-wavefront k_miller ran: calls below the throughput kernels' threshold)
+    const bool wide = !team && gsz * groups <= c->miller_wide_max && !use_mp(c, gsz * groups);
+    const bool mp = team ? true : (!wide && !one_per_block && use_mp(c, gsz * groups));
     const bool mp2 = team ? team == 2 : (mp && use_mp2(c, gsz * groups));   // a few thousand pairs: teams of two fill the chip
-    const size_t per_block = one_per_block ? 1 : (mp ? (mp2 ? (size_t)2 : (size_t)BLSVM_MP_G) : (size_t)MILLER_WAVES);
+    const size_t per_block = (one_per_block || wide) ? 1 : (mp ? (mp2 ? (size_t)2 : (size_t)BLSVM_MP_G) : (size_t)MILLER_WAVES);
     size_t bpg = (gsz + per_block - 1) / per_block;
     *bpg_out = bpg;
     if (bpg * groups > 0x7FFFFFFFull) return fail(-EINVAL, "batch too large");
     if (bpg * groups + 2 > c->degen_cap) return fail(-ENOMEM, "work list too small");
     blsgpu::DegenList dg{c->d_degen, c->d_degen + 1, (const uint8_t*)d_inf};
     HIP_TRY(hipMemsetAsync(c->d_degen, 0, sizeof(uint32_t), st));
-    if (mp2) {
+    if (wide) {
+        KernelTimer kt(c, st, 0);
+        hipLaunchKernelGGL(blsgpu::mlw::k_miller_wide, dim3((unsigned)(bpg * groups)), dim3(128), 0, st, (const uint32_t*)d_g1,
+                           (const uint32_t*)d_g2, (uint32_t)(gsz * groups), d_partials, dg);
+    } else if (mp2) {
         KernelTimer kt(c, st, 0);
         hipLaunchKernelGGL(blsgpu::k_miller_mp<2>, dim3((unsigned)(bpg * groups)), dim3(64), (size_t)blsgpu::MP_TEAM_BYTES, st, c->tabs,
                            (const uint32_t*)d_g1, (const uint32_t*)d_g2, (uint32_t)gsz, (uint32_t)bpg, d_partials, dg);

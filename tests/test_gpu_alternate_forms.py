@@ -8,6 +8,7 @@ creation (csrc/blsgpu_api.hip), so each gets the reference's vectors.
   BLSGPU_LS_HORNER_FORM=1   k_ml_horner: ten groups per wavefront; =2 k_ml_horner_wide: a product over 36 lanes
                             (default since round 4: k_ml_horner_fexp, a product per lane, and k_ml_merge_wide for merge
                             levels with few outputs -- BLSGPU_LS_MERGE_WIDE_MAX=0 keeps k_ml_merge for all of them)
+  BLSGPU_MILLER_WIDE_MAX=0  small calls on the wavefront VM's k_miller (four pairs per workgroup + product tree) instead of k_miller_wide
   BLSGPU_VM_EXACT_LANES=0   degenerate blocks of the wavefront-VM kernels recomputed by k_miller_slow
                             (default: k_ml_lines_exact in block mode + k_ml_small in list mode)
   BLSGPU_TEST_LS_NOMEM=1    test hook: launch_miller_ls reports -ENOMEM before touching the device, the call must go
@@ -34,6 +35,7 @@ FORMS = {
     "merge_levels_six_lanes_per_value": ({"BLSGPU_LS_MERGE_WIDE_MAX": "0"}, True),          # k_ml_merge for every level
     "both_old_forms": ({"BLSGPU_LS_LINES_FORM": "1", "BLSGPU_LS_HORNER_FORM": "1"}, True),
     "vm_slow_program_for_degenerate_blocks": ({"BLSGPU_VM_EXACT_LANES": "0"}, False),
+    "small_calls_on_the_wavefront_vm": ({"BLSGPU_MILLER_WIDE_MAX": "0"}, False),              # k_miller: round 4's default below 4096 pairs
     "line_stream_workspace_unavailable": ({"BLSGPU_TEST_LS_NOMEM": "1"}, True),
     "workgroups_of_64_threads": ({"BLSGPU_WG256_MAX_WAVES": "0"}, True),                    # round 3's launch shape for every size
 }

@@ -57,11 +57,14 @@ DEGEN = ["ord13", "ord13_neg", "ord13_p_zero", "ord13_px_zero", "ord13_in_team",
          "flag_on_off_curve", "pflag_only", "all_kinds"]
 
 
-KERNELS = {"k_miller": (1 << 30, 2 ** 64 - 1), "k_miller_mp<3>": (0, 0), "k_miller_mp<2>": (0, 1 << 30)}
+# (mp threshold, mp3 threshold, wide maximum): k_miller_wide (round 5: one pair per two-wavefront workgroup, a product per lane,
+# csrc/blsgpu_mlw.hip) is what calls of up to 2048 pairs take by default; k_miller is the wavefront VM's one-pair-per-wavefront form
+KERNELS = {"k_miller": (1 << 30, 2 ** 64 - 1, 0), "k_miller_wide": (1 << 30, 2 ** 64 - 1, 1 << 30),
+           "k_miller_mp<3>": (0, 0, 2048), "k_miller_mp<2>": (0, 1 << 30, 2048)}
 
 
 class kernel_choice:
-    """force one of the three Miller kernels whatever the batch size (thresholds of include/blsgpu.h)"""
+    """force one of the four Miller kernels whatever the batch size (thresholds of include/blsgpu.h)"""
 
     def __init__(self, engine, which):
         self.engine, self.thr = engine, KERNELS[which]
@@ -69,10 +72,12 @@ class kernel_choice:
     def __enter__(self):
         self.engine.set_mp_threshold(self.thr[0])
         self.engine.set_mp3_threshold(self.thr[1])
+        self.engine.set_miller_wide_max(self.thr[2])
 
     def __exit__(self, *a):
         self.engine.set_mp_threshold(4096)
         self.engine.set_mp3_threshold(2 ** 64 - 1)              # back to the measured schedule
+        self.engine.set_miller_wide_max(2048)
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
@@ -80,8 +85,8 @@ class kernel_choice:
 def test_degenerate_pairs(engine, golden, name, kernel):
     """Inputs on which the reference's special cases decide (low-order, off-curve, zero, flagged:
     tests/golden/pairing_degenerate.json, reference-generated).  The fast kernels must notice and
-    k_miller_slow must reproduce the reference's bytes -- through k_miller (one pair per wavefront) and
-    through k_miller_mp with three and with two pairs per wavefront."""
+    k_miller_slow must reproduce the reference's bytes -- through k_miller (one pair per wavefront), k_miller_wide (one pair
+    per two-wavefront workgroup) and k_miller_mp with three and with two pairs per wavefront."""
     v = golden("pairing_degenerate.json")["cases"][name]
     n = len(v["g1"])
     with kernel_choice(engine, kernel):
@@ -91,7 +96,7 @@ def test_degenerate_pairs(engine, golden, name, kernel):
 @pytest.mark.parametrize("kernel", list(KERNELS))
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 64, 65, 1025])
 def test_every_kernel_on_ordinary_batches(engine, golden, seeded_pairs, oracle, kernel, n):
-    """the three Miller kernels give the same bytes on ordinary batches of every raggedness"""
+    """the four Miller kernels give the same bytes on ordinary batches of every raggedness"""
     g1, g2 = seeded_pairs
     a, b = g1[:96 * n], g2[:192 * n]
     want = bytes.fromhex(golden("pairing.json")["seeded"]["1025"]["out"]) if n == 1025 else oracle.pairing_multi(a, b, n, threads=8)
@@ -338,7 +343,8 @@ def test_batched_independent_pairings(engine, golden, seeded_pairs, oracle):
     assert engine.final_exp_batch(ins) == b"".join(bytes.fromhex(r["out"]) for r in recs) * 4
 
 
-@pytest.mark.parametrize("gsz,groups,kernel", [(25, 5, "k_miller_mp<3>"), (25, 5, "k_miller_mp<2>"), (25, 5, "k_miller"),
+@pytest.mark.parametrize("gsz,groups,kernel", [(25, 5, "k_miller_mp<3>"), (25, 5, "k_miller_mp<2>"), (25, 5, "k_miller"), (25, 5, "k_miller_wide"),
+                                               (205, 5, "k_miller_wide"), (64, 16, "k_miller_wide"),
                                                (205, 5, "k_miller_mp<3>"), (205, 5, "k_miller_mp<2>"), (1025, 3, "k_miller_mp<3>"),
                                                (1025, 3, "k_miller_mp<2>"), (64, 16, "k_miller")])
 def test_batched_large_groups(engine, seeded_pairs, gsz, groups, kernel):
