@@ -459,6 +459,7 @@ def run_pairing(env, args):
             shard[k].final_batch_dev(gath[k], world, B, outs[k], st)
 
     dt, step_ms, ktimes = timed_steps(env, args, step, engs, streams)
+    ws_after_steps = {"all_contexts": sum(e.workspace_bytes()["total"] for e in engs), "contexts": len(engs), "one_context": eng.workspace_bytes()}
     results = [bytes(o.cpu().numpy()) for o in outs[:min(S, args.steps)]]
     assert all(r == results[0] for r in results), "streams disagree"
     per = [results[0][576 * v:576 * (v + 1)] for v in range(B)]
@@ -501,7 +502,7 @@ def run_pairing(env, args):
     if rank == 0 and not args.no_latency:
         # the throughput-against-batch curve of ONE call (the headline needs 524 800 pairs in flight per step): the literal
         # configs among them -- 1025 pairs = configs[1], 8192 = the per-GPU shard of configs[2], 65 536 = configs[2] on one GPU
-        for m in (1, 1025, 4096, 8192, 16384, 65536, 262144, 1048576):
+        for m in (1, 2, 5, 64, 512, 1025, 2048, 4096, 8192, 16384, 65536, 262144, 1048576):
             reps = (m + len(g1) // 96 - 1) // (len(g1) // 96)
             x1, x2 = env.up((g1 * reps)[:96 * m]), env.up((g2 * reps)[:192 * m])
             eng.reserve(m)
@@ -607,8 +608,10 @@ def run_pairing(env, args):
                          "degenerate_pair_kernel_ms_per_step": sum(slow_ms) / max(1, launches),
                          "final_exp_kernel_ms_avg_overlapped": (sum(fexp_ms) / len(fexp_ms)) if fexp_ms else None,
                          "one_step_alone_kernel_ms": solo,
-                         "hbm_workspace_bytes": {"all_contexts": sum(e.workspace_bytes()["total"] for e in engs),
-                                                 "contexts": len(engs), "one_context": eng.workspace_bytes()},
+                         # the step's working set (sampled right after the timed steps); the later probes of this run (single
+                         # calls of up to 2^20 pairs, the other configs) grow context 0 further: its high-water mark beside it
+                         "hbm_workspace_bytes": ws_after_steps,
+                         "hbm_workspace_bytes_high_water_after_all_probes": {"context_0": eng.workspace_bytes()["total"]},
                          "whole_step_TMACs": (MAC_PER_PAIRING * n + MAC_PER_FINAL_EXP) * B * world / (dt / args.steps) / 1e12,
                          "step_latency_ms_avg": sum(step_ms) / len(step_ms), "step_latency_ms_min": step_ms[0],
                          "hbm_GBps_algorithmic": alg_bytes / (miller_avg * 1e-3) / 1e9,
@@ -687,7 +690,63 @@ def secondary(env, args, eng, gen1, gen2):
         if name == "c4":
             out[name].update(combine_ms=ln["combine_s"] * 1e3, verify_ms=ln["verify_s"] * 1e3)
     out["verify_pipeline"] = run_verify_pipeline(env, eng)
+    out["verify_single_signature"] = run_verify_single(env, eng)
     return out
+
+
+def run_verify_single(env, eng):
+    """BLS.verify of ONE signature (bls.py:153-201): hash the one message hash to G2 (ec.py:528-550), then the two-pair
+    multi-pairing e(-G1, sig) e(pk, H(m)) and its final exponentiation -- blsgpu_verify_pipeline_dev on device-resident
+    buffers, and the host-buffer entry (one upload, 576 bytes back: PCIe and the host's launch path included).  Latency, not
+    throughput: the call is a chain of a few wavefronts (csrc/blsgpu_mlw.hip, blsgpu_fexpw.hip)."""
+    torch = env.torch
+    from bls_py import hostmath as H
+    from bls_py.keys import PrivateKey
+    sk = PrivateKey(int.from_bytes(hashlib.sha256(b"single").digest(), "big") % (N_ORDER - 1) + 1)
+    msg = b"one message"
+    sig = sk.sign(msg)
+    mh = hashlib.sha256(msg).digest()
+    pk = H.g1_affine_bytes(sig.aggregation_info.public_keys[0].value.to_affine()._aff())
+    neg_g1 = H.g1_affine_bytes(H.jac_to_affine(H.F1, H.jac_mul(H.F1, H.aff_to_jac(H.F1, H.G1_GEN), N_ORDER - 1)))
+    sig_b = H.g2_affine_bytes(sig.value.to_affine()._aff())
+    d_g1 = env.up(neg_g1 + pk)
+    d_g2 = env.up(sig_b + bytes(192))
+    d_mh = env.up(mh)
+    d_h = torch.zeros(192, dtype=torch.uint8, device=env.dev)
+    d_out = torch.zeros(576, dtype=torch.uint8, device=env.dev)
+    stream = torch.cuda.Stream(device=env.dev)
+    st = stream.cuda_stream
+    lib, h = eng.lib, eng.h
+
+    def timed(fn, reps=6):
+        fn(); stream.synchronize()
+        best = 1e9
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream); fn(); b.record(stream); stream.synchronize()
+            best = min(best, a.elapsed_time(b))
+        return best
+    ms_all = timed(lambda: lib.blsgpu_verify_pipeline_dev(h, d_g1.data_ptr(), d_g2.data_ptr(), d_mh.data_ptr(), 1, None, None, 0, d_out.data_ptr(), st))
+    one = (1).to_bytes(48, "big") + bytes(48 * 11)
+    if bytes(d_out.cpu().numpy()) != one:
+        raise SystemExit("verify_single_signature: the signature did not verify -- bench invalid")
+    ms_hash = timed(lambda: lib.blsgpu_hash_to_g2_dev(h, d_mh.data_ptr(), 1, d_h.data_ptr(), st))
+    ms_pair = timed(lambda: eng.pairing_multi_dev(d_g1.data_ptr(), d_g2.data_ptr(), 2, d_out.data_ptr(), st))
+    t = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        got = eng.verify_pipeline(neg_g1, sig_b, mh, 1, keys_affine=pk)
+    wall = (time.perf_counter() - t) / reps
+    if got != one:
+        raise SystemExit("verify_single_signature (host buffers): the signature did not verify -- bench invalid")
+    # a tampered message must NOT verify
+    bad = eng.verify_pipeline(neg_g1, sig_b, hashlib.sha256(b"another message").digest(), 1, keys_affine=pk)
+    if bad == one:
+        raise SystemExit("verify_single_signature: a wrong message verified -- bench invalid")
+    return {"value": ms_all, "unit": "ms", "higher_is_better": False, "check": "result == Fq12 one; a different message does not verify",
+            "workload": "BLS.verify of one signature on device-resident buffers: hash one message to G2 + two-pair multi-pairing + final exponentiation (blsgpu_verify_pipeline_dev)",
+            "hash_to_g2_of_one_message_ms": ms_hash, "two_pair_multi_pairing_ms": ms_pair,
+            "host_buffer_entry_wall_ms": wall * 1e3}
 
 
 def run_verify_pipeline(env, eng, B=256, n=1024):

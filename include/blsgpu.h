@@ -83,7 +83,7 @@ int blsgpu_ctx_set_mp_threshold(blsgpu_ctx *ctx, size_t pairs);
 /* Calls of at most `pairs` pairs (below the line-stream threshold) run the WIDE Miller loop (csrc/blsgpu_mlw.hip): one pair
  * per workgroup of two wavefronts with a field product per lane -- the loop of fq_miller_loop (fields_t.py:1091-1111) at
  * the depth of one wavefront's instruction stream, the latency form for BLS.verify of a few signatures
- * (bls.py:197-201).  Default 2048; 0 = never (the wavefront-VM kernels).  Results are identical either way. */
+ * (bls.py:197-201).  Default 1536 (measured crossover against the wavefront-VM kernel, tools/miller_wide_probe.py); 0 = never (the wavefront-VM kernels).  Results are identical either way. */
 int blsgpu_ctx_set_miller_wide_max(blsgpu_ctx *ctx, size_t pairs);
 /* The throughput kernel runs three pairs per wavefront from `pairs` pairs per call on and two pairs per
  * wavefront below (a call of a few thousand pairs fills the chip with teams of two and each finishes sooner).

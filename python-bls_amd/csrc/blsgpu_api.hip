@@ -57,7 +57,7 @@ struct blsgpu_ctx {
     uint32_t* d_out = nullptr;         // 576-byte result staging
     uint32_t* d_degen = nullptr;       // [0] count, [1 ..] block indices of degenerate pairs (k_miller_slow's work list)
     size_t degen_cap = 0;
-    size_t miller_wide_max = 2048;     // calls of at most this many pairs run the wide Miller loop (blsgpu_mlw.hip: one pair per two-wavefront workgroup, a product per lane); 0: never
+    size_t miller_wide_max = 1536;     // calls of at most this many pairs run the wide Miller loop (blsgpu_mlw.hip: one pair per two-wavefront workgroup, a product per lane); 0: never
     size_t mp_threshold = 4096;        // pairs from which k_miller_mp is used
     size_t mp3_threshold = (size_t)-1; // ... with three pairs per wavefront from here on, two below; -1: the measured schedule
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method

@@ -66,15 +66,28 @@ __device__ __forceinline__ void st14(char* vf, uint32_t a, const int32_t* __rest
 #pragma unroll
     for (int j = 0; j < NL; j++) *reinterpret_cast<int32_t*>(p + 256 * j) = V[j];
 }
-// One step of a wavefront.  Column bound of fp28_dot2 (units of 2^56): every stored limb is below 2^28, an operand the sum of
-// two: 2 x (2 x 2) = 8, what 64 bits hold.
+// V[a], limb by limb
+__device__ __forceinline__ void rd1(int32_t* __restrict__ out, const char* vf, uint32_t a) {
+    const char* pa = vf + a;
+#pragma unroll
+    for (int j = 0; j < NL; j++) out[j] = *reinterpret_cast<const int32_t*>(pa + 256 * j);
+}
+// One step of a wavefront, in the three shapes the tables use (bits 8 - 9 of a program word): K products per lane; BS: every second
+// operand is one slot (its second address is ignored).  Column bound of fp28_dot2 (units of 2^56): every stored limb is below 2^28,
+// an operand the sum of two: 2 x (2 x 2) = 8, what 64 bits hold.
+template <int K, bool BS>
 __device__ __forceinline__ void wstep(char* vf, const Rec& r) {
-    int32_t A0[NL], B0[NL], A1[NL], B1[NL], p[NL], t[NL], V[NL];
+    int32_t A0[NL], B0[NL], p[NL], t[NL], V[NL];
     rd2(A0, vf, r.w[0]);
-    rd2(B0, vf, r.w[1]);
-    rd2(A1, vf, r.w[2]);
-    rd2(B1, vf, r.w[3]);
-    bls28::fp28_dot2(p, A0, B0, A1, B1);
+    if (BS) rd1(B0, vf, r.w[1] & 0xFFFFu); else rd2(B0, vf, r.w[1]);
+    if (K == 2) {
+        int32_t A1[NL], B1[NL];
+        rd2(A1, vf, r.w[2]);
+        if (BS) rd1(B1, vf, r.w[3] & 0xFFFFu); else rd2(B1, vf, r.w[3]);
+        bls28::fp28_dot2(p, A0, B0, A1, B1);
+    } else {
+        bls28::fp28_dot1(p, A0, B0);
+    }
 #pragma unroll
     for (int j = 0; j < NL; j++) {
         const int32_t u = p[j] + __builtin_amdgcn_update_dpp(0, p[j], 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
@@ -133,20 +146,27 @@ __global__ void __launch_bounds__(128) k_miller_wide(const uint32_t* __restrict_
         if (qd < 14u) st14(vf, dst + 4u * vr, V);
     }
     __syncthreads();
-    const uint8_t* prog = wave ? MLW_PROG_CHAIN : MLW_PROG_ACC;
+    // the wavefront's program: word pc + 2 is fetched (a scalar load) while step pc runs, the lanes' records of step pc + 1 as well
+    const uint32_t* prog = wave ? MLW_PROG_CHAIN : MLW_PROG_ACC;
     uint32_t pc = 0;
-    uint32_t knext = prog[0];
-    Rec rnext = load_rec(knext & 0x3Fu, lane);
+    uint32_t k1 = prog[0], k2 = prog[1];
+    Rec r1 = load_rec(k1 & 0x3Fu, lane);
 #pragma unroll 1
     for (uint32_t ph = 0; ph < (uint32_t)MLW_PHASES; ph++) {
 #pragma unroll 1
         while (true) {
-            const uint32_t k = knext;
-            const Rec r = rnext;
+            const uint32_t k = k1;
+            const Rec r = r1;
+            k1 = k2;
+            k2 = prog[pc + 2];
             pc++;
-            knext = prog[pc];                                          // (the generator appends one byte past the end)
-            rnext = load_rec(knext & 0x3Fu, lane);
-            if ((k & 0x3Fu) != (uint32_t)MLW_NOP) wstep(vf, r);
+            r1 = load_rec(k1 & 0x3Fu, lane);
+            if ((k & 0x3Fu) != (uint32_t)MLW_NOP) {
+                const uint32_t shape = (k >> 8) & 3u;
+                if (shape == 0u) wstep<2, false>(vf, r);
+                else if (shape == 1u) wstep<2, true>(vf, r);
+                else wstep<1, false>(vf, r);
+            }
             if (k & (uint32_t)MLW_LAST) break;
         }
         __syncthreads();

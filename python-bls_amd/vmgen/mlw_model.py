@@ -97,6 +97,10 @@ class Step:
     def __init__(self, name, outputs):
         self.name, self.outputs = name, outputs
         assert len(outputs) <= 16
+        # the shape the kernel specialises on: K products per lane (1 when no output has more than four), and whether every
+        # second operand is ONE slot (the sparse products: a line coefficient)
+        self.K = 1 if all(len(prods) <= 4 for _, _, prods in outputs) else 2
+        self.b_single = all(len(b) <= 1 for _, _, prods in outputs for _, b in prods)
         self.rec = []                              # per lane: (a1, a2, b1, b2, a3, a4, b3, b4, dst, scale)
         for g in range(16):
             if g < len(outputs):
@@ -107,7 +111,8 @@ class Step:
             for r in range(4):
                 ops = []
                 for t in range(2):
-                    p = prods[2 * r + t] if 2 * r + t < len(prods) else ([], [])
+                    i = self.K * r + t if t < self.K else None
+                    p = prods[i] if i is not None and i < len(prods) else ([], [])
                     for operand in p:
                         assert len(operand) <= 2
                         s = [_src(x) for x in operand] + [ZERO, ZERO]
@@ -280,12 +285,17 @@ KINDS += [_ch0[0], _ch0[1], _ch1[1], _ch0[2], _ch0[3]] + build_check()
 KIND = {s.name: i for i, s in enumerate(KINDS)}
 NOP = 0x3f
 LAST = 0x80                                        # flag on the last step of a phase
+# the routine a step kind runs (bits 8 - 9 of a program word): 0 two products per lane, 1 two products with one-slot second
+# operands, 2 one product per lane
+def variant_of(step):
+    return 2 if step.K == 1 else (1 if step.b_single else 0)
 
 
 def programs():
-    """(acc program, chain program): bytes, one per step; bit 7 = last step of its phase (the wavefronts meet at a barrier
-    after every phase), NOP | LAST = nothing to do in this phase.  Phase p: the chain wave runs iteration p of the loop
-    (p <= 62; lines into buffer p & 1), the accumulator wave iteration p - 1 (p >= 1)."""
+    """(acc program, chain program): one word per step -- bits 0 - 5 the kind, bit 7 = last step of its phase (the wavefronts meet
+    at a barrier after every phase), bits 8 - 9 the routine (variant_of); NOP | LAST = nothing to do in this phase.  Phase p: the
+    chain wave runs iteration p of the loop (p <= 62; lines into buffer p & 1), the accumulator wave iteration p - 1 (p >= 1) --
+    and in phase 0, where it has nothing to multiply yet, the test "Q on the twist"."""
     chord_at = [s for s, kind in LS.line_schedule() if kind == "c"]
     iters = LS.NX.bit_length() - 1
     acc, chain = [], []
@@ -294,14 +304,14 @@ def programs():
         if p >= 1:
             s = p - 1
             a = [KIND["SQR"], KIND["MUL%d0" % (s & 1)]] + ([KIND["MUL%d1" % (s & 1)]] if s in chord_at else [])
+        if p == 0:
+            a = [KIND["CK1"], KIND["CK2"]]
         if p < iters:
-            if p == 0:
-                c += [KIND["CK1"], KIND["CK2"]]
             c += [KIND["L1"], KIND["L2%d" % (p & 1)]]
             if p in chord_at:
                 c += [KIND["C1"], KIND["C2%d" % (p & 1)], KIND["C3"], KIND["C4"]]
         for prog, steps in ((acc, a), (chain, c)):
-            steps = steps or [NOP]
+            steps = [k | (variant_of(KINDS[k]) << 8) for k in steps] or [NOP]
             prog += steps[:-1] + [steps[-1] | LAST]
     return acc, chain
 

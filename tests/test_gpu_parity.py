@@ -58,9 +58,9 @@ DEGEN = ["ord13", "ord13_neg", "ord13_p_zero", "ord13_px_zero", "ord13_in_team",
 
 
 # (mp threshold, mp3 threshold, wide maximum): k_miller_wide (round 5: one pair per two-wavefront workgroup, a product per lane,
-# csrc/blsgpu_mlw.hip) is what calls of up to 2048 pairs take by default; k_miller is the wavefront VM's one-pair-per-wavefront form
+# csrc/blsgpu_mlw.hip) is what calls of up to 1536 pairs take by default; k_miller is the wavefront VM's one-pair-per-wavefront form
 KERNELS = {"k_miller": (1 << 30, 2 ** 64 - 1, 0), "k_miller_wide": (1 << 30, 2 ** 64 - 1, 1 << 30),
-           "k_miller_mp<3>": (0, 0, 2048), "k_miller_mp<2>": (0, 1 << 30, 2048)}
+           "k_miller_mp<3>": (0, 0, 1536), "k_miller_mp<2>": (0, 1 << 30, 1536)}
 
 
 class kernel_choice:
@@ -77,7 +77,7 @@ class kernel_choice:
     def __exit__(self, *a):
         self.engine.set_mp_threshold(4096)
         self.engine.set_mp3_threshold(2 ** 64 - 1)              # back to the measured schedule
-        self.engine.set_miller_wide_max(2048)
+        self.engine.set_miller_wide_max(1536)
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))

@@ -71,9 +71,10 @@ def test_step_formulas_against_the_line_stream_model():
 def test_programs_have_the_loop_shape():
     acc, chain = M.programs()
     assert sum(1 for k in acc if k & M.LAST) == sum(1 for k in chain if k & M.LAST) == 64
+    assert [k & 0x3f for k in acc[:2]] == [M.KIND["CK1"], M.KIND["CK2"]]      # the idle accumulator wave tests "Q on the twist"
     steps = lambda prog: [k & 0x3f for k in prog if k & 0x3f != M.NOP]
     assert sum(1 for k in steps(acc) if k == M.KIND["SQR"]) == 63
-    assert len(steps(acc)) == 63 + 68                                  # a squaring per iteration, a sparse product per line
+    assert len(steps(acc)) == 2 + 63 + 68                                  # a squaring per iteration, a sparse product per line
     assert sum(1 for k in steps(chain) if k == M.KIND["L1"]) == 63 and sum(1 for k in steps(chain) if k == M.KIND["C4"]) == 5
 
 
