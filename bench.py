@@ -629,10 +629,11 @@ def run_pairing(env, args):
         if projection:
             line["projected_8_gpu_step"] = projection
         if line_stream:
-            # the stage's kernels one by one; k_ml_accum also by the multiply-accumulates it EXECUTES (2 x 7 x 196
-            # v_mad_i64_i32 per line product per lane, six lanes; 68 lines per pair) against the measured rate of that
-            # instruction (profiles/r03_fp28_microbench.txt: 34.1 T/s at four wavefronts per SIMD)
-            exec_mads = 2 * 7 * 196 * 6 * LS_LINES * n * B
+            # the stage's kernels one by one; k_ml_accum also by the multiply-accumulates it EXECUTES (round 5: three sums of
+            # three products, 3 x 4 x 196 v_mad_i64_i32 per line product per lane -- 2 x 7 x 196 in rounds 3 - 4 --, six lanes;
+            # 68 lines per pair) against the measured rate of that instruction (profiles/r03_fp28_microbench.txt: 34.1 T/s at
+            # four wavefronts per SIMD)
+            exec_mads = 3 * 4 * 196 * 6 * LS_LINES * n * B
             line["roofline"]["stage_kernels_ms_avg"] = ls_avg
             line["roofline"]["k_ml_accum_executed_mad28_Tps"] = exec_mads / (ls_avg["k_ml_accum"] * 1e-3) / 1e12
             line["roofline"]["k_ml_accum_frac_of_mad_i64_i32_peak"] = exec_mads / (ls_avg["k_ml_accum"] * 1e-3) / 1e12 / PEAK_MAD28_T

@@ -15,8 +15,9 @@
 //   k_ml_accum   SIX LANES PER ACCUMULATOR (ten accumulators per wavefront): lane k holds the coefficient f_k of
 //                f = sum f_k w^k (Fq12 = Fq2[w]/(w^6 - xi)).  A team multiplies the line L of the pairs of its chunk
 //                into its accumulator: c_k = f_k l0 + F_{k-2} l2 + F_{k-3} l3 with F_i = f_i (i >= 0), xi f_{i+6}
-//                (i < 0) fetched from the team's lanes with ds_bpermute; each part of c_k is ONE sum of six products
-//                with one Montgomery reduction (fp28_dot6).  No squarings, no dependency between line indices.
+//                (i < 0) fetched from the team's lanes with ds_bpermute; the three Fq2 terms are summed lazily and taken
+//                Karatsuba-wise (round 5: three sums of three products, fp28_dot3, instead of two sums of six).  No
+//                squarings, no dependency between line indices.
 //   k_ml_small   groups of a few pairs: one team per group runs the whole loop f <- f^2 prod l on the same lines.
 //   k_ml_merge   dense products of the chunks' partial products (same lane layout).
 //   k_ml_horner_wide  f <- f^2 (before a tangent) ; f <- f M_L over the 68 per-line products of a group, a dense product
@@ -733,34 +734,9 @@ __device__ __forceinline__ void mul3(int32_t* __restrict__ re, int32_t* __restri
     bls28::fp28_dot6(re, X0.re, y0r, X0.nim, y0i, X1.re, y1r, X1.nim, y1i, X2.re, y2r, X2.nim, y2i);
     bls28::fp28_dot6(im, X0.re, y0i, X0.im, y0r, X1.re, y1i, X1.im, y1r, X2.re, y2i, X2.im, y2r);
 }
-// the same with the positions of the second and third term at run time: a LINE is f_0-term + w^jA + w^jB with
-// (jA, jB) = (2, 3) for the scaled lines of k_ml_lines2 and (3, 5) / (4, 5) for the reference's own line values
-// (k_ml_lines_exact: coefficient 0 in Fq, its imaginary part stored as zeros).  Column bound as mul3<0, 2, 3>: 2 + 3 + 3.
-__device__ __forceinline__ void fetch_rt(Xop& X, const Pub& P, const Team& t, uint32_t J) {
-    const uint32_t src = t.c >= J ? t.c - J : t.c + 6u - J;
-    const uint32_t addr = t.base4 + src * 4u;
-    const bool offer_xi = t.c + J >= 6u;                  // (the source chooses the form: see fetch<J>)
-    int32_t o[NL];
-#pragma unroll
-    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.xre[j] : P.re[j];
-    bperm14(X.re, o, addr);
-#pragma unroll
-    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.xim[j] : P.im[j];
-    bperm14(X.im, o, addr);
-#pragma unroll
-    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.nxim[j] : P.nim[j];
-    bperm14(X.nim, o, addr);
-}
-__device__ __forceinline__ void mul_line(int32_t* __restrict__ re, int32_t* __restrict__ im, const Pub& P, const Team& t, uint32_t jA, uint32_t jB,
-                                         const int32_t* y0r, const int32_t* y0i, const int32_t* y1r, const int32_t* y1i,
-                                         const int32_t* y2r, const int32_t* y2i) {
-    Xop X0, X1, X2;
-    fetch<0>(X0, P, t);
-    fetch_rt(X1, P, t, jA);
-    fetch_rt(X2, P, t, jB);
-    bls28::fp28_dot6(re, X0.re, y0r, X0.nim, y0i, X1.re, y1r, X1.nim, y1i, X2.re, y2r, X2.nim, y2i);
-    bls28::fp28_dot6(im, X0.re, y0i, X0.im, y0r, X1.re, y1i, X1.im, y1r, X2.re, y2i, X2.im, y2r);
-}
+// A LINE is f_0-term + w^jA + w^jB with (jA, jB) = (2, 3) for the scaled lines of k_ml_lines2 and (3, 5) / (4, 5) for the
+// reference's own line values (k_ml_lines_exact: coefficient 0 in Fq, its imaginary part stored as zeros); the sparse product
+// takes the positions at run time (mul_line_k3 below).
 // positions of line L of a pair whose flag byte is `flag` (0: scaled lines; else bit 0 set and bit 1 + c = chord c took the
 // reference's "vertical" branch)
 __device__ __forceinline__ void line_positions(uint32_t L, uint32_t flag, uint32_t& jA, uint32_t& jB) {
@@ -809,14 +785,66 @@ __device__ __forceinline__ void set_one(int32_t* __restrict__ fre, int32_t* __re
     for (int j = 0; j < NL; j++) { fre[j] = t.c == 0u ? one[j] : 0; fim[j] = 0; }
 }
 
+// ---- the sparse product f <- f l: Karatsuba over the lazily summed terms (round 5) -------------------------------------------
+// c = sum_j F_j y_j (three Fq2 terms) as  P1 = sum Xre yr,  P2 = sum Xim yi,  P3 = sum (Xre + Xim)(yr + yi):  re = P1 - P2,
+// im = P3 - P1 - P2 -- nine Fq products and THREE reductions (3 x fp28_dot3 = 2352 multiply-adds) against the twelve and two
+// (2 x fp28_dot6 = 2744) of rounds 3 - 4; the unreduced columns of P1 and P2 are never needed (reducing each sum by itself costs
+// one more reduction, 196, but no 64-bit column bookkeeping, and fewer operands are live than in fp28_dot6: 229 registers
+// against 238).  What it costs: the sums of the operand parts, two carry passes on the line's (yr + yi) for the column bound
+// of P3, and a carry pass on each part of the result (differences of reduced values).  Measured on the bench's step
+// (profiles/r05_accum_variants_ab.txt): k_ml_accum 22.3 -> 20.2 ms per 524 800 pairs -- the ratio of the two instruction
+// streams (3805 -> 3450), which DESIGN.md had argued away on a register estimate for two rounds.
+struct Pub2 { int32_t re[NL], im[NL], xre[NL], xim[NL]; };
+struct Xop2 { int32_t re[NL], im[NL]; };
+__device__ __forceinline__ void fetch2_rt(Xop2& X, const Pub2& P, const Team& t, uint32_t J) {
+    const uint32_t src = t.c >= J ? t.c - J : t.c + 6u - J;
+    const uint32_t addr = t.base4 + src * 4u;
+    const bool offer_xi = t.c + J >= 6u;                  // (the source chooses the form: see fetch<J>)
+    int32_t o[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.xre[j] : P.re[j];
+    bperm14(X.re, o, addr);
+#pragma unroll
+    for (int j = 0; j < NL; j++) o[j] = offer_xi ? P.xim[j] : P.im[j];
+    bperm14(X.im, o, addr);
+}
+// fre, fim: normalised digits (value in (-2q, 3q)); y: the line record's six parts
+__device__ __forceinline__ void mul_line_k3(int32_t* __restrict__ fre, int32_t* __restrict__ fim, const Team& t, uint32_t jA, uint32_t jB,
+                                            const int32_t (&y)[6][NL]) {
+    Pub2 P;
+#pragma unroll
+    for (int j = 0; j < NL; j++) { P.re[j] = fre[j]; P.im[j] = fim[j]; P.xre[j] = fre[j] - fim[j]; P.xim[j] = fre[j] + fim[j]; }
+    Xop2 X1, X2;
+    fetch2_rt(X1, P, t, jA);
+    fetch2_rt(X2, P, t, jB);
+    int32_t p1[NL], p2[NL], p3[NL];
+    // column bounds (units of 2^56; fp28_dot3 holds 8): P1 1 + 1 + 1, P2 1 + 2 + 2 (|xim| limbs below 2^29), P3 (2 x 2) + (2 x 1) + (2 x 1)
+    bls28::fp28_dot3(p1, P.re, y[0], X1.re, y[2], X2.re, y[4]);
+    bls28::fp28_dot3(p2, P.im, y[1], X1.im, y[3], X2.im, y[5]);
+    int32_t s0[NL], s1[NL], s2[NL], ys0[NL];
+    r28::F<0, 2> t1, t2;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        s0[j] = P.re[j] + P.im[j]; s1[j] = X1.re[j] + X1.im[j]; s2[j] = X2.re[j] + X2.im[j];
+        ys0[j] = y[0][j] + y[1][j]; t1.v[j] = y[2][j] + y[3][j]; t2.v[j] = y[4][j] + y[5][j];
+    }
+    const fe ys1 = r28::norm(t1), ys2 = r28::norm(t2);
+    bls28::fp28_dot3(p3, s0, ys0, s1, ys1.v, s2, ys2.v);
+    r28::F<1, 1> dr; r28::F<2, 1> di;
+#pragma unroll
+    for (int j = 0; j < NL; j++) { dr.v[j] = p1[j] - p2[j]; di.v[j] = p3[j] - p1[j] - p2[j]; }
+    const fe nr = r28::norm(dr), ni = r28::norm(di);
+#pragma unroll
+    for (int j = 0; j < NL; j++) { fre[j] = nr.v[j]; fim[j] = ni.v[j]; }
+}
 // Team (group g, chunk j, line L) = index ((g * cpg + j) * 68 + L): the product of line L over the pairs
 // [j * chunk, min(gsz, (j + 1) * chunk)) of group g that are not marked bad -> out[index * 168].
 #ifndef BLSGPU_ML_ACCUM_WAVES
 #define BLSGPU_ML_ACCUM_WAVES 2
 #endif
 __global__ void __launch_bounds__(256, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad, uint32_t n,
-                                                                         uint32_t gsz, uint32_t chunk, uint32_t cpg, uint32_t nteams,
-                                                                         int32_t* __restrict__ out)
+                                                                            uint32_t gsz, uint32_t chunk, uint32_t cpg, uint32_t nteams,
+                                                                            int32_t* __restrict__ out)
 #if BLSGPU_EMIT(BLSGPU_TU_ML)
 {
     const Team t = team_of_lane();
@@ -849,10 +877,10 @@ __global__ void __launch_bounds__(256, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const i
                 y[(e + 2) / NL][(e + 2) % NL] = q[k].z; y[(e + 3) / NL][(e + 3) % NL] = q[k].w;
             }
         }
-        Pub P;
-        publish<false>(P, fre, fim);
         int32_t re[NL], im[NL];
-        mul_line(re, im, P, t, jA, jB, y[0], y[1], y[2], y[3], y[4], y[5]);
+#pragma unroll
+        for (int k = 0; k < NL; k++) { re[k] = fre[k]; im[k] = fim[k]; }
+        mul_line_k3(re, im, t, jA, jB, y);
 #pragma unroll
         for (int k = 0; k < NL; k++) { fre[k] = use ? re[k] : fre[k]; fim[k] = use ? im[k] : fim[k]; }
     }
@@ -1007,10 +1035,10 @@ __global__ void __launch_bounds__(256, 2) k_ml_small(const int32_t* __restrict__
                     y[(e + 2) / NL][(e + 2) % NL] = q[k].z; y[(e + 3) / NL][(e + 3) % NL] = q[k].w;
                 }
             }
-            Pub P;
-            publish<true>(P, fre, fim);                    // f may be a dense product's sum: normalised xi forms
-            int32_t re[NL], im[NL];
-            mul_line(re, im, P, t, jA, jB, y[0], y[1], y[2], y[3], y[4], y[5]);
+            int32_t re[NL], im[NL];                         // (f: normalised digits, from a dense product's sum or a sparse product)
+#pragma unroll
+            for (int k = 0; k < NL; k++) { re[k] = fre[k]; im[k] = fim[k]; }
+            mul_line_k3(re, im, t, jA, jB, y);
 #pragma unroll
             for (int k = 0; k < NL; k++) { fre[k] = use ? re[k] : fre[k]; fim[k] = use ? im[k] : fim[k]; }
         }
