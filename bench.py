@@ -342,12 +342,16 @@ class ClockWatch:
 
 
 def timed_steps(env, args, step, engs, streams):
-    """W warm-up steps, barrier, K timed steps, barrier: (seconds max over ranks, per-step ms, kernel times)"""
+    """W warm-up steps, [the multiply-add probe,] barrier, K timed steps, barrier: (seconds max over ranks, per-step ms, kernel times)"""
     torch = env.torch
     S = len(streams)
     torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
+    torch.cuda.synchronize()
+    # the roof in THIS process on THIS box: ~30 ms of v_mad_i64_i32 on every SIMD right before the timed steps (the chip is warm
+    # and at its power-limited clock after the warm-up steps)
+    env.peak_now = engs[0].mad_probe(30.0) if not getattr(args, "no_peak_probe", False) else None
     env.barrier()
     for e in engs:
         e.timing_enable(True)         # HIP events around every kernel, on the stream it runs on
@@ -597,6 +601,9 @@ def run_pairing(env, args):
                        "backend": env.backend if env.dist else "none", "ranks_in_process_group": len(info)},
             "roofline": {"bound": "valu-int32-mac", "achieved": ach, "peak": PEAK_TMACS, "unit": "TMAC/s",
                          "frac": ach / PEAK_TMACS, "traffic": traffic,
+                         # the same against the multiply-add rate a 30 ms probe kernel reached in THIS run right before the timed steps
+                         "peak_measured_this_run": getattr(env, "peak_now", None),
+                         "frac_of_peak_measured_this_run": (ach / env.peak_now) if getattr(env, "peak_now", None) else None,
                          "traffic_unit": "bytes per launch, offline rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (%s)" % traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel": kname,
@@ -1090,6 +1097,7 @@ def main():
     ap.add_argument("--free-streams", action="store_true",
                     help="do not order the Miller stages of consecutive steps (default: step i + 1's starts after step i's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-peak-probe", action="store_true", help="skip the 30 ms multiply-add rate probe before the timed steps")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="c2: skip the c3 / c4 / c5 / h2c runs after the timed region")
     ap.add_argument("--dry-run", action="store_true",

@@ -79,6 +79,11 @@ int blsgpu_ctx_trim(blsgpu_ctx *ctx);
  * (several pairs per wavefront sharing one accumulator); smaller batches the
  * latency-oriented one (one pair per wavefront).  Default 4096; 0 = always the
  * throughput kernel.  Results are identical either way. */
+/* Measurement aid (bench.py): the chip's 32 x 32 + 64-bit multiply-add rate (v_mad_i64_i32) measured NOW by a probe kernel of
+ * about `target_ms` milliseconds on `stream`; *tmacs = 10^12 multiply-adds per second.  The roofline of this path is that
+ * instruction's issue rate (integer VALU, not HBM or MFMA), and the clock the package's power limit leaves differs
+ * by a few per cent between boxes. */
+int blsgpu_timing_mad_probe(blsgpu_ctx *ctx, double target_ms, double *tmacs, void *stream);
 int blsgpu_ctx_set_mp_threshold(blsgpu_ctx *ctx, size_t pairs);
 /* Calls of at most `pairs` pairs (below the line-stream threshold) run the WIDE Miller loop (csrc/blsgpu_mlw.hip): one pair
  * per workgroup of two wavefronts with a field product per lane -- the loop of fq_miller_loop (fields_t.py:1091-1111) at

@@ -696,6 +696,39 @@ BLSGPU_EXPORT int blsgpu_timing_read(blsgpu_ctx* c, float* ms, int* kind, size_t
     return 0;
 }
 
+// The chip's v_mad_i64_i32 rate right now: a probe kernel of about `target_ms` milliseconds (2048 workgroups x 256 threads, eight
+// independent multiply-add chains per lane), timed with HIP events on `stream`; *tmacs = 10^12 multiply-adds per second.
+BLSGPU_EXPORT int blsgpu_timing_mad_probe(blsgpu_ctx* c, double target_ms, double* tmacs, void* stream) {
+    if (!c || !tmacs) return fail(-EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    constexpr unsigned BLOCKS = 2048, THREADS = 256;
+    if (int rc = grow_buffer(c, &c->d_io, &c->io_cap, (size_t)BLOCKS * THREADS * 4)) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    double rate = 0.0;
+    uint32_t iters = 20000;                                   // ~2.4 ms at 34 T/s: calibrates the second launch
+    for (int pass = 0; pass < 2; pass++) {
+        HIP_TRY(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(blsgpu::probe::k_mad_probe, dim3(BLOCKS), dim3(THREADS), 0, st, (uint32_t*)c->d_io, iters, (uint32_t)pass);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e1, st));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        rate = (double)BLOCKS * THREADS * 8.0 * iters / (ms * 1e-3) / 1e12;
+        if (pass == 0 && ms > 0.f) {
+            double want = (double)iters * target_ms / ms;
+            iters = want < 1000.0 ? 1000u : (want > 4e6 ? 4000000u : (uint32_t)want);
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *tmacs = rate;
+    return 0;
+}
+
 BLSGPU_EXPORT int blsgpu_ctx_set_mp_threshold(blsgpu_ctx* c, size_t pairs) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
     c->mp_threshold = pairs;

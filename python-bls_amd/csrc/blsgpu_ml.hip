@@ -253,6 +253,23 @@ __device__ __forceinline__ h sqr(const h& x) {
     bls28::fp28_dot1(r.v, u, w);                                       // |u|, |w| < 2^29: 4 units
     return r;
 }
+// g^2 - 12 e^2 (round 5): the lane's part of a square is ONE product -- (a + b)(a - b) on the even lane, (2 b) a on the odd one --,
+// so the difference of the two squares is a sum of two products with one reduction (588 multiply-adds; two squares, a
+// scaling and a carry pass before: 784 + 84).  Column bound: |u|, |w| < 2^29 for g (4 units), 12 u normalised x |w| < 2^29 for e (2).
+__device__ __forceinline__ h sqr_m12sqr(const h& g, const h& e) {
+    const h pg = swp(g), pe = swp(e);
+    int32_t ug[NL], wg[NL], nwe[NL];
+    S<2> ue;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        ug[j] = g.v[j] + (odd() ? g.v[j] : pg.v[j]); wg[j] = odd() ? pg.v[j] : g.v[j] - pg.v[j];
+        ue.v[j] = e.v[j] + (odd() ? e.v[j] : pe.v[j]); nwe[j] = odd() ? -pe.v[j] : pe.v[j] - e.v[j];
+    }
+    const h ue12 = mulc_norm<12>(ue);
+    h r;
+    bls28::fp28_dot2(r.v, ug, wg, ue12.v, nwe);
+    return r;
+}
 template <int M> __device__ __forceinline__ h mulf(const S<M>& x, const fe& k) {     // by an Fq value (both lanes hold it)
     static_assert(M <= 8, "");
     h r;
@@ -300,7 +317,7 @@ __device__ __forceinline__ void tangent_step(h& X, h& Y, h& Z, const fe& px3n, c
     const S<3> F3 = mulc<3>(E);
     const h BmF = norm(sub(B, F3)), G = norm(add(B, F3));
     X = mul(left(A2), right(BmF));
-    Y = norm(sub(sqr(G), mulc_norm<12>(sqr(E))));                     // G^2 - 12 E^2 as two squares (2 x 392 against 980 for the sum of four products)
+    Y = sqr_m12sqr(G, E);                                             // G^2 - 12 E^2: one sum of two products (round 4: two squares, 2 x 392 + the scaling)
     Z = mul(left(B), right(z8));
 }
 __device__ __forceinline__ void chord_step(h& X, h& Y, h& Z, const h& xq, const h& yq, const fe& px3n, const fe& py3,

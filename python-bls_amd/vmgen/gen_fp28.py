@@ -46,7 +46,7 @@ def stmt(macs, zero_init=False):
     assert len(ops) + 1 <= 30, len(ops)
     ins = ", ".join('"%s"(%s)' % (k, e) for e, k in ops)
     acc = '"=&v"(acc)' if zero_init else '"+&v"(acc)'
-    return '    asm volatile("%s"\n                 : %s : %s : "vcc");\n' % ("\\n\\t".join(lines), acc, ins)
+    return '    asm volatile("%s" BLS28_XNOP\n                 : %s : %s : "vcc");\n' % ("\\n\\t".join(lines), acc, ins)
 
 
 def chunks(macs, zero_init=False):
@@ -124,6 +124,7 @@ def generate(path=None):
     out = ["/* generated by python-bls_amd/vmgen/gen_fp28.py -- do not edit */\n#pragma once\n#include <stdint.h>\n",
            "// Carry-free Montgomery sums of products on 14 signed 28-bit limbs, R = 2^392 (gfx950 device code only).\n"
            "// Column bound (checked by the callers' types, csrc/fp28.h): 14 * sum_t |a_t limb| |b_t limb| + 14 * 2^56 < 2^63.\n",
+           "// (timing experiment: -DBLS28_XNOP='\"\\n\\ts_nop 0\"' appends a wait state to every statement)\n#ifndef BLS28_XNOP\n#define BLS28_XNOP\n#endif\n",
            "namespace bls28 {\n"]
     for K in (1, 2, 3, 4, 6):
         out.append(gen_dot(K))
