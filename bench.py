@@ -136,6 +136,28 @@ def pmc_traffic(kernels, pairings_per_launch):
     return int(total), "profiles/" + os.path.basename(path)
 
 
+def config_traffic(name):
+    """HBM bytes per step of a secondary config (c4 / c5 / h2c) from the COMMITTED rocprofv3 --pmc passes over `bench.py --config
+    <name>` (tools/profile_round.sh; tools/collect_profiles.py sums FETCH_SIZE and WRITE_SIZE of the dispatches between the timed
+    region's marks, per step) -- reported only when the summary's header names THIS build; FETCH_SIZE doubled as for pmc_traffic."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_configs_traffic.csv")))
+    if not cands:
+        return None, None
+    path, ok, kb = cands[-1], False, {}
+    with open(path) as f:
+        for row in f:
+            if row.startswith("#"):
+                ok = ("build " + source_hash()) in row
+                continue
+            c = row.strip().split(",")
+            if len(c) == 4 and c[0] == name and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                kb[c[1]] = float(c[3])
+    if not ok or len(kb) != 2:
+        return None, None
+    return int((2 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), "profiles/" + os.path.basename(path)
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -358,6 +380,7 @@ def timed_steps(env, args, step, engs, streams):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     watch = ClockWatch(torch, env.local_dev)
     watch.start()
+    engs[0].mark(1)                   # (the device is idle here: everything dispatched until the closing mark is the timed region)
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record(streams[i % S])
@@ -365,6 +388,7 @@ def timed_steps(env, args, step, engs, streams):
         ev[i][1].record(streams[i % S])
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
+    engs[0].mark(2)
     env.clock = watch.stop()
     step_ms = sorted(a.elapsed_time(b) for a, b in ev)
     ktimes = [t for e in engs for t in e.timing_read()]
@@ -694,7 +718,9 @@ def secondary(env, args, eng, gen1, gen2):
     for name, fn in (("c4", run_c4), ("c5", run_c5), ("h2c", run_h2c)):
         ln = fn(env, sub)
         out[name] = {"value": ln["value"], "unit": ln["unit"], "ms": ln["ms_per_step"], "check": ln["config"]["check"],
-                     "workload": ln["config"]["workload"], "roofline_frac": ln["roofline"]["frac"]}
+                     "workload": ln["config"]["workload"], "roofline_frac": ln["roofline"]["frac"],
+                     "traffic": ln["roofline"].get("traffic"), "traffic_source": ln["roofline"].get("traffic_source"),
+                     "algorithmic_bytes": ln["roofline"].get("algorithmic_bytes")}
         if name == "c4":
             out[name].update(combine_ms=ln["combine_s"] * 1e3, verify_ms=ln["verify_s"] * 1e3)
     out["verify_pipeline"] = run_verify_pipeline(env, eng)
@@ -802,16 +828,22 @@ def run_verify_pipeline(env, eng, B=256, n=1024):
             "workload": "%d aggregate verifications x %d messages, device resident: hash to G2 + %d-pair multi-pairing each" % (B, n, n + 1)}
 
 
-def device_timed(env, fn, reps):
+def device_timed(env, fn, reps, mark=None):
+    """seconds per call of fn over `reps` back-to-back calls (HIP events); mark: an engine whose empty marker kernel brackets
+    the calls in a profile of the run"""
     torch = env.torch
     fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if mark is not None:
+        mark.mark(1)
     a.record()
     for _ in range(reps):
         fn()
     b.record()
     torch.cuda.synchronize()
+    if mark is not None:
+        mark.mark(2)
     return a.elapsed_time(b) * 1e-3 / reps
 
 
@@ -878,12 +910,14 @@ def run_c4(env, args):
         step(i)
     torch.cuda.synchronize()
     env.barrier()
+    eng.mark(1)
     t0 = time.perf_counter()
     for i in range(reps):
         step(i)
     torch.cuda.synchronize()
     env.barrier()
     dt_step = (time.perf_counter() - t0) / reps
+    eng.mark(2)
     ok_p = all(bytes(vo.cpu().numpy()) == one * groups for vo in vouts) and all(bytes(t.cpu().numpy()) == want for t in touts)
     dt = env.max_over_ranks(dt_step)
     oks = env.gather_objects(ok_c and ok_v and ok_p)
@@ -904,7 +938,7 @@ def run_c4(env, args):
             "combine_s": dt_c, "verify_s": dt_v, "one_step_alone_ms": (dt_c + dt_v) * 1e3,
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_msm_lane2x (+ k_lane_prep, windows, horner)", "peak": PEAK_TMACS, "unit": "TMAC/s",
                          "achieved": mac_combine * groups / dt_c / 1e12, "frac": mac_combine * groups / dt_c / 1e12 / PEAK_TMACS,
-                         "verify_achieved": mac_verify * groups / dt_v / 1e12, "traffic": None,
+                         "verify_achieved": mac_verify * groups / dt_v / 1e12, "traffic": config_traffic("c4")[0], "traffic_source": config_traffic("c4")[1],
                          "whole_step_TMACs": (mac_combine + mac_verify) * groups / dt / 1e12,
                          "whole_step_frac": (mac_combine + mac_verify) * groups / dt / 1e12 / PEAK_TMACS,
                          "algorithmic_bytes": groups * k * (192 + 32)}}
@@ -976,11 +1010,13 @@ def run_c5(env, args):
         for i in range(S):
             step(i)
         torch.cuda.synchronize()
+        eng.mark(1)
         t0 = time.perf_counter()
         for i in range(reps):
             step(i)
         torch.cuda.synchronize()
         dt_step = (time.perf_counter() - t0) / reps
+        eng.mark(2)
         ok_p = all(bytes(o.cpu().numpy()) == bytes(tout.cpu().numpy()) for o in outs)
     dtm = env.max_over_ranks(dt_step)
     got = bytes(tout.cpu().numpy())
@@ -1007,7 +1043,7 @@ def run_c5(env, args):
             "one_step_alone_ms": dt_alone * 1e3,
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_srt_accum (+ k_lane_prep, k_srt_count/scan/scatter/fix/bits, fold, windows, horner)",
                          "peak": PEAK_TMACS, "unit": "TMAC/s", "achieved": mac / dtm / 1e12 / env.world, "frac": mac / dtm / 1e12 / PEAK_TMACS / env.world,
-                         "traffic": None,
+                         "traffic": config_traffic("c5")[0], "traffic_source": config_traffic("c5")[1],
                          "executed_TMACs": executed / dtm / 1e12 if total == 1 << 20 and env.world == 1 else None,
                          "algorithmic_bytes": total * (96 + 32), "hbm_GBps_algorithmic": total * 128 / dtm / 1e9}}
     return None
@@ -1022,7 +1058,7 @@ def run_h2c(env, args):
     tin = env.up(msgs)
     tout = torch.zeros(n * 192, dtype=torch.uint8, device=env.dev)
     reps = max(1, args.steps)
-    dt = device_timed(env, lambda: eng.lib.blsgpu_hash_to_g2_dev(eng.h, tin.data_ptr(), n, tout.data_ptr(), 0), reps)
+    dt = device_timed(env, lambda: eng.lib.blsgpu_hash_to_g2_dev(eng.h, tin.data_ptr(), n, tout.data_ptr(), 0), reps, mark=eng)
     got = bytes(tout.cpu().numpy())
     # check: the REFERENCE's digest of these very outputs where a committed fixture holds it (rank 0's first 16 384 / 20 000
     # messages: tests/golden/h2c_20000.json, produced by importing the reference), else three messages against the host
@@ -1050,7 +1086,9 @@ def run_h2c(env, args):
             "config": {"workload": "hash_to_point_prehashed_Fq2 of %d message hashes per GPU (SHA-256 chain, two SW encodings one per lane with the powers in registers, cofactor clearing one message per lane pair)" % n,
                        "name": "h2c", "check": check or "3 messages against the host integer code (itself pinned to the reference's vectors)"},
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_pow + k_h2c_stage + k_h2c_clear", "peak": PEAK_TMACS, "unit": "TMAC/s",
-                         "achieved": mac * n / dt / 1e12, "frac": mac * n / dt / 1e12 / PEAK_TMACS, "traffic": None}}
+                         "achieved": mac * n / dt / 1e12, "frac": mac * n / dt / 1e12 / PEAK_TMACS,
+                         "traffic": config_traffic("h2c")[0] if n == 16384 else None, "traffic_source": config_traffic("h2c")[1] if n == 16384 else None,
+                         "algorithmic_bytes": n * (32 + 192)}}
     return None
 
 

@@ -84,6 +84,10 @@ int blsgpu_ctx_trim(blsgpu_ctx *ctx);
  * instruction's issue rate (integer VALU, not HBM or MFMA), and the clock the package's power limit leaves differs
  * by a few per cent between boxes. */
 int blsgpu_timing_mad_probe(blsgpu_ctx *ctx, double target_ms, double *tmacs, void *stream);
+/* Measurement aid: one dispatch of an empty kernel (blsgpu::probe::k_mark) on `stream`.  bench.py brackets every timed region
+ * with two of them; tools/collect_profiles.py cuts the per-dispatch counters of a rocprofv3 --pmc run to the dispatches between
+ * the marks (the HBM traffic per step of roofline.traffic). */
+int blsgpu_timing_mark(blsgpu_ctx *ctx, unsigned tag, void *stream);
 int blsgpu_ctx_set_mp_threshold(blsgpu_ctx *ctx, size_t pairs);
 /* Calls of at most `pairs` pairs (below the line-stream threshold) run the WIDE Miller loop (csrc/blsgpu_mlw.hip): one pair
  * per workgroup of two wavefronts with a field product per lane -- the loop of fq_miller_loop (fields_t.py:1091-1111) at

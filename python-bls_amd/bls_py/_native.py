@@ -15,7 +15,7 @@ SYMBOLS = (
     "blsgpu_version", "blsgpu_last_error", "blsgpu_ctx_create", "blsgpu_ctx_destroy",
     "blsgpu_ctx_reserve", "blsgpu_ctx_set_mp_threshold", "blsgpu_ctx_set_miller_wide_max", "blsgpu_pairing_multi", "blsgpu_pairing_multi_dev",
     "blsgpu_miller_product_dev", "blsgpu_final_exp_product_dev", "blsgpu_final_exp",
-    "blsgpu_timing_enable", "blsgpu_timing_read", "blsgpu_timing_mad_probe",
+    "blsgpu_timing_enable", "blsgpu_timing_read", "blsgpu_timing_mad_probe", "blsgpu_timing_mark",
     "blsgpu_g1_msm", "blsgpu_g2_msm", "blsgpu_g1_msm_dev", "blsgpu_g2_msm_dev",
     "blsgpu_final_exp_batch", "blsgpu_pairing_multi_batch", "blsgpu_pairing_multi_batch_dev",
     "blsgpu_map_to_g2", "blsgpu_map_to_g2_dev",
@@ -65,6 +65,7 @@ def load_library(path=None):
         L.blsgpu_ctx_set_mp_threshold.argtypes = [vp, sz]
         L.blsgpu_ctx_set_mp3_threshold.argtypes = [vp, sz]
         L.blsgpu_timing_mad_probe.argtypes = [vp, ctypes.c_double, ctypes.POINTER(ctypes.c_double), vp]
+        L.blsgpu_timing_mark.argtypes = [vp, ctypes.c_uint, vp]
         L.blsgpu_ctx_set_miller_wide_max.argtypes = [vp, sz]
         L.blsgpu_ctx_set_ls_threshold.argtypes = [vp, sz, sz]
         L.blsgpu_ctx_set_ls_teams.argtypes = [vp, sz]
@@ -150,6 +151,10 @@ class Engine:
         out = ctypes.c_double(0.0)
         self._check(self.lib.blsgpu_timing_mad_probe(self.h, float(target_ms), ctypes.byref(out), stream), "blsgpu_timing_mad_probe")
         return out.value
+
+    def mark(self, tag=0, stream=None):
+        """one dispatch of an empty kernel: brackets a timed region in a profile of the run"""
+        self._check(self.lib.blsgpu_timing_mark(self.h, tag, stream), "blsgpu_timing_mark")
 
     def set_miller_wide_max(self, pairs):
         """Calls of at most `pairs` pairs run the wide Miller loop (one pair per two-wavefront workgroup); 0: never."""

@@ -66,7 +66,6 @@ struct blsgpu_ctx {
     size_t h2c_lane_threshold = 2048;  // messages from which the three encoding stages run one encoding per lane (k_h2c_sw0/1/2)
     bool h2c_jacobi = true;            // ... with the quadratic characters decided by a Jacobi-symbol routine: two powers per encoding, not five
     size_t h2c_jacobi_threshold = 16384;   // ... from this many messages (below, five parallel powers finish sooner than three serial symbol loops)
-    bool h2c_reg_pairs = true;         // ... on lane pairs (k_h2c_clear_pairs); false: one message per lane (k_h2c_clear_reg)
     size_t h2c_quad_max = 16384;       // ... on lane QUADS up to this many messages (k_h2c_clear_quads: half the depth while the chip is not full)
     bool test_ls_nomem = false;        // test hook (BLSGPU_TEST_LS_NOMEM=1): the line-stream workspace "cannot be allocated"
     void* d_h2c_ws = nullptr;          // the lane-private point slots of k_h2c_clear_pairs
@@ -92,10 +91,8 @@ struct blsgpu_ctx {
     void* d_bad = nullptr;             // one byte per pair: left to the slow program
     size_t bad_cap = 0;
     bool vm_exact_lanes = true;        // degenerate blocks of the VM kernels through the lane kernels (k_ml_lines_exact / k_ml_small) instead of k_miller_slow
-    int ls_horner_form = 3;            // 3: one group per wavefront, a product PER LANE (blsgpu_fexpw.hip; merges of few outputs likewise); 2: a product spread over 36 lanes; 1: ten groups per wavefront
     size_t ls_merge_wide_max = 16384;  // merge levels with at most this many outputs run one wavefront per output
     size_t ls_quad_max = 20480;        // calls of at most this many pairs run the point chains on lane QUADS (k_ml_lines4: 0.6 of the depth while lane pairs leave SIMDs empty)
-    int ls_lines_form = 2;             // 2: the point chains on lane pairs (k_ml_lines2); 1: one pair per lane (k_ml_lines)
     size_t fexp_team_threshold = 5120; // results per call from which the final exponentiations run six lanes each (blsgpu_fexp.hip); below: one result per wavefront (measured crossover, tools/fexp_latency.py)
     bool fexp_wide = true;             // fewer results than that: one result per wavefront, a product per lane (blsgpu_fexpw.hip); false: the VM program
     size_t fexp_wide_max_partials = 8; // ... which also multiplies up to this many partials per result itself (a dense product is ~2.5 us)
@@ -528,14 +525,11 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_FEXP_WIDE")) c->fexp_wide = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_FEXP_WIDE_MAX_PARTIALS")) c->fexp_wide_max_partials = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_VM_EXACT_LANES")) c->vm_exact_lanes = atoi(e) != 0;
-    if (const char* e = getenv("BLSGPU_LS_LINES_FORM")) c->ls_lines_form = atoi(e) == 1 ? 1 : 2;
-    if (const char* e = getenv("BLSGPU_LS_HORNER_FORM")) c->ls_horner_form = atoi(e) == 1 ? 1 : (atoi(e) == 2 ? 2 : 3);
     if (const char* e = getenv("BLSGPU_LS_MERGE_WIDE_MAX")) c->ls_merge_wide_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_QUAD_MAX")) c->ls_quad_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
-    if (const char* e = getenv("BLSGPU_H2C_REG_PAIRS")) c->h2c_reg_pairs = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_H2C_QUAD_MAX")) c->h2c_quad_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_TEST_LS_NOMEM")) c->test_ls_nomem = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_H2C_JACOBI")) c->h2c_jacobi = atoi(e) != 0;
@@ -726,6 +720,16 @@ BLSGPU_EXPORT int blsgpu_timing_mad_probe(blsgpu_ctx* c, double target_ms, doubl
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *tmacs = rate;
+    return 0;
+}
+
+// One dispatch of an empty kernel (blsgpu::probe::k_mark) on `stream`: a caller brackets its timed region with two of them so that
+// a profile of the run can be cut to that region (the counters of rocprofv3 --pmc are per dispatch).
+BLSGPU_EXPORT int blsgpu_timing_mark(blsgpu_ctx* c, unsigned tag, void* stream) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(blsgpu::probe::k_mark, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint32_t)tag);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -1016,10 +1020,7 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     HIP_TRY(hipMemsetAsync(c->d_degen, 0, sizeof(uint32_t), st));
     {
         KernelTimer kt(c, st, 4);
-        if (c->ls_lines_form == 1)
-            hipLaunchKernelGGL(ml::k_ml_lines, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_g1, (const uint32_t*)d_g2,
-                               (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
-        else if (n <= c->ls_quad_max) {                       // few pairs: four lanes each, the tangent step's levels shared by the two pairs
+        if (n <= c->ls_quad_max) {                       // few pairs: four lanes each, the tangent step's levels shared by the two pairs
             const WaveShape ws = wave_shape(c, (4 * n + 63) / 64);
             hipLaunchKernelGGL(ml::k_ml_lines4, dim3(ws.blocks), dim3(ws.threads), 0, st, (const uint32_t*)d_g1,
                                (const uint32_t*)d_g2, (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
@@ -1063,7 +1064,7 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
         const size_t cpo = (cpg + FAN - 1) / FAN;
         teams = groups * cpo * ml::LINES;
         KernelTimer kt(c, st, 6);
-        if (c->ls_horner_form == 3 && teams <= c->ls_merge_wide_max)       // few outputs: one wavefront each, a product per lane
+        if (teams <= c->ls_merge_wide_max)                                 // few outputs: one wavefront each, a product per lane
             hipLaunchKernelGGL(fxw::k_ml_merge_wide, dim3((unsigned)teams), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur], (uint32_t)cpg,
                                (uint32_t)FAN, (uint32_t)cpo, (int32_t*)c->d_lsp[cur ^ 1]);
         else {
@@ -1078,18 +1079,11 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     }
     if (c->bulk_event) HIP_TRY(hipEventRecord(c->bulk_event, st));
     {
-        const bool fuse = c->ls_horner_form == 3 && d_fused_out != nullptr && use_fexp_wide(c, 1, groups);
+        const bool fuse = d_fused_out != nullptr && use_fexp_wide(c, 1, groups);
         KernelTimer kt(c, st, fuse ? 2 : 7);
-        if (c->ls_horner_form == 3) {
-            hipLaunchKernelGGL(fxw::k_ml_horner_fexp, dim3((unsigned)groups), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur], d_partials, 144u,
-                               (uint32_t*)(fuse ? d_fused_out : nullptr));
-            if (fused) *fused = fuse;
-        } else if (c->ls_horner_form == 1)
-            hipLaunchKernelGGL(ml::k_ml_horner, dim3((unsigned)((groups + ml::TEAMS - 1) / ml::TEAMS)), dim3(64), 0, st,
-                               (const int32_t*)c->d_lsp[cur], (uint32_t)groups, d_partials, 144u);
-        else
-            hipLaunchKernelGGL(ml::k_ml_horner_wide, dim3((unsigned)groups), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur],
-                               (uint32_t)groups, d_partials, 144u);
+        hipLaunchKernelGGL(fxw::k_ml_horner_fexp, dim3((unsigned)groups), dim3(64), 0, st, (const int32_t*)c->d_lsp[cur], d_partials, 144u,
+                           (uint32_t*)(fuse ? d_fused_out : nullptr));
+        if (fused) *fused = fuse;
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1523,19 +1517,16 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
         unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);
         hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)d_out);
-    } else if (c->h2c_reg_pairs && n <= c->h2c_quad_max) {   // a batch that leaves SIMDs empty on lane pairs: one message per lane QUAD
+    } else if (n <= c->h2c_quad_max) {   // a batch that leaves SIMDs empty on lane pairs: one message per lane QUAD
         const WaveShape ws = wave_shape(c, (4 * n + 63) / 64);                   // every launched lane owns rows of the workspace
         if (int rc2 = grow_buffer(c, &c->d_h2c_ws, &c->h2c_ws_cap, (size_t)ws.blocks * ws.threads * BLS28_H2C_NSLOTS * 3 * blsgpu::r28::NL * 4)) return rc2;
         hipLaunchKernelGGL(blsgpu::k_h2c_clear_quads, dim3(ws.blocks), dim3(ws.threads), 0, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)c->d_h2c_ws, (uint32_t*)d_out);
-    } else if (c->h2c_reg_pairs) {         // one message per lane pair, the point operations as a script
+    } else {                               // one message per lane pair, the point operations as a script
         const WaveShape ws = wave_shape(c, (2 * n + 63) / 64);
         if (int rc2 = grow_buffer(c, &c->d_h2c_ws, &c->h2c_ws_cap, (size_t)ws.blocks * ws.threads * BLS28_H2C_NSLOTS * 3 * blsgpu::r28::NL * 4)) return rc2;
         hipLaunchKernelGGL(blsgpu::k_h2c_clear_pairs, dim3(ws.blocks), dim3(ws.threads), 0, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)c->d_h2c_ws, (uint32_t*)d_out);
-    } else {
-        hipLaunchKernelGGL(blsgpu::k_h2c_clear_reg, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->tabs, img, (uint32_t)n,
-                           (uint32_t*)d_out);
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -660,74 +660,16 @@ __global__ void __launch_bounds__(64, 3) k_h2c_clear(VmTables T, const uint32_t*
 #endif
 
 // ---------------------------------------------------------------------------
-// Cofactor clearing with ONE MESSAGE PER LANE, everything in registers (the same
-// formulas as vmgen/h2c_programs.build_h2: complete projective addition / doubling
-// of Renes-Costello-Batina for a = 0, the endomorphism psi, ec.py:536-550).  The
-// point arithmetic of one message is strictly sequential (two double-and-add chains
-// by |x|), so the 64-lane VM needs five messages per wavefront to keep its
-// lanes busy; here every lane carries a message and nothing but products and modular
-// additions is executed.  The field product is a real function call (s_swappc, operands
-// by value in VGPRs): inlining 36 products per point addition would not fit the
-// instruction cache.
-
+// Cofactor clearing in registers (the same formulas as vmgen/h2c_programs.build_h2: complete projective addition / doubling of
+// Renes-Costello-Batina for a = 0, the endomorphism psi, ec.py:536-550).  The point arithmetic of one message is strictly
+// sequential (two double-and-add chains by |x|), so the 64-lane VM needs five messages per wavefront to keep its lanes busy;
+// the register forms carry a message per lane pair / lane quad.  (Round 2's form with one message per LANE -- 460 registers and
+// 6 KB of scratch -- lost to the lane-pair form at every size and was removed in round 5.)
 // enc = the stage image (see k_h2c_stage): encoding e sits in team e / NE, slots S + 5 (e % NE) .. + 5.
 // out: n_msg x 192 bytes canonical affine (x.c0 || x.c1 || y.c0 || y.c1), (0,0) for infinity.
-__global__ void __launch_bounds__(64) k_h2c_clear_reg(VmTables T, const uint32_t* __restrict__ enc, uint32_t n_msg,
-                                                      uint32_t* __restrict__ out)
-#if BLSGPU_EMIT(BLSGPU_TU_H2C)
-{
-    using namespace r28;
-    typedef ptT<fe2> pt;
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_msg) return;
-    auto vm = [&](const uint32_t* p) { uint32_t x[12]; for (int j = 0; j < 12; j++) x[j] = p[j]; return from_vm(x); };   // the VM leaves values < 2q
-    pt S[2];
-    for (int s = 0; s < 2; s++) {
-        const uint32_t e = 2 * m + s;
-        const uint32_t* src = enc + ((size_t)(e / BLSVM_H1_NE) * H1_IMG + (BLSVM_H1_S - BLSVM_H1_STATE0) + 5 * (e % BLSVM_H1_NE)) * 12;
-        S[s] = {{vm(src), vm(src + 12)}, {vm(src + 24), vm(src + 36)}, {vm(src + 48), fe_zero()}};
-    }
-    constexpr uint32_t PSIX = BLSVM_HC_PSIX - BLSVM_HC_SLOT0 + BLSVM_HC_TBL0, PSIY = BLSVM_HC_PSIY - BLSVM_HC_SLOT0 + BLSVM_HC_TBL0;
-    const fe2 psix = {vm(T.consts + PSIX * 12), vm(T.consts + (PSIX + 1) * 12)}, psiy = {vm(T.consts + PSIY * 12), vm(T.consts + (PSIY + 1) * 12)};
-    auto psi = [&](const pt& P) { return pt{mul(conj(P.X), psix), mul(conj(P.Y), psiy), norm(conj(P.Z))}; };
-    auto mul_x = [&](const pt& P) {                              // [|x|] P, |x| = 0xd201000000010000
-        pt A = P;
-#pragma unroll 1
-        for (int bit = 62; bit >= 0; bit--) {
-            A = pdbl_fn(A);
-            if ((0xd201000000010000ull >> bit) & 1ull) A = padd_fn(A, P);
-        }
-        return A;
-    };
-    const pt P = padd_fn(S[0], S[1]);
-    const pt T0 = mul_x(P);                                      // [x] P       (ec.py:540-550)
-    const pt T1 = mul_x(T0);                                     // [x^2] P
-    const pt t2 = padd_fn(padd_fn(T1, T0), pneg(P));
-    const pt t3 = psi(padd_fn(T0, P));
-    const pt p2 = psi(psi(pdbl_fn(P)));
-    const pt R = padd_fn(padd_fn(t2, pneg(t3)), p2);
-    // affine: (X, Y) / Z with 1 / Z = conj(Z) / N(Z); Z = 0 gives (0, 0).  The inversion is the safegcd routine of fq32.h on
-    // the VM's form of the norm.
-    const fe n = dot2(R.Z.a, R.Z.a, R.Z.b, R.Z.b);
-    uint32_t nv[12], niv[12];
-    to_vm(nv, n);
-    bls::fq_inv(niv, nv);
-    const fe ninv = from_vm(niv);
-    const fe2 zi = {mul(R.Z.a, ninv), mul(neg(R.Z.b), ninv)};
-    const fe2 xa = mul(R.X, zi), ya = mul(R.Y, zi);
-    const fe o[4] = {xa.a, xa.b, ya.a, ya.b};
-    for (int k = 0; k < 4; k++) {
-        uint32_t y[12];
-        to_raw(y, o[k]);
-        for (int w = 0; w < 12; w++) out[(size_t)m * 48 + k * 12 + w] = bswap32(y[11 - w]);
-    }
-}
-#else
-;
-#endif
 
-// The same with ONE MESSAGE PER LANE PAIR (round 3): the Fq2 split of blsgpu_ml.hip / sp2 (even lane real parts, odd
-// lane imaginary parts).  k_h2c_clear_reg holds 460 registers and 6 KB of scratch per lane; here a lane holds half of
+// ONE MESSAGE PER LANE PAIR (round 3): the Fq2 split of blsgpu_ml.hip / sp2 (even lane real parts, odd
+// lane imaginary parts).  One message per lane held 460 registers and 6 KB of scratch per lane; here a lane holds half of
 // every coordinate (256 registers, two wavefronts per SIMD), the point operations exist ONCE in the code -- the
 // clearing is a script (fexp_tables_gfx950.h BLS28_H2C_OPS, vmgen/gen_fexp.h2c_clear_script) over one point in
 // registers and five lane-private slots in HBM -- and 16 384 messages already give 512 wavefronts.

@@ -10,7 +10,7 @@
 //                accumulator, so it runs alone; every step stores its line l = l0 + l2 w^2 + l3 w^3 (three Fq2 values,
 //                P already multiplied in) as an 84-dword record: lines[(L * n + pair) * 84], L = 0 .. 67 in execution
 //                order (63 tangents, 5 chords).  22.8 KB per pair: the 8 TB/s of HBM3E are what makes cutting the
-//                loop here affordable.  (k_ml_lines: the same with one pair per lane, kept for comparison.)
+//                loop here affordable.  (k_ml_lines4: the same on lane quads for calls that leave SIMDs empty on lane pairs.)
 //   k_ml_lines_exact  the pairs the fast formulas are not valid for: the reference's own line values into the same records.
 //   k_ml_accum   SIX LANES PER ACCUMULATOR (ten accumulators per wavefront): lane k holds the coefficient f_k of
 //                f = sum f_k w^k (Fq12 = Fq2[w]/(w^6 - xi)).  A team multiplies the line L of the pairs of its chunk
@@ -20,9 +20,10 @@
 //                squarings, no dependency between line indices.
 //   k_ml_small   groups of a few pairs: one team per group runs the whole loop f <- f^2 prod l on the same lines.
 //   k_ml_merge   dense products of the chunks' partial products (same lane layout).
-//   k_ml_horner_wide  f <- f^2 (before a tangent) ; f <- f M_L over the 68 per-line products of a group, a dense product
-//                spread over 36 lanes; hands the result to the wavefront VM's form (one partial per group for
-//                k_reduce / the final exponentiation).  (k_ml_horner: ten groups per wavefront, kept for comparison.)
+//   k_ml_horner_fexp (blsgpu_fexpw.hip)  f <- f^2 (before a tangent) ; f <- f M_L over the 68 per-line products of a group with
+//                a product per lane, then the final exponentiation in place or the wavefront VM's form of the partial.  (The
+//                forms of rounds 3 - 4 that lost at every size -- one pair per lane, ten groups per Horner wavefront, a dense
+//                product over 36 lanes -- were removed in round 5.)
 //
 // The value differs from the reference's Miller product by the line scalings (Fq2 factors and w^3 per line) that
 // the final exponentiation removes iff they are non-zero: a pair whose Q is off the twist, flagged,
@@ -65,94 +66,6 @@ __device__ __forceinline__ void store_line(int32_t* __restrict__ rec, const int3
         rec[4 * NL + j] = l3a.v[j]; rec[5 * NL + j] = l3b.v[j];
     }
 }
-
-// tangent step (vmgen/programs.t_double): X3 = 2XY(B - F), Y3 = (B + F)^2 - 12 E^2, Z3 = 4 B H with B = Y^2,
-// E = 3b' Z^2, F = 3E, H = 2YZ; line (B - E, X^2 (-3 px), H py)
-__device__ __forceinline__ void tangent_step(fe2& X, fe2& Y, fe2& Z, const fe& px3n, const fe& py2, int32_t* __restrict__ rec) {
-    const fe2 A = r28::mul(X, Y), B = r28::sqr(Y), C = r28::sqr(Z), XX = r28::sqr(X), YZ = r28::mul(Y, Z);
-    const fe2 E = r28::b3(C);
-    const auto F3 = r28::mulc<3>(E);
-    const fe2 BmF = r28::norm(r28::sub(B, F3));
-    const fe2 G = r28::norm(r28::add(B, F3));
-    const fe2 nE12 = r28::mulc_norm<12>(r28::neg(E));
-    const auto l0 = r28::sub(B, E);
-    const fe l2a = r28::mul(XX.a, px3n), l2b = r28::mul(XX.b, px3n);
-    const fe l3a = r28::mul(YZ.a, py2), l3b = r28::mul(YZ.b, py2);
-    store_line(rec, l0.a.v, l0.b.v, l2a, l2b, l3a, l3b);
-    X = r28::mul(r28::add(A, A), BmF);
-    Y = r28::dot2(G, G, nE12, E);
-    Z = r28::mul(B, r28::mulc_norm<8>(YZ));
-}
-// chord step (vmgen/programs.t_add, px_is_m3): th = Y - yq Z, la = X - xq Z, ...; line 3 (th xq - la yq), th (-3 px), la 3 py
-__device__ __forceinline__ void chord_step(fe2& X, fe2& Y, fe2& Z, const fe2& xq, const fe2& yq, const fe& px3n, const fe& py3,
-                                           int32_t* __restrict__ rec) {
-    const fe2 th = r28::norm(r28::sub(Y, r28::mul(yq, Z))), la = r28::norm(r28::sub(X, r28::mul(xq, Z)));
-    const fe2 C = r28::sqr(th), D = r28::sqr(la), E = r28::mul(la, D), Fz = r28::mul(Z, C), Gg = r28::mul(X, D);
-    const fe2 H = r28::norm(r28::sub(r28::add(E, Fz), r28::add(Gg, Gg)));
-    const fe2 GH = r28::norm(r28::sub(Gg, H));
-    const fe2 xq3 = r28::mulc_norm<3>(xq), nyq3 = r28::mulc_norm<3>(r28::neg(yq));
-    const fe2 l0 = r28::dot2(th, xq3, la, nyq3);
-    const fe l2a = r28::mul(th.a, px3n), l2b = r28::mul(th.b, px3n);
-    const fe l3a = r28::mul(la.a, py3), l3b = r28::mul(la.b, py3);
-    store_line(rec, l0.a.v, l0.b.v, l2a, l2b, l3a, l3b);
-    const fe2 nE = r28::norm(r28::neg(E));
-    const fe2 Y3 = r28::dot2(th, GH, nE, Y);
-    X = r28::mul(la, H);
-    Z = r28::mul(Z, E);
-    Y = Y3;
-}
-
-// One pair per lane.  bad[pair] = 1 and the pair goes on the work list iff the fast formulas are not the reference's
-// value for it (Q flagged, Q off the twist, final Z = 0); its lines are then ignored by k_ml_accum.
-#ifndef BLSGPU_ML_LINES_WAVES
-#define BLSGPU_ML_LINES_WAVES 1
-#endif
-__global__ void __launch_bounds__(64, BLSGPU_ML_LINES_WAVES) k_ml_lines(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
-                                                                         int32_t* __restrict__ lines, uint8_t* __restrict__ bad, DegenList dg)
-#if BLSGPU_EMIT(BLSGPU_TU_ML)
-{
-    const uint32_t p = blockIdx.x * 64u + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t* s1 = g1 + (size_t)p * 24;
-    const uint32_t* s2 = g2 + (size_t)p * 48;
-    fe px3n, py2;
-    fe2 X, Y, Z = r28::fe2_one();
-    bool ok = !q_flagged(dg, p);
-    {
-        const fe px = load_coord(s1), py = load_coord(s1 + 12);
-        px3n = r28::mulc_norm<3>(r28::neg(px));
-        py2 = r28::mulc_norm<2>(py);
-        X = {load_coord(s2), load_coord(s2 + 12)};
-        Y = {load_coord(s2 + 24), load_coord(s2 + 36)};
-        // Q on the twist: y^2 - x^3 - 4 (1 + u) = 0
-        const fe2 yy = r28::sqr(Y), xxx = r28::mul(r28::sqr(X), X);
-        const auto four = r28::mulc<4>(r28::fe_one());
-        const auto da = r28::sub(r28::sub(yy.a, xxx.a), four), db = r28::sub(r28::sub(yy.b, xxx.b), four);
-        ok = ok && r28::is_zero(r28::mul(da, r28::fe_one())) && r28::is_zero(r28::mul(db, r28::fe_one()));
-    }
-    int32_t* rec = lines + (size_t)p * LINE_DW;
-    const size_t lstride = (size_t)n * LINE_DW;
-#pragma unroll 1
-    for (int bit = 62; bit >= 0; bit--) {
-        tangent_step(X, Y, Z, px3n, py2, rec);
-        rec += lstride;
-        if ((ML_NX >> bit) & 1ull) {
-            const fe2 xq = {load_coord(s2), load_coord(s2 + 12)}, yq = {load_coord(s2 + 24), load_coord(s2 + 36)};
-            const fe py3 = r28::mulc_norm<3>(load_coord(s1 + 12));
-            chord_step(X, Y, Z, xq, yq, px3n, py3, rec);
-            rec += lstride;
-        }
-    }
-    ok = ok && !r28::is_zero(Z);
-    bad[p] = ok ? 0 : 1;
-    if (!ok) {
-        const uint32_t at = atomicAdd(dg.count, 1u);
-        dg.blocks[at] = p;
-    }
-}
-#else
-;
-#endif
 
 // ---- stage A on LANE PAIRS: an Fq2 value split over two adjacent lanes ---------------------------------------------
 // The even lane holds the real part, the odd lane the imaginary part; the partner's part is one DPP move per limb away
@@ -951,52 +864,6 @@ __global__ void __launch_bounds__(256, 2) k_ml_merge(const int32_t* __restrict__
 ;
 #endif
 
-// Team g: f = M_0; for L = 1 .. 67: (tangent: f <- f^2;) f <- f M_L with M_L = prods[(g * 68 + L) * 168]; then the
-// VM's form: partials[g * pstride + ...] (144 words, the reference's flat order, x 2^384 canonical).
-__global__ void __launch_bounds__(64, 2) k_ml_horner(const int32_t* __restrict__ prods, uint32_t groups, uint32_t* __restrict__ partials,
-                                                     uint32_t pstride)
-#if BLSGPU_EMIT(BLSGPU_TU_ML)
-{
-    __shared__ int32_t own[TEAMS + 1][DENSE_DW];
-    const Team t = team_of_lane();
-    const uint32_t g = blockIdx.x * TEAMS + t.slot;
-    const bool valid = t.slot < (uint32_t)TEAMS && g < groups;
-    const uint32_t gc = valid ? g : 0u;
-    const int32_t* rec = prods + (size_t)gc * LINES * DENSE_DW;
-    int32_t fre[NL], fim[NL];
-#pragma unroll
-    for (int k = 0; k < NL; k++) { fre[k] = rec[t.c * 2 * NL + k]; fim[k] = rec[t.c * 2 * NL + NL + k]; }
-    int32_t* mine = &own[t.slot][0];
-#pragma unroll 1
-    for (uint32_t L = 1; L < (uint32_t)LINES; L++) {
-        if (line_is_tangent(L)) {
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < NL; k++) { mine[t.c * 2 * NL + k] = fre[k]; mine[t.c * 2 * NL + NL + k] = fim[k]; }
-            __syncthreads();
-            mul_dense(fre, fim, t, LdsRec{mine});
-        }
-        mul_dense(fre, fim, t, GlobalRec{rec + (size_t)L * DENSE_DW});
-    }
-    if (valid) {
-        const uint32_t flat = (t.c & 1u) ? 3u + (t.c >> 1) : (t.c >> 1);       // w-powers 0,2,4,1,3,5 in the flat order
-        uint32_t* o = partials + (size_t)g * pstride + flat * 24u;
-        fe a, b;
-#pragma unroll
-        for (int k = 0; k < NL; k++) { a.v[k] = fre[k]; b.v[k] = fim[k]; }
-        uint32_t w[12];
-        r28::to_vm(w, a);
-#pragma unroll
-        for (int k = 0; k < 12; k++) o[k] = w[k];
-        r28::to_vm(w, b);
-#pragma unroll
-        for (int k = 0; k < 12; k++) o[12 + k] = w[k];
-    }
-}
-#else
-;
-#endif
-
 // Small groups (a batch of verifications of a few pairs each: threshold verifies, single signatures): the classic loop
 // f <- f^2 prod_i l_{i,L} with ONE GROUP PER TEAM of six lanes, lines from k_ml_lines2 -- the per-line products of a
 // group of two are not worth an accumulator each, and the group count already fills the chip.
@@ -1079,90 +946,6 @@ __global__ void __launch_bounds__(256, 2) k_ml_small(const int32_t* __restrict__
 ;
 #endif
 
-// The same chain with ONE GROUP PER WAVEFRONT and the six terms of every coefficient on six different lanes: lane
-// (t, k) = 6 t + k computes the one Fq2 product F_{k-t} g_t (two sums of two products), the six products of a coefficient
-// are added across the lanes (ds_bpermute) and every lane ends up with f_k.  A dense product is then ~1.6 k
-// instructions deep instead of ~6.8 k: the chain of 62 squarings and 67 products is what a single long multi-pairing
-// waits for (2.15 -> 0.5 ms).  Lanes 36 .. 63 repeat lanes 0 .. 27.
-__device__ __forceinline__ void wide_op(int32_t* __restrict__ fre, int32_t* __restrict__ fim, const int32_t* __restrict__ yre,
-                                        const int32_t* __restrict__ yim, uint32_t ax, bool wrap, const uint32_t (&ar)[5]) {
-    int32_t nim[NL], xre[NL], xim[NL], nxim[NL];
-#pragma unroll
-    for (int j = 0; j < NL; j++) { nim[j] = -fim[j]; xre[j] = fre[j] - fim[j]; xim[j] = fre[j] + fim[j]; nxim[j] = -xim[j]; }
-    int32_t Xre[NL], Xim[NL], Xnim[NL], a[NL], b[NL];
-    bperm14(a, fre, ax); bperm14(b, xre, ax);
-#pragma unroll
-    for (int j = 0; j < NL; j++) Xre[j] = wrap ? b[j] : a[j];
-    bperm14(a, fim, ax); bperm14(b, xim, ax);
-#pragma unroll
-    for (int j = 0; j < NL; j++) Xim[j] = wrap ? b[j] : a[j];
-    bperm14(a, nim, ax); bperm14(b, nxim, ax);
-#pragma unroll
-    for (int j = 0; j < NL; j++) Xnim[j] = wrap ? b[j] : a[j];
-    int32_t pre[NL], pim[NL];
-    bls28::fp28_dot2(pre, Xre, yre, Xnim, yim);            // units: 1 + 2 (|xi f| limbs below 2^29): inside 8
-    bls28::fp28_dot2(pim, Xre, yim, Xim, yre);
-    r28::F<0, 6> sr, si;
-#pragma unroll
-    for (int j = 0; j < NL; j++) { sr.v[j] = pre[j]; si.v[j] = pim[j]; }
-#pragma unroll
-    for (int u = 0; u < 5; u++) {
-        bperm14(a, pre, ar[u]); bperm14(b, pim, ar[u]);
-#pragma unroll
-        for (int j = 0; j < NL; j++) { sr.v[j] += a[j]; si.v[j] += b[j]; }
-    }
-    const fe nr = r28::norm(sr), ni = r28::norm(si);       // six values in (-q, 2q): digits back below 2^28
-#pragma unroll
-    for (int j = 0; j < NL; j++) { fre[j] = nr.v[j]; fim[j] = ni.v[j]; }
-}
-__global__ void __launch_bounds__(64) k_ml_horner_wide(const int32_t* __restrict__ prods, uint32_t groups, uint32_t* __restrict__ partials,
-                                                       uint32_t pstride)
-#if BLSGPU_EMIT(BLSGPU_TU_ML)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t l36 = lane < 36u ? lane : lane - 36u;
-    const uint32_t t = l36 / 6u, k = l36 - t * 6u;
-    const uint32_t g = blockIdx.x;
-    const int32_t* rec = prods + (size_t)g * LINES * DENSE_DW;
-    const uint32_t ax = (t * 6u + (k >= t ? k - t : k + 6u - t)) * 4u;     // own row, coefficient (k - t) mod 6
-    const bool wrap = t > k;
-    const uint32_t ay = (t * 6u + t) * 4u;                                   // own row, coefficient t
-    uint32_t ar[5];
-#pragma unroll
-    for (int u = 0; u < 5; u++) ar[u] = (((t + 1u + u) % 6u) * 6u + k) * 4u;  // the other rows, same coefficient
-    int32_t fre[NL], fim[NL];
-#pragma unroll
-    for (int j = 0; j < NL; j++) { fre[j] = rec[k * 2 * NL + j]; fim[j] = rec[k * 2 * NL + NL + j]; }
-#pragma unroll 1
-    for (uint32_t L = 1; L < (uint32_t)LINES; L++) {
-        int32_t yre[NL], yim[NL];
-        if (line_is_tangent(L)) {
-            bperm14(yre, fre, ay); bperm14(yim, fim, ay);
-            wide_op(fre, fim, yre, yim, ax, wrap, ar);
-        }
-        const int32_t* m = rec + (size_t)L * DENSE_DW + t * 2 * NL;
-#pragma unroll
-        for (int j = 0; j < NL; j++) { yre[j] = m[j]; yim[j] = m[NL + j]; }
-        wide_op(fre, fim, yre, yim, ax, wrap, ar);
-    }
-    if (lane < 6u && g < groups) {
-        const uint32_t flat = (k & 1u) ? 3u + (k >> 1) : (k >> 1);
-        uint32_t* o = partials + (size_t)g * pstride + flat * 24u;
-        fe a, b;
-#pragma unroll
-        for (int j = 0; j < NL; j++) { a.v[j] = fre[j]; b.v[j] = fim[j]; }
-        uint32_t w[12];
-        r28::to_vm(w, a);
-#pragma unroll
-        for (int j = 0; j < 12; j++) o[j] = w[j];
-        r28::to_vm(w, b);
-#pragma unroll
-        for (int j = 0; j < 12; j++) o[12 + j] = w[j];
-    }
-}
-#else
-;
-#endif
 }  // namespace ml
 
 }  // namespace blsgpu

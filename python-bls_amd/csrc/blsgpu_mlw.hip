@@ -230,5 +230,15 @@ __global__ void __launch_bounds__(256) k_mad_probe(uint32_t* __restrict__ out, u
 #else
 ;
 #endif
+// an empty kernel whose dispatches bracket a timed region in a rocprofv3 trace (blsgpu_timing_mark; tools/collect_profiles.py sums
+// the counters of the dispatches between two of them)
+__global__ void k_mark(uint32_t tag)
+#if BLSGPU_EMIT(BLSGPU_TU_FXW)
+{
+    (void)tag;
+}
+#else
+;
+#endif
 }  // namespace probe
 }  // namespace blsgpu

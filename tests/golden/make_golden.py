@@ -956,6 +956,43 @@ def gen_msm(big):
     dump("msm.json", out)
 
 
+def _msm_chunk(args):
+    """partial sum  sum_i t_i (a_i G1)  over PRF indices [lo, hi) (seed 5: bench.py --config c5), by the reference's own
+    Jacobian scalar multiplication and addition (fields_t.py:705-741, 762-797); also the digest of the chunk's points"""
+    lo, hi = args
+    gj = generator_Fq().to_jacobian()
+    acc, h = None, hashlib.sha256()
+    for i in range(lo, hi):
+        pj = prf_scalar(b"blsgpu/a", 5, i) * gj
+        h.update(g1_bytes(pj.to_affine()))
+        term = prf_scalar(b"blsgpu/t", 5, i) * pj
+        acc = term if acc is None else acc + term
+    a = acc.to_affine()
+    return lo, int(a.x), int(a.y), h.hexdigest()
+
+
+def gen_msm_seeded(n=1 << 20, workers=6):
+    """BASELINE configs[4] at full size: ONE G1 multi-scalar sum over the 2^20 different PRF points of bench.py --config c5
+    (P_i = a_i G1, scalars t_i; seed 5), computed by the reference point by point (2^21 scalar multiplications of pure
+    Python: ~25 minutes on 6 processes).  Records the sum, the digest of the point list by chunks of 4096 and a few points."""
+    import multiprocessing as mp
+    step = 4096
+    with mp.Pool(workers) as pool:
+        parts = pool.map(_msm_chunk, [(lo, min(n, lo + step)) for lo in range(0, n, step)], chunksize=1)
+    parts.sort()
+    acc = None
+    for lo, x, y, _ in parts:
+        pt = AffinePoint(Fq(Q, x), Fq(Q, y), False, default_ec).to_jacobian()
+        acc = pt if acc is None else acc + pt
+    g1 = generator_Fq()
+    samples = {str(i): g1_bytes(prf_scalar(b"blsgpu/a", 5, i) * g1).hex() for i in (0, 1, 4095, 4096, n // 2, n - 1)}
+    dump("msm_seeded_%d.json" % n, {
+        "n": n, "seed": 5, "points": "P_i = prf(blsgpu/a, 5, i) G1", "scalars": "t_i = prf(blsgpu/t, 5, i)",
+        "sum_affine": g1_bytes(acc.to_affine()).hex(),
+        "sha256_of_chunk_digests": hashlib.sha256("".join(d for _, _, _, d in parts).encode()).hexdigest(),
+        "chunk": step, "chunk_point_digests_first_4": [d for _, _, _, d in parts[:4]], "sample_points": samples})
+
+
 def gen_points():
     """Group-law vectors in the boundary's Jacobian tuple form; parity is on
     the affine image (fields_t.py:762-933, 705-741)."""
@@ -991,6 +1028,9 @@ if __name__ == "__main__":
     if "h2c_20000" in only:                 # opt-in: about a minute on 8 cores
         gen_h2c_20000()
         only = [a for a in only if a != "h2c_20000"] or ["-"]
+    if "msm_seeded" in only:                # opt-in: ~25 minutes on 6 processes (BASELINE configs[4] at full size)
+        gen_msm_seeded()
+        only = [a for a in only if a != "msm_seeded"] or ["-"]
     if "seeded8192" in only:                # opt-in: ~10 minutes of pure Python
         gen_seeded_digest(8192)
         only = [a for a in only if a != "seeded8192"] or ["-"]

@@ -2,12 +2,10 @@
 workspace cannot be allocated (VERDICT r3 item 1 d / e): each is reachable through an environment knob read at context
 creation (csrc/blsgpu_api.hip), so each gets the reference's vectors.
 
-  BLSGPU_LS_LINES_FORM=1    k_ml_lines: the point chains with one pair per lane (default: k_ml_lines2, lane pairs)
   BLSGPU_LS_QUAD_MAX=0      k_ml_lines2 (one pair per lane PAIR) for calls of every size: the kernel of bench.py's 524 800-pair
                             step, which calls of up to 20 480 pairs -- every vector here -- otherwise leave to k_ml_lines4
-  BLSGPU_LS_HORNER_FORM=1   k_ml_horner: ten groups per wavefront; =2 k_ml_horner_wide: a product over 36 lanes
-                            (default since round 4: k_ml_horner_fexp, a product per lane, and k_ml_merge_wide for merge
-                            levels with few outputs -- BLSGPU_LS_MERGE_WIDE_MAX=0 keeps k_ml_merge for all of them)
+  BLSGPU_LS_MERGE_WIDE_MAX=0  k_ml_merge (six lanes per value) for every merge level (default: k_ml_merge_wide, one wavefront per
+                            output, for levels with few outputs)
   BLSGPU_MILLER_WIDE_MAX=0  small calls on the wavefront VM's k_miller (four pairs per workgroup + product tree) instead of k_miller_wide
   BLSGPU_VM_EXACT_LANES=0   degenerate blocks of the wavefront-VM kernels recomputed by k_miller_slow
                             (default: k_ml_lines_exact in block mode + k_ml_small in list mode)
@@ -29,11 +27,7 @@ pytestmark = pytest.mark.gpu
 
 FORMS = {
     "point_chains_on_lane_pairs": ({"BLSGPU_LS_QUAD_MAX": "0"}, True),                       # k_ml_lines2 at these sizes
-    "lines_one_pair_per_lane": ({"BLSGPU_LS_LINES_FORM": "1"}, True),
-    "horner_ten_groups_per_wavefront": ({"BLSGPU_LS_HORNER_FORM": "1"}, True),
-    "horner_product_over_36_lanes": ({"BLSGPU_LS_HORNER_FORM": "2"}, True),                # round 3's default
     "merge_levels_six_lanes_per_value": ({"BLSGPU_LS_MERGE_WIDE_MAX": "0"}, True),          # k_ml_merge for every level
-    "both_old_forms": ({"BLSGPU_LS_LINES_FORM": "1", "BLSGPU_LS_HORNER_FORM": "1"}, True),
     "vm_slow_program_for_degenerate_blocks": ({"BLSGPU_VM_EXACT_LANES": "0"}, False),
     "small_calls_on_the_wavefront_vm": ({"BLSGPU_MILLER_WIDE_MAX": "0"}, False),              # k_miller: round 4's default below 4096 pairs
     "line_stream_workspace_unavailable": ({"BLSGPU_TEST_LS_NOMEM": "1"}, True),

@@ -75,9 +75,10 @@ def test_large_batch_properties(engine):
     assert [rev[192 * i:192 * (i + 1)] for i in range(n)] == pts[::-1]
 
 
-def test_one_message_per_lane_clearing(golden):
-    """The register form of the cofactor clearing (the default from 65 536 messages on; BLSGPU_H2C_REG_THRESHOLD), forced for a
-    small batch: reference vectors, infinity summands, ragged counts, and equality with the VM form."""
+def test_register_form_of_the_clearing_on_small_batches(golden):
+    """The register forms of the cofactor clearing (lane quads / lane pairs: the default from 8192 messages on;
+    BLSGPU_H2C_REG_THRESHOLD), forced for small batches: reference vectors, infinity summands, ragged counts, and equality with the
+    VM form."""
     import os
     from bls_py import _native
     old = os.environ.get("BLSGPU_H2C_REG_THRESHOLD")

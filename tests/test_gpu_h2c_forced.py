@@ -3,7 +3,7 @@
 The engine picks its kernels by batch size (csrc/blsgpu_api.hip map_to_g2_impl): encodings on the wavefront VM below
 2048 messages, one encoding per lane (k_h2c_sw0/1/2) from there, the quadratic characters by the binary symbol routine
 (k_h2c_swj0/1/2) from 16 384; cofactor clearing on the VM below 8192, on lane QUADS (k_h2c_clear_quads) up to 16 384
-messages, on lane pairs (k_h2c_clear_pairs) above, one message per lane (k_h2c_clear_reg) as an alternative.  No committed fixture is that large except h2c_20000.json, so
+messages, on lane pairs (k_h2c_clear_pairs) above (round 2's one-message-per-lane form, which lost at every size, was removed in round 5).  No committed fixture is that large except h2c_20000.json, so
 here the thresholds are moved (BLSGPU_H2C_* read at context creation) and EVERY combination runs
 
   * tests/golden/hash_to_curve.json   the reference's hash_to_point_prehashed_Fq2 (ec.py:528-550) and sw_encode
@@ -26,15 +26,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 BIG = str(1 << 40)
-# name -> environment of the context.  enc: vm / lane / jacobi; clear: vm / pairs / quads / reg
+# name -> environment of the context.  enc: vm / lane / jacobi; clear: vm / pairs / quads
 CONFIGS = {}
 for enc, env_enc in (("vm", {"BLSGPU_H2C_LANE_THRESHOLD": BIG}),
                      ("lane", {"BLSGPU_H2C_LANE_THRESHOLD": "1", "BLSGPU_H2C_JACOBI_THRESHOLD": BIG}),
                      ("jacobi", {"BLSGPU_H2C_LANE_THRESHOLD": "1", "BLSGPU_H2C_JACOBI_THRESHOLD": "1"})):
     for clr, env_clr in (("vm", {"BLSGPU_H2C_REG_THRESHOLD": BIG}),
-                         ("pairs", {"BLSGPU_H2C_REG_THRESHOLD": "1", "BLSGPU_H2C_REG_PAIRS": "1", "BLSGPU_H2C_QUAD_MAX": "0"}),
-                         ("quads", {"BLSGPU_H2C_REG_THRESHOLD": "1", "BLSGPU_H2C_REG_PAIRS": "1", "BLSGPU_H2C_QUAD_MAX": BIG}),
-                         ("reg", {"BLSGPU_H2C_REG_THRESHOLD": "1", "BLSGPU_H2C_REG_PAIRS": "0"})):
+                         ("pairs", {"BLSGPU_H2C_REG_THRESHOLD": "1", "BLSGPU_H2C_QUAD_MAX": "0"}),
+                         ("quads", {"BLSGPU_H2C_REG_THRESHOLD": "1", "BLSGPU_H2C_QUAD_MAX": BIG})):
         CONFIGS["%s+%s" % (enc, clr)] = dict(env_enc, **env_clr)
 
 

@@ -2,7 +2,7 @@
 into profiles/ under round names.  ROUND=r02 python tools/collect_profiles.py"""
 import collections, csv, glob, json, os, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RN = os.environ.get("ROUND", "r04")
+RN = os.environ.get("ROUND", "r05")
 R = os.path.join(ROOT, "gpurun_out", RN)
 P = os.path.join(ROOT, "profiles")
 
@@ -80,3 +80,32 @@ with open(os.path.join(P, RN + "_ls_pmc_summary.csv"), "w") as f:
         if "k_ml_" in k:
             f.write("%s,%s,%d,%.6g\n" % (k.replace("void ", ""), c, d, x))
 print(open(os.path.join(P, RN + "_ls_pmc_summary.csv")).read())
+
+
+# HBM traffic per step of the secondary configs: counters of the dispatches BETWEEN the timed region's two marks
+# (blsgpu::probe::k_mark, bench.py), divided by the steps of that run; stamped with the build like the line-stream rows
+def region_total(d, counter):
+    rows = [r for r in csv.DictReader(open(find(d, "*counter_collection.csv"))) if r["Counter_Name"] == counter]
+    marks = sorted(int(r["Dispatch_Id"]) for r in rows if "k_mark" in r["Kernel_Name"])
+    if len(marks) < 2:
+        raise SystemExit("no marks in " + d)
+    lo, hi = marks[-2], marks[-1]
+    return sum(float(r["Counter_Value"]) for r in rows if lo < int(r["Dispatch_Id"]) < hi)
+
+
+with open(os.path.join(P, RN + "_configs_traffic.csv"), "w") as f:
+    f.write("# build %s  (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --config <name> --steps 2`; KB per STEP, "
+            "summed over the dispatches between the timed region's marks)\n" % bench.source_hash())
+    f.write("config,counter,steps,kb_per_step\n")
+    for c in ("c4", "c5", "h2c"):
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = "pmc_%s_%s" % (c, ctr)
+            try:
+                steps = json.loads(json_line(os.path.join(R, d + ".json")))["steps"]
+                f.write("%s,%s,%d,%.6g\n" % (c, ctr, steps, region_total(d, ctr) / steps))
+            except (SystemExit, OSError, KeyError) as e:
+                print("no traffic for", c, ctr, e)
+print(open(os.path.join(P, RN + "_configs_traffic.csv")).read())
+for src, dst in (("miller_wide_probe.jsonl", "_miller_wide_probe.jsonl"),):
+    if os.path.exists(os.path.join(R, src)) and os.path.getsize(os.path.join(R, src)):
+        shutil.copy(os.path.join(R, src), os.path.join(P, RN + dst))

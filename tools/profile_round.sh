@@ -1,7 +1,7 @@
 # Runs on the GPU box (gpurun): the round's bench lines, rocprofv3 kernel stats and PMC passes.
 # ROUND=r04 bash tools/profile_round.sh ; then ROUND=r04 python tools/collect_profiles.py here copies the summaries into profiles/.
 set -e
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
@@ -25,7 +25,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VA
 for c in c4 c5 h2c; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS -d $O/pmc_$c -o p --output-format csv -- python3 bench.py --config $c --steps 1 > $O/pmc_$c.json 2> $O/pmc_$c.err || echo "pmc $c failed"
 done
+# HBM traffic of the secondary configs: FETCH_SIZE / WRITE_SIZE in passes of their own, cut to the timed region by the marks
+for c in c4 c5 h2c; do
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc_${c}_$ctr -o p --output-format csv -- python3 bench.py --config $c --steps 2 > $O/pmc_${c}_$ctr.json 2> $O/pmc_${c}_$ctr.err || echo "pmc $c $ctr failed"
+  done
+done
 echo "pmc done"
+timeout -k 10 200 python tools/miller_wide_probe.py > $O/miller_wide_probe.jsonl 2> $O/miller_wide_probe.err || echo "wide probe failed"
 timeout -k 10 200 python tools/sweep_n.py > $O/sweep_n.jsonl 2> $O/sweep_n.err || echo "sweep failed"
 timeout -k 10 200 python tools/fexp_latency.py > $O/fexp_latency.jsonl 2> $O/fexp_latency.err || echo "fexp latency failed"
 timeout -k 10 100 python tools/fexpw_stamps.py > $O/fexpw_stamps.json 2> $O/fexpw_stamps.err || echo "stamps failed"
