@@ -935,7 +935,7 @@ def run_c4(env, args):
             "config": {"workload": "BASELINE configs[3]: %d groups per GPU, G2 multi-scalar combine of 67 shares + 2-pair verify; "
                                    "bucket method with signed 4-bit digits, one (group, window) per lane PAIR (Fq2 split over two lanes), 8 buckets in HBM, complete mixed additions; verifies: point chains on lane pairs + one accumulator per group (k_ml_lines2, k_ml_small)" % groups, "name": "c4",
                        "steps_in_flight": S, "check": "combine == c_g x reference golden, every verify == 1 (alone and in the timed steps)"},
-            "combine_s": dt_c, "verify_s": dt_v, "one_step_alone_ms": (dt_c + dt_v) * 1e3,
+            "combine_s": dt_c, "verify_s": dt_v, "one_step_alone_ms": (dt_c + dt_v) * 1e3, "value_alone": groups * env.world / (dt_c + dt_v),
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_msm_lane2x (+ k_lane_prep, windows, horner)", "peak": PEAK_TMACS, "unit": "TMAC/s",
                          "achieved": mac_combine * groups / dt_c / 1e12, "frac": mac_combine * groups / dt_c / 1e12 / PEAK_TMACS,
                          "verify_achieved": mac_verify * groups / dt_v / 1e12, "traffic": config_traffic("c4")[0], "traffic_source": config_traffic("c4")[1],
@@ -996,7 +996,8 @@ def run_c5(env, args):
     dt_alone = (time.perf_counter() - t0) / reps
     # the timed steps: three (or --streams) sums in flight on contexts of their own (one GPU: the bit sums / Horner of one sum, a few
     # hundred wavefronts, run beside the next sum's list additions); with a process group the steps stay one after another
-    S = max(3, args.streams) if env.dist is None else 1    # (a sum's tail is a third of its length: three keep the chip busy)
+    # (a sum's tail is a third of its length: three in flight keep the chip busy; an explicit --streams is honoured, 1 = one after another)
+    S = (args.streams if args.streams_given else 3) if env.dist is None else 1
     dt_step, ok_p = dt_alone, True
     if S > 1:
         shards = [shard] + [GpuShardBackend(_native.Engine(env.local_dev), env.dev) for _ in range(S - 1)]
@@ -1019,10 +1020,21 @@ def run_c5(env, args):
         eng.mark(2)
         ok_p = all(bytes(o.cpu().numpy()) == bytes(tout.cpu().numpy()) for o in outs)
     dtm = env.max_over_ranks(dt_step)
+    dt_alone_max = env.max_over_ranks(dt_alone)
     got = bytes(tout.cpu().numpy())
     parts = env.gather_objects(sum(x * y for x, y in zip(a, t)) % N_ORDER)       # sum t_i (a_i G) = (sum t_i a_i) G
     want, _ = eng.g1_msm(gen1, [sum(parts) % N_ORDER], 1, 1)
-    oks = env.gather_objects(got == want and ok_p)
+    check = "sum t_i (a_i G) == (sum t_i a_i) G"
+    ok_ref = True
+    ref = os.path.join(ROOT, "tests", "golden", "msm_seeded_%d.json" % total)
+    if env.rank == 0 and os.path.exists(ref):
+        # the REFERENCE's own sum over these very points and scalars (2^21 scalar multiplications of pure Python,
+        # tests/golden/make_golden.py msm_seeded), and a sample of the input points as the reference computes them
+        with open(ref) as f:
+            fx = json.load(f)
+        ok_ref = got.hex() == fx["sum_affine"] and all(pts[96 * (int(i) - lo):96 * (int(i) - lo + 1)].hex() == p for i, p in fx["sample_points"].items() if lo <= int(i) < hi)
+        check = "the reference's sum over the same 2^20 points and scalars (tests/golden/msm_seeded_%d.json) + %s" % (total, check)
+    oks = env.gather_objects(got == want and ok_p and ok_ref)
     if env.rank == 0:
         if not all(oks):
             raise SystemExit("result mismatch -- bench invalid")
@@ -1039,8 +1051,8 @@ def run_c5(env, args):
                                    "13-bit windows, counting sort of the (window, digit) keys, equal pieces of the sorted list per lane "
                                    "(complete mixed additions on 28-bit limbs in registers), bit sums of the buckets, Horner (DESIGN.md 2d)" % (total, n),
                        "name": "c5", "parallelism": "points split %d ways + all-gather of 100 B per rank" % env.world,
-                       "steps_in_flight": S, "check": "sum t_i (a_i G) == (sum t_i a_i) G"},
-            "one_step_alone_ms": dt_alone * 1e3,
+                       "steps_in_flight": S, "check": check},
+            "one_step_alone_ms": dt_alone * 1e3, "value_alone": total / dt_alone_max,
             "roofline": {"bound": "valu-int32-mac", "kernel": "k_srt_accum (+ k_lane_prep, k_srt_count/scan/scatter/fix/bits, fold, windows, horner)",
                          "peak": PEAK_TMACS, "unit": "TMAC/s", "achieved": mac / dtm / 1e12 / env.world, "frac": mac / dtm / 1e12 / PEAK_TMACS / env.world,
                          "traffic": config_traffic("c5")[0], "traffic_source": config_traffic("c5")[1],
@@ -1141,6 +1153,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only (no GPU): form the process group, all-gather one 576-byte partial per rank over gloo, report")
     args = ap.parse_args()
+    args.streams_given = any(a == "--streams" or a.startswith("--streams=") for a in sys.argv[1:])
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     if args.dry_run:

@@ -123,9 +123,15 @@ int blsgpu_ctx_set_bulk_event(blsgpu_ctx *ctx, void *event);
  * (size_t)-1: never.  Results are identical either way. */
 int blsgpu_ctx_set_fexp_team_threshold(blsgpu_ctx *ctx, size_t results);
 /* Diagnostic: a device buffer of (script length) x 576 bytes that receives the accumulator of result 0 after every
- * operation of the batched final exponentiation's script (tools/fexp_trace.py compares it with the integer model), or
+ * operation of the batched final exponentiation's script -- the six-lanes-per-result form k_fexp_team only; force it with
+ * blsgpu_ctx_set_fexp_team_threshold(ctx, 1) -- (tools/fexp_trace.py compares it with the integer model), or
  * NULL (default). */
 int blsgpu_ctx_set_fexp_trace(blsgpu_ctx *ctx, void *d_buf);
+/* Diagnostic: a device buffer of (script length + 1) x 8 bytes that receives the GPU cycle counter of result 0 before the
+ * one-result-per-wavefront final exponentiation's script (csrc/blsgpu_fexpw.hip) and after every operation of it
+ * (tools/fexpw_stamps.py), or NULL (default).  (A buffer of its own: blsgpu_ctx_set_fexp_trace's holds field elements and is
+ * written by the six-lanes-per-result form only.) */
+int blsgpu_ctx_set_fexpw_stamps(blsgpu_ctx *ctx, void *d_buf);
 /* Diagnostic: the first `bytes` bytes of the line records the last line-stream call left in the workspace
  * (lines[(L * n + pair) * 84] int32, csrc/blsgpu_ml.hip); tools/exact_trace.py compares them with the integer model. */
 int blsgpu_debug_read_lines(blsgpu_ctx *ctx, void *host_buf, size_t bytes);

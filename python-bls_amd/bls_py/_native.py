@@ -23,7 +23,7 @@ SYMBOLS = (
     "blsgpu_g1_decompress", "blsgpu_g2_decompress", "blsgpu_g1_decompress_dev", "blsgpu_g2_decompress_dev",
     "blsgpu_hash_to_g2", "blsgpu_hash_to_g2_dev",
     "blsgpu_miller_loop_batch", "blsgpu_miller_loop_batch_dev", "blsgpu_line_eval_batch", "blsgpu_ctx_trim",
-    "blsgpu_fq12_op_batch", "blsgpu_fq12_pow_batch", "blsgpu_ctx_set_mp3_threshold", "blsgpu_ctx_set_ls_threshold", "blsgpu_ctx_set_ls_teams", "blsgpu_ctx_set_bulk_event", "blsgpu_ctx_set_fexp_team_threshold", "blsgpu_ctx_set_fexp_trace", "blsgpu_debug_read_lines",
+    "blsgpu_fq12_op_batch", "blsgpu_fq12_pow_batch", "blsgpu_ctx_set_mp3_threshold", "blsgpu_ctx_set_ls_threshold", "blsgpu_ctx_set_ls_teams", "blsgpu_ctx_set_bulk_event", "blsgpu_ctx_set_fexp_team_threshold", "blsgpu_ctx_set_fexp_trace", "blsgpu_ctx_set_fexpw_stamps", "blsgpu_debug_read_lines",
     "blsgpu_ctx_workspace_bytes", "blsgpu_verify_pipeline", "blsgpu_verify_pipeline_dev",
 )
 
@@ -72,6 +72,7 @@ def load_library(path=None):
         L.blsgpu_ctx_set_bulk_event.argtypes = [vp, vp]
         L.blsgpu_ctx_set_fexp_team_threshold.argtypes = [vp, sz]
         L.blsgpu_ctx_set_fexp_trace.argtypes = [vp, vp]
+        L.blsgpu_ctx_set_fexpw_stamps.argtypes = [vp, vp]
         L.blsgpu_debug_read_lines.argtypes = [vp, vp, sz]
         L.blsgpu_ctx_workspace_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
         L.blsgpu_verify_pipeline.argtypes = [vp, cp, cp, cp, sz, cp, cp, cp, sz, cp]

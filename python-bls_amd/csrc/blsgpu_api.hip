@@ -96,7 +96,8 @@ struct blsgpu_ctx {
     size_t fexp_team_threshold = 5120; // results per call from which the final exponentiations run six lanes each (blsgpu_fexp.hip); below: one result per wavefront (measured crossover, tools/fexp_latency.py)
     bool fexp_wide = true;             // fewer results than that: one result per wavefront, a product per lane (blsgpu_fexpw.hip); false: the VM program
     size_t fexp_wide_max_partials = 8; // ... which also multiplies up to this many partials per result itself (a dense product is ~2.5 us)
-    void* d_fexp_dbg = nullptr;        // tools/fexp_trace.py: the accumulator of result 0 after every operation of the script
+    void* d_fexp_dbg = nullptr;        // tools/fexp_trace.py: the accumulator of result 0 after every operation of the script (k_fexp_team)
+    void* d_fexpw_stamps = nullptr;    // tools/fexpw_stamps.py: cycle counter of result 0 around every operation of the script (k_fexp_wide)
     void* d_fexp_ws = nullptr;         // their slots
     size_t fexp_ws_cap = 0;
     hipEvent_t bulk_event = nullptr;   // caller's event, recorded after the last chip-filling kernel of a Miller stage
@@ -773,6 +774,13 @@ BLSGPU_EXPORT int blsgpu_ctx_set_fexp_trace(blsgpu_ctx* c, void* d_buf) {
     c->d_fexp_dbg = d_buf;
     return 0;
 }
+// Diagnostic (tools/fexpw_stamps.py): device buffer of (BLS28_FEXP_NOPS + 1) x 8 bytes that receives the cycle counter of result 0
+// before the one-result-per-wavefront final exponentiation's script and after every operation of it, or NULL.
+BLSGPU_EXPORT int blsgpu_ctx_set_fexpw_stamps(blsgpu_ctx* c, void* d_buf) {
+    if (!c) return fail(-EINVAL, "ctx is NULL");
+    c->d_fexpw_stamps = d_buf;
+    return 0;
+}
 BLSGPU_EXPORT int blsgpu_ctx_set_bulk_event(blsgpu_ctx* c, void* event) {
     if (!c) return fail(-EINVAL, "ctx is NULL");
     c->bulk_event = (hipEvent_t)event;
@@ -867,7 +875,7 @@ static int launch_fexp_wide(blsgpu_ctx* c, const uint32_t* d_in, size_t m, size_
                             hipStream_t st) {
     KernelTimer kt(c, st, 2);
     hipLaunchKernelGGL(blsgpu::fxw::k_fexp_wide, dim3((unsigned)groups), dim3(64), 0, st, d_in, (uint32_t)m, (uint32_t)istride,
-                       (uint32_t)gstride, (uint32_t*)d_out_bytes, (unsigned long long*)c->d_fexp_dbg);
+                       (uint32_t)gstride, (uint32_t*)d_out_bytes, (unsigned long long*)c->d_fexpw_stamps);
     HIP_TRY(hipGetLastError());
     return 0;
 }

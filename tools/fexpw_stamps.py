@@ -11,7 +11,7 @@ e = _native.Engine(0)
 e.set_fexp_team_threshold(None)
 S = F.script()
 buf = torch.zeros(len(S) * 576, dtype=torch.uint8, device="cuda")
-e._check(e.lib.blsgpu_ctx_set_fexp_trace(e.h, buf.data_ptr()), "trace")
+e._check(e.lib.blsgpu_ctx_set_fexpw_stamps(e.h, buf.data_ptr()), "stamps")
 g = json.load(open(os.path.join(ROOT, "tests/golden/pairing.json")))
 x = bytes.fromhex(g["gen"]["miller"])
 for _ in range(3):
