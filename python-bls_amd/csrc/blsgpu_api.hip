@@ -21,6 +21,7 @@
 #include "blsgpu_mlw.hip"
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
+#include "blsgpu_h2cw.hip"
 
 #if BLSGPU_EMIT(BLSGPU_TU_HOST)
 namespace {
@@ -62,6 +63,7 @@ struct blsgpu_ctx {
     size_t mp3_threshold = (size_t)-1; // ... with three pairs per wavefront from here on, two below; -1: the measured schedule
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
+    size_t h2c_wide_max = 1024;        // up to this many messages the cofactor clearing runs one message per WAVEFRONT with a product per lane (blsgpu_h2cw.hip: the latency form); 0: never
     size_t h2c_reg_threshold = 8192;   // messages from which cofactor clearing runs in registers (one message per lane PAIR; measured: DESIGN.md 2c)
     size_t h2c_lane_threshold = 2048;  // messages from which the three encoding stages run one encoding per lane (k_h2c_sw0/1/2)
     bool h2c_jacobi = true;            // ... with the quadratic characters decided by a Jacobi-symbol routine: two powers per encoding, not five
@@ -530,6 +532,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_LS_QUAD_MAX")) c->ls_quad_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_H2C_WIDE_MAX")) c->h2c_wide_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_QUAD_MAX")) c->h2c_quad_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_TEST_LS_NOMEM")) c->test_ls_nomem = atoi(e) != 0;
@@ -1521,7 +1524,9 @@ static int map_to_g2_impl(blsgpu_ctx* c, const void* d_in, size_t n, void* d_out
         hipLaunchKernelGGL((blsgpu::k_h2c_stage<2, 0>), dim3((unsigned)teams), dim3(64), lds, st, c->tabs, (const uint32_t*)nullptr,
                            (uint32_t)(2 * n), img);
     HIP_TRY(hipGetLastError());
-    if (n < c->h2c_reg_threshold) {        // the VM form (BLSVM_H2_NM messages per wavefront)
+    if (n <= c->h2c_wide_max && n < c->h2c_reg_threshold) {   // a few messages: one per wavefront, a product per lane (the latency form)
+        hipLaunchKernelGGL(blsgpu::h2cw::k_h2c_clear_wide, dim3((unsigned)n), dim3(64), 0, st, c->tabs, img, (uint32_t)n, (uint32_t*)d_out);
+    } else if (n < c->h2c_reg_threshold) { // the VM form (BLSVM_H2_NM messages per wavefront)
         unsigned b2 = (unsigned)((n + BLSVM_H2_NM - 1) / BLSVM_H2_NM);
         hipLaunchKernelGGL(blsgpu::k_h2c_clear, dim3(b2), dim3(64), (size_t)blsgpu::H2_TEAM_DW * 4, st, c->tabs, img, (uint32_t)n,
                            (uint32_t*)d_out);

@@ -42,8 +42,26 @@ QD = to_limbs(Q)
 
 # ---- the value file: names -> (page, quad) ------------------------------------------------------------------------------
 class Names:
+    """a value file layout: names -> (page, quad); "ZERO" and "TRASH" must be among them"""
+
     def __init__(self):
         self.at = {}
+
+    @property
+    def zero(self):
+        return self.slot("ZERO")
+
+    @property
+    def trash(self):
+        return self.slot("TRASH")
+
+    def src(self, term):
+        """dword address of one (coefficient, source) term of an operand"""
+        c, s = term
+        if isinstance(s, tuple):                   # ("line", buffer, kind, coefficient, part): the value itself only
+            assert c == 1
+            return line_slot(*s[1:])
+        return self.slot(s, c)
 
     def put(self, page, quad, *names):
         for i, n in enumerate(names):
@@ -83,19 +101,12 @@ def T(*terms):
     return list(terms)
 
 
-def _src(term):
-    c, s = term
-    if isinstance(s, tuple):
-        assert c == 1
-        return line_slot(*s[1:])
-    return N.slot(s, c)
-
-
 class Step:
     """one step kind: up to 16 outputs, each on a lane quad; the per-lane table it compiles to"""
 
-    def __init__(self, name, outputs):
-        self.name, self.outputs = name, outputs
+    def __init__(self, name, outputs, names=None):
+        names = names or N
+        self.name, self.outputs, self.names = name, outputs, names
         assert len(outputs) <= 16
         # the shape the kernel specialises on: K products per lane (1 when no output has more than four), and whether every
         # second operand is ONE slot (the sparse products: a line coefficient)
@@ -115,14 +126,14 @@ class Step:
                     p = prods[i] if i is not None and i < len(prods) else ([], [])
                     for operand in p:
                         assert len(operand) <= 2
-                        s = [_src(x) for x in operand] + [ZERO, ZERO]
+                        s = [names.src(x) for x in operand] + [names.zero, names.zero]
                         ops += s[:2]
                 if dst is None:
-                    d = TRASH
+                    d = names.trash
                 elif isinstance(dst, tuple):       # a line coefficient: the value itself only
-                    d = line_slot(*dst[1:]) if r == 0 else TRASH
+                    d = line_slot(*dst[1:]) if r == 0 else names.trash
                 else:
-                    d = N.slot(dst, VARIANT[r])
+                    d = names.slot(dst, VARIANT[r])
                 self.rec.append(tuple(ops) + (d, scale * VARIANT[r]))
 
     def symbolic(self, val):
@@ -337,7 +348,8 @@ def scale_reduce_norm(t, s):
 class Machine:
     """the value file of one workgroup; step() executes one step kind's table for all 64 lanes of a wavefront"""
 
-    def __init__(self):
+    def __init__(self, names=None, kinds=None):
+        self.names, self.kinds = names or N, kinds or KINDS
         self.vf = {}                               # slot address -> 14 digits
         self.max_abs = 0.0                         # largest |stored value| / q seen
         self.store_value("ZERO", 0)
@@ -351,10 +363,10 @@ class Machine:
         """x (a residue) in Montgomery form, in its four multiples, the way the kernel stores an input"""
         d = to_limbs(x * R % Q)
         for r, c in enumerate(VARIANT):
-            self.vf[N.slot(name, c)] = scale_reduce_norm(d, c)
+            self.vf[self.names.slot(name, c)] = scale_reduce_norm(d, c)
 
     def value(self, name):
-        return from_limbs(self.rd(N.slot(name))) * pow(R, -1, Q) % Q
+        return from_limbs(self.rd(self.names.slot(name))) * pow(R, -1, Q) % Q
 
     def line(self, buf, kind):
         rinv = pow(R, -1, Q)
@@ -362,7 +374,8 @@ class Machine:
                      for c in range(3))
 
     def step(self, kind):
-        rec = KINDS[kind].rec
+        rec = self.kinds[kind].rec
+        TRASH = self.names.trash
         P = []
         for lane in range(LANES):
             a1, a2, b1, b2, a3, a4, b3, b4, dst, scale = rec[lane]

@@ -2,7 +2,8 @@
 
 The engine picks its kernels by batch size (csrc/blsgpu_api.hip map_to_g2_impl): encodings on the wavefront VM below
 2048 messages, one encoding per lane (k_h2c_sw0/1/2) from there, the quadratic characters by the binary symbol routine
-(k_h2c_swj0/1/2) from 16 384; cofactor clearing on the VM below 8192, on lane QUADS (k_h2c_clear_quads) up to 16 384
+(k_h2c_swj0/1/2) from 16 384; cofactor clearing one message per WAVEFRONT with a product per lane (k_h2c_clear_wide, round 5: the
+latency form) up to 1024 messages, on the VM below 8192, on lane QUADS (k_h2c_clear_quads) up to 16 384
 messages, on lane pairs (k_h2c_clear_pairs) above (round 2's one-message-per-lane form, which lost at every size, was removed in round 5).  No committed fixture is that large except h2c_20000.json, so
 here the thresholds are moved (BLSGPU_H2C_* read at context creation) and EVERY combination runs
 
@@ -26,12 +27,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 BIG = str(1 << 40)
-# name -> environment of the context.  enc: vm / lane / jacobi; clear: vm / pairs / quads
+# name -> environment of the context.  enc: vm / lane / jacobi; clear: wide / vm / pairs / quads
 CONFIGS = {}
 for enc, env_enc in (("vm", {"BLSGPU_H2C_LANE_THRESHOLD": BIG}),
                      ("lane", {"BLSGPU_H2C_LANE_THRESHOLD": "1", "BLSGPU_H2C_JACOBI_THRESHOLD": BIG}),
                      ("jacobi", {"BLSGPU_H2C_LANE_THRESHOLD": "1", "BLSGPU_H2C_JACOBI_THRESHOLD": "1"})):
-    for clr, env_clr in (("vm", {"BLSGPU_H2C_REG_THRESHOLD": BIG}),
+    for clr, env_clr in (("wide", {"BLSGPU_H2C_REG_THRESHOLD": BIG, "BLSGPU_H2C_WIDE_MAX": BIG}),
+                         ("vm", {"BLSGPU_H2C_REG_THRESHOLD": BIG, "BLSGPU_H2C_WIDE_MAX": "0"}),
                          ("pairs", {"BLSGPU_H2C_REG_THRESHOLD": "1", "BLSGPU_H2C_QUAD_MAX": "0"}),
                          ("quads", {"BLSGPU_H2C_REG_THRESHOLD": "1", "BLSGPU_H2C_QUAD_MAX": BIG})):
         CONFIGS["%s+%s" % (enc, clr)] = dict(env_enc, **env_clr)
