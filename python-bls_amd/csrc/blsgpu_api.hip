@@ -63,7 +63,7 @@ struct blsgpu_ctx {
     size_t mp3_threshold = (size_t)-1; // ... with three pairs per wavefront from here on, two below; -1: the measured schedule
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
-    size_t h2c_wide_max = 1024;        // up to this many messages the cofactor clearing runs one message per WAVEFRONT with a product per lane (blsgpu_h2cw.hip: the latency form); 0: never
+    size_t h2c_wide_max = 2048;        // up to this many messages the cofactor clearing runs one message per WAVEFRONT with a product per lane (blsgpu_h2cw.hip: the latency form); 0: never
     size_t h2c_reg_threshold = 8192;   // messages from which cofactor clearing runs in registers (one message per lane PAIR; measured: DESIGN.md 2c)
     size_t h2c_lane_threshold = 2048;  // messages from which the three encoding stages run one encoding per lane (k_h2c_sw0/1/2)
     bool h2c_jacobi = true;            // ... with the quadratic characters decided by a Jacobi-symbol routine: two powers per encoding, not five

@@ -3,7 +3,7 @@
 The engine picks its kernels by batch size (csrc/blsgpu_api.hip map_to_g2_impl): encodings on the wavefront VM below
 2048 messages, one encoding per lane (k_h2c_sw0/1/2) from there, the quadratic characters by the binary symbol routine
 (k_h2c_swj0/1/2) from 16 384; cofactor clearing one message per WAVEFRONT with a product per lane (k_h2c_clear_wide, round 5: the
-latency form) up to 1024 messages, on the VM below 8192, on lane QUADS (k_h2c_clear_quads) up to 16 384
+latency form) up to 2048 messages, on the VM below 8192, on lane QUADS (k_h2c_clear_quads) up to 16 384
 messages, on lane pairs (k_h2c_clear_pairs) above (round 2's one-message-per-lane form, which lost at every size, was removed in round 5).  No committed fixture is that large except h2c_20000.json, so
 here the thresholds are moved (BLSGPU_H2C_* read at context creation) and EVERY combination runs
 

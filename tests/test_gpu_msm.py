@@ -489,8 +489,11 @@ def test_c4_full_size_10000_groups(engine, golden):
 
 def test_c5_full_size_distinct_points(engine, golden):
     """BASELINE configs[4] at full size with the DEFAULT kernel selection: one G1 multi-scalar sum over
-    2^20 DIFFERENT points a_i G (PRF scalars), checked by  sum t_i (a_i G) = (sum t_i a_i) G  (the reference's 1024-key
-    aggregate through the same kernels: test_reference_1024_key_aggregate_through_sorted_buckets)."""
+    2^20 DIFFERENT points a_i G (PRF scalars) against the REFERENCE's own sum over the same points and scalars
+    (tests/golden/msm_seeded_1048576.json: 2^21 scalar multiplications of the reference's pure Python, fields_t.py:705-741 and
+    :762-797 through ec.py, generated by tests/golden/make_golden.py msm_seeded), the reference's digests of the first 16 384
+    input points and six sample points; and by  sum t_i (a_i G) = (sum t_i a_i) G."""
+    import hashlib
     gen1 = bytes.fromhex(golden("pairing.json")["gen"]["g1"])
     n = 1 << 20
     a = [_prf(b"blsgpu/a", 5, i) for i in range(n)]
@@ -501,9 +504,17 @@ def test_c5_full_size_distinct_points(engine, golden):
         pts += p
     sample = [pts[96 * i:96 * (i + 1)] for i in range(0, n, 257)]
     assert len(set(sample)) == len(sample)
+    fx = golden("msm_seeded_1048576.json")
+    assert fx["n"] == n and fx["seed"] == 5
+    for i, want_pt in fx["sample_points"].items():                 # the inputs as the reference computes them
+        assert pts[96 * int(i):96 * (int(i) + 1)].hex() == want_pt, i
+    step = fx["chunk"]
+    for k, d in enumerate(fx["chunk_point_digests_first_4"]):
+        assert hashlib.sha256(pts[96 * step * k:96 * step * (k + 1)]).hexdigest() == d, k
     got, inf = engine.g1_msm(pts, t, n, 1)
+    assert got.hex() == fx["sum_affine"] and not inf[0]           # the reference's sum
     want, _ = engine.g1_msm(gen1, [sum(x * y for x, y in zip(a, t)) % N_ORDER], 1, 1)
-    assert got == want and not inf[0]
+    assert got == want
     # plain sum (scalars = NULL) of the same points
     got, _ = engine.g1_msm(pts, None, n, 1)
     want, _ = engine.g1_msm(gen1, [sum(a) % N_ORDER], 1, 1)
