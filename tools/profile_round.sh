@@ -1,10 +1,13 @@
 # Runs on the GPU box (gpurun): the round's bench lines, rocprofv3 kernel stats and PMC passes.
-# ROUND=r04 bash tools/profile_round.sh ; then ROUND=r04 python tools/collect_profiles.py here copies the summaries into profiles/.
+# ROUND=r05 PART=A bash tools/profile_round.sh ; ROUND=r05 PART=B bash tools/profile_round.sh  (two gpurun calls: a call is limited to
+# 20 minutes) ; then ROUND=r05 python tools/collect_profiles.py here copies the summaries into profiles/.
 set -e
 R=${ROUND:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R
 mkdir -p $O
+PART=${PART:-AB}
+if [[ $PART == *A* ]]; then
 timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench done"
 timeout -k 10 200 python bench.py --gpus 2 --backend gloo --steps 8 --warmup 2 > $O/bench_2rank_gloo_rehearsal.json 2> $O/bench_2rank.err
@@ -19,6 +22,8 @@ for c in c4 c5 h2c; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt_$c -o kt --output-format csv -- python3 bench.py --config $c --steps 2 > $O/kt_$c.json 2> $O/kt_$c.err
 done
 echo "kernel traces done"
+fi
+if [[ $PART == *B* ]]; then
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency --no-secondary > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency --no-secondary > $O/pmc_write.json 2> $O/pmc_write.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS -d $O/pmc_sq -o s --output-format csv -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-latency --no-secondary > $O/pmc_sq.json 2> $O/pmc_sq.err
@@ -38,4 +43,5 @@ timeout -k 10 200 python tools/fexp_latency.py > $O/fexp_latency.jsonl 2> $O/fex
 timeout -k 10 100 python tools/fexpw_stamps.py > $O/fexpw_stamps.json 2> $O/fexpw_stamps.err || echo "stamps failed"
 timeout -k 10 100 python tools/h2c_sweep.py 16384 65536 262144 > $O/h2c_sweep.jsonl 2> $O/h2c_sweep.err || echo "h2c sweep failed"
 timeout -k 10 200 python tools/pipeline_rate.py 256 > $O/pipeline_rate.json 2> $O/pipeline_rate.err || echo "pipeline failed"
+fi
 cat $O/bench_default.json
