@@ -58,6 +58,7 @@ struct blsgpu_ctx {
     uint32_t* d_out = nullptr;         // 576-byte result staging
     uint32_t* d_degen = nullptr;       // [0] count, [1 ..] block indices of degenerate pairs (k_miller_slow's work list)
     size_t degen_cap = 0;
+    size_t miller_wide3_max = 256;     // ... with the accumulator split over two wavefronts (three per pair) up to this many pairs: three SIMDs per pair are free
     size_t miller_wide_max = 1536;     // calls of at most this many pairs run the wide Miller loop (blsgpu_mlw.hip: one pair per two-wavefront workgroup, a product per lane); 0: never
     size_t mp_threshold = 4096;        // pairs from which k_miller_mp is used
     size_t mp3_threshold = (size_t)-1; // ... with three pairs per wavefront from here on, two below; -1: the measured schedule
@@ -519,6 +520,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     blsgpu_ctx* c = new blsgpu_ctx();
     c->device = device;
     c->mp_threshold = default_mp_threshold();
+    if (const char* e = getenv("BLSGPU_MILLER_WIDE3_MAX")) c->miller_wide3_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MILLER_WIDE_MAX")) c->miller_wide_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MP3_THRESHOLD")) c->mp3_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_THRESHOLD")) c->ls_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -951,8 +953,12 @@ static int launch_miller(blsgpu_ctx* c, const void* d_g1, const void* d_g2, cons
     HIP_TRY(hipMemsetAsync(c->d_degen, 0, sizeof(uint32_t), st));
     if (wide) {
         KernelTimer kt(c, st, 0);
-        hipLaunchKernelGGL(blsgpu::mlw::k_miller_wide, dim3((unsigned)(bpg * groups)), dim3(128), 0, st, (const uint32_t*)d_g1,
-                           (const uint32_t*)d_g2, (uint32_t)(gsz * groups), d_partials, dg);
+        if (gsz * groups <= c->miller_wide3_max)
+            hipLaunchKernelGGL(blsgpu::mlw::k_miller_wide<3>, dim3((unsigned)(bpg * groups)), dim3(192), 0, st, (const uint32_t*)d_g1,
+                               (const uint32_t*)d_g2, (uint32_t)(gsz * groups), d_partials, dg);
+        else
+            hipLaunchKernelGGL(blsgpu::mlw::k_miller_wide<2>, dim3((unsigned)((bpg * groups + 1) / 2)), dim3(256), 0, st, (const uint32_t*)d_g1,
+                               (const uint32_t*)d_g2, (uint32_t)(gsz * groups), d_partials, dg);
     } else if (mp2) {
         KernelTimer kt(c, st, 0);
         hipLaunchKernelGGL(blsgpu::k_miller_mp<2>, dim3((unsigned)(bpg * groups)), dim3(64), (size_t)blsgpu::MP_TEAM_BYTES, st, c->tabs,

@@ -72,10 +72,10 @@ __device__ __forceinline__ void rd1(int32_t* __restrict__ out, const char* vf, u
 #pragma unroll
     for (int j = 0; j < NL; j++) out[j] = *reinterpret_cast<const int32_t*>(pa + 256 * j);
 }
-// One step of a wavefront, in the three shapes the tables use (bits 8 - 9 of a program word): K products per lane; BS: every second
-// operand is one slot (its second address is ignored).  Column bound of fp28_dot2 (units of 2^56): every stored limb is below 2^28,
+// One step of a wavefront, in the four shapes the tables use (bits 8 - 9 of a program word): K products per lane; BS: every second
+// operand is one slot (its second address is ignored); OCT: eight lanes per output (a third level of the lane sum).  Column bound of fp28_dot2 (units of 2^56): every stored limb is below 2^28,
 // an operand the sum of two: 2 x (2 x 2) = 8, what 64 bits hold.
-template <int K, bool BS>
+template <int K, bool BS, bool OCT = false>
 __device__ __forceinline__ void wstep(char* vf, const Rec& r) {
     int32_t A0[NL], B0[NL], p[NL], t[NL], V[NL];
     rd2(A0, vf, r.w[0]);
@@ -92,6 +92,7 @@ __device__ __forceinline__ void wstep(char* vf, const Rec& r) {
     for (int j = 0; j < NL; j++) {
         const int32_t u = p[j] + __builtin_amdgcn_update_dpp(0, p[j], 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
         t[j] = u + __builtin_amdgcn_update_dpp(0, u, 0x4E, 0xF, 0xF, true);                       // quad_perm [2,3,0,1]
+        if (OCT) t[j] += __builtin_amdgcn_update_dpp(0, t[j], 0x141, 0xF, 0xF, true);             // row_half_mirror: the other quad of the eight lanes
     }
     srn(V, t, (int32_t)r.w[4] >> 16);
     st14(vf, r.w[4] & 0xFFFFu, V);
@@ -106,20 +107,34 @@ __device__ __forceinline__ bool stored_zero(const char* vf, uint32_t a) {
 
 // Block b = pair b of the call (group b / gsz): its Miller value (up to the factors the final exponentiation removes) as
 // ONE partial in the wavefront VM's form: partials[b * 144 ...] (12 x 12 words x 2^384, the reference's flat order).
-__global__ void __launch_bounds__(128) k_miller_wide(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
-                                                     uint32_t* __restrict__ partials, DegenList dg)
+// W = 2: wave 0 the accumulator, wave 1 the chain.  W = 3 (calls of so few pairs that three SIMDs per pair are free): the accumulator's
+// steps split over waves 0 and 1 -- an output's products on eight lanes, ONE per lane, so an accumulator step costs what a chain step
+// costs (780 instead of ~1000 instructions) and a barrier follows each; wave 2 the chain.
+// The two-wavefront form carries TWO pairs per workgroup (256 threads: four wavefronts, one per SIMD of a CU -- 128-thread workgroups
+// were stacked on two SIMDs of a CU while the other two stayed empty: 342 - 512 pairs took 0.44 ms instead of 0.32); the pairs share
+// nothing but the barriers.
+template <int W>
+__global__ void __launch_bounds__(W == 2 ? 256 : 192) k_miller_wide(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
+                                                                    uint32_t* __restrict__ partials, DegenList dg)
 #if BLSGPU_EMIT(BLSGPU_TU_FXW)
 {
-    __shared__ int32_t vfile[VF_DW];
-    __shared__ int32_t bad_flag;
-    char* vf = reinterpret_cast<char*>(vfile);
+    constexpr uint32_t PAIRS = W == 2 ? 2u : 1u;
+    __shared__ int32_t vfiles[PAIRS][VF_DW];
+    __shared__ int32_t bad_flags[PAIRS];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t pair = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)VF_DW; i += 128u) vfile[i] = 0;
-    if (threadIdx.x == 0) bad_flag = 0;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t slot = wv / (uint32_t)W, wave = wv - slot * (uint32_t)W;
+    const uint32_t pair_raw = blockIdx.x * PAIRS + slot;
+    const bool active = pair_raw < n;
+    const uint32_t pair = active ? pair_raw : n - 1u;              // (an odd call's spare half repeats the last pair and writes nothing)
+    int32_t* vfile = vfiles[slot];
+    int32_t& bad_flag = bad_flags[slot];
+    char* vf = reinterpret_cast<char*>(vfile);
+    for (uint32_t i = wave * 64u + lane; i < (uint32_t)VF_DW; i += 64u * W) vfile[i] = 0;
+    if (wave == 0u && lane == 0u) bad_flag = 0;
     __syncthreads();
-    if (wave == 1u) {
+    constexpr uint32_t CHAIN = W - 1;
+    if (wave == CHAIN) {
         // the inputs in their four multiples: quad i of this wavefront stores value i of the list below
         const uint32_t qd = lane >> 2, vr = lane & 3u;
         const int32_t variant = vr == 0u ? 1 : (vr == 1u ? -1 : (vr == 2u ? 2 : -2));
@@ -147,12 +162,12 @@ __global__ void __launch_bounds__(128) k_miller_wide(const uint32_t* __restrict_
     }
     __syncthreads();
     // the wavefront's program: word pc + 2 is fetched (a scalar load) while step pc runs, the lanes' records of step pc + 1 as well
-    const uint32_t* prog = wave ? MLW_PROG_CHAIN : MLW_PROG_ACC;
+    const uint32_t* prog = W == 2 ? (wave ? MLW_PROG_CHAIN : MLW_PROG_ACC) : (wave == 0u ? MLW3_PROG_A : (wave == 1u ? MLW3_PROG_B : MLW3_PROG_C));
     uint32_t pc = 0;
     uint32_t k1 = prog[0], k2 = prog[1];
     Rec r1 = load_rec(k1 & 0x3Fu, lane);
 #pragma unroll 1
-    for (uint32_t ph = 0; ph < (uint32_t)MLW_PHASES; ph++) {
+    for (uint32_t ph = 0; ph < (uint32_t)(W == 2 ? MLW_PHASES : MLW3_PHASES); ph++) {
 #pragma unroll 1
         while (true) {
             const uint32_t k = k1;
@@ -163,29 +178,30 @@ __global__ void __launch_bounds__(128) k_miller_wide(const uint32_t* __restrict_
             r1 = load_rec(k1 & 0x3Fu, lane);
             if ((k & 0x3Fu) != (uint32_t)MLW_NOP) {
                 const uint32_t shape = (k >> 8) & 3u;
-                if (shape == 0u) wstep<2, false>(vf, r);
+                if (W == 3 && shape == 3u) wstep<1, false, true>(vf, r);
+                else if (shape == 2u || W == 3) wstep<1, false>(vf, r);          // (the three-wavefront programs have no two-product steps)
                 else if (shape == 1u) wstep<2, true>(vf, r);
-                else wstep<1, false>(vf, r);
+                else wstep<2, false>(vf, r);
             }
             if (k & (uint32_t)MLW_LAST) break;
         }
         __syncthreads();
     }
-    if (wave == 1u) {
+    if (wave == CHAIN) {
         // the fast formulas are the reference's value iff Q is on the twist, the chain did not end at Z = 0 and Q is not flagged
         const bool on_twist = stored_zero(vf, MLW_AT_D0) && stored_zero(vf, MLW_AT_D1);
         const bool z_zero = stored_zero(vf, MLW_AT_Z0) && stored_zero(vf, MLW_AT_Z1);
         if (lane == 0u && (!on_twist || z_zero || q_flagged(dg, pair))) bad_flag = 1;
     }
     __syncthreads();
-    if (wave == 0u) {
+    if (wave == 0u && active) {
         const uint32_t quad = lane >> 2;
         if (quad < 12u && (lane & 3u) == 0u) {
             const uint32_t k = quad >> 1, part = quad & 1u;
             const uint32_t flat = (k & 1u) ? 3u + (k >> 1) : (k >> 1);             // w-powers 0,2,4,1,3,5 in the flat order
             fe a;
 #pragma unroll
-            for (int j = 0; j < NL; j++) a.v[j] = *reinterpret_cast<const int32_t*>(vf + MLW_AT_F00 + 4u * lane + 256 * j);
+            for (int j = 0; j < NL; j++) a.v[j] = *reinterpret_cast<const int32_t*>(vf + (W == 2 ? MLW_AT_F00 : MLW3_AT_F_FINAL) + 4u * lane + 256 * j);
             uint32_t w[12];
             r28::to_vm(w, a);
             uint32_t* o = partials + (size_t)pair * 144 + flat * 24u + part * 12u;
@@ -197,10 +213,13 @@ __global__ void __launch_bounds__(128) k_miller_wide(const uint32_t* __restrict_
             dg.blocks[at] = pair;
         }
     }
-    (void)n;
 }
 #else
 ;
+#endif
+// every instantiation the host side launches: this translation unit is the one that emits them (blsgpu_tu.h)
+#if BLSGPU_TU == BLSGPU_TU_FXW
+__attribute__((used)) static const void* const blsgpu_instances_mlw[] = {(const void*)&k_miller_wide<2>, (const void*)&k_miller_wide<3>};
 #endif
 }  // namespace mlw
 

@@ -85,7 +85,9 @@ N.put(2, 0, "A0", "A1", "B0", "B1", "E0", "E1", "F0", "F1", "XX0", "XX1", "YZ0",
 N.put(3, 0, "TH0", "TH1", "LA0", "LA1", "CC0", "CC1", "DD0", "DD1", "CE0", "CE1", "H0", "H1", "GG0", "GG1")
 # page 4: two line buffers of (tangent l0 l2 l3, chord l0 l2 l3), parts interleaved; only the value itself is stored, one
 # slot per value: buffer b, line kind t (0 tangent, 1 chord), coefficient c, part p at slot 12 b + 6 t + 2 c + p
-PAGES = 5
+# page 5: the accumulator's second copy (three-wavefront form: the two accumulator waves read one copy and write the other)
+N.put(5, 0, *["g%d%d" % (k, p) for k in range(6) for p in range(2)])
+PAGES = 6
 LINE_PAGE = 4
 ZERO = N.slot("ZERO")
 TRASH = N.slot("TRASH")
@@ -104,22 +106,24 @@ def T(*terms):
 class Step:
     """one step kind: up to 16 outputs, each on a lane quad; the per-lane table it compiles to"""
 
-    def __init__(self, name, outputs, names=None):
+    def __init__(self, name, outputs, names=None, group=4):
         names = names or N
-        self.name, self.outputs, self.names = name, outputs, names
-        assert len(outputs) <= 16
-        # the shape the kernel specialises on: K products per lane (1 when no output has more than four), and whether every
-        # second operand is ONE slot (the sparse products: a line coefficient)
-        self.K = 1 if all(len(prods) <= 4 for _, _, prods in outputs) else 2
+        self.name, self.outputs, self.names, self.group = name, outputs, names, group
+        assert group in (4, 8) and len(outputs) <= LANES // group
+        # the shape the kernel specialises on: K products per lane (1 when no output has more products than its group has lanes), and
+        # whether every second operand is ONE slot (the sparse products: a line coefficient).  group = 8 (the three-wavefront form):
+        # an output's up to eight products on eight lanes, one each; its four multiples are written by the group's first four lanes
+        self.K = 1 if all(len(prods) <= group for _, _, prods in outputs) else 2
+        assert group == 4 or self.K == 1
         self.b_single = all(len(b) <= 1 for _, _, prods in outputs for _, b in prods)
         self.rec = []                              # per lane: (a1, a2, b1, b2, a3, a4, b3, b4, dst, scale)
-        for g in range(16):
+        for g in range(LANES // group):
             if g < len(outputs):
                 dst, scale, prods = outputs[g]
                 assert len(prods) <= 8, (name, dst, len(prods))
             else:
                 dst, scale, prods = None, 0, []
-            for r in range(4):
+            for r in range(group):
                 ops = []
                 for t in range(2):
                     i = self.K * r + t if t < self.K else None
@@ -128,13 +132,13 @@ class Step:
                         assert len(operand) <= 2
                         s = [names.src(x) for x in operand] + [names.zero, names.zero]
                         ops += s[:2]
-                if dst is None:
+                if dst is None or r >= 4:
                     d = names.trash
                 elif isinstance(dst, tuple):       # a line coefficient: the value itself only
                     d = line_slot(*dst[1:]) if r == 0 else names.trash
                 else:
                     d = names.slot(dst, VARIANT[r])
-                self.rec.append(tuple(ops) + (d, scale * VARIANT[r]))
+                self.rec.append(tuple(ops) + (d, scale * VARIANT[r & 3]))
 
     def symbolic(self, val):
         """evaluate mod q on a dict name -> residue (lines: key = the tuple); returns {dst: value}"""
@@ -156,8 +160,9 @@ def _fq2_sqr(x):
     return re, im
 
 
-def build_sqr():
-    """f <- f^2 in Fq2[w]/(w^6 - xi): c_k = sum over unordered {s, t}, s + t = k mod 6 (xi when s + t >= 6)"""
+def build_sqr(part_of=None, group=4, name="SQR", src="f", dst="f"):
+    """f <- f^2 in Fq2[w]/(w^6 - xi): c_k = sum over unordered {s, t}, s + t = k mod 6 (xi when s + t >= 6); part_of = (lo, hi):
+    only the outputs lo .. hi - 1 of the twelve (the three-wavefront form splits them over two wavefronts)"""
     outs = []
     for k in range(6):
         for part in range(2):
@@ -167,7 +172,7 @@ def build_sqr():
                 if s > t:
                     continue
                 wrap = s + t >= 6
-                a, b = "f%d" % s, "f%d" % t
+                a, b = "%s%d" % (src, s), "%s%d" % (src, t)
                 if s == t:
                     sq = (T((1, a + "0"), (1, a + "1")), T((1, a + "0"), (-1, a + "1")))           # re of f_s^2
                     cr = lambda c: (T((c, a + "0")), T((1, a + "1")))                              # c/2 x im of f_s^2
@@ -186,11 +191,13 @@ def build_sqr():
                         prods += [(fr, T((1, b + "0"))), (nfi, T((1, b + "1")))]
                     else:
                         prods += [(fr, T((1, b + "1"))), (fi, T((1, b + "0")))]
-            outs.append(("f%d%d" % (k, part), 1, prods))
-    return Step("SQR", outs)
+            outs.append(("%s%d%d" % (dst, k, part), 1, prods))
+    if part_of:
+        outs = outs[part_of[0]:part_of[1]]
+    return Step(name, outs, group=group)
 
 
-def build_mul_line(buf, kind):
+def build_mul_line(buf, kind, part_of=None, group=4, suffix="", src="f", dst="f"):
     """f <- f l for the line in buffer `buf` (kind 0 tangent, 1 chord): c_k = F_k l0 + F_{k-2} l2 + F_{k-3} l3,
     F_i = f_i (i >= 0) or xi f_{i+6}"""
     outs = []
@@ -199,7 +206,7 @@ def build_mul_line(buf, kind):
             prods = []
             for c, j in enumerate(LS.LINE_POS):
                 s, wrap = (k - j) % 6, j > k
-                a = "f%d" % s
+                a = "%s%d" % (src, s)
                 y0, y1 = ("line", buf, kind, c, 0), ("line", buf, kind, c, 1)
                 if wrap:
                     fr, fi, nfi = T((1, a + "0"), (-1, a + "1")), T((1, a + "0"), (1, a + "1")), T((-1, a + "0"), (-1, a + "1"))
@@ -209,8 +216,10 @@ def build_mul_line(buf, kind):
                     prods += [(fr, T((1, y0))), (nfi, T((1, y1)))]
                 else:
                     prods += [(fr, T((1, y1))), (fi, T((1, y0)))]
-            outs.append(("f%d%d" % (k, part), 1, prods))
-    return Step("MUL%d%d" % (buf, kind), outs)
+            outs.append(("%s%d%d" % (dst, k, part), 1, prods))
+    if part_of:
+        outs = outs[part_of[0]:part_of[1]]
+    return Step("MUL%d%d%s" % (buf, kind, suffix), outs, group=group)
 
 
 def build_l1():
@@ -293,13 +302,26 @@ KINDS = [build_sqr(), build_mul_line(0, 0), build_mul_line(0, 1), build_mul_line
          build_l1(), build_l2(0), build_l2(1)]
 _ch0, _ch1 = build_chord(0), build_chord(1)
 KINDS += [_ch0[0], _ch0[1], _ch1[1], _ch0[2], _ch0[3]] + build_check()
+# the three-wavefront form (calls of so few pairs that three SIMDs per pair are free): the accumulator's steps split over TWO
+# wavefronts, an output's products on eight lanes -- one product per lane (A: outputs 0 .. 7 of the square, 0 .. 5 of a sparse
+# product; B: the rest); the chain wave's kinds are the same
+# -- and since the two run side by side, every step reads one copy of f (pages 0 / 5: "f" / "g") and writes the OTHER: no wave
+# overwrites what its partner is still reading.  Kind names end in the direction: ...fg reads f, writes g.
+for _src, _dst in (("f", "g"), ("g", "f")):
+    _d = _src + _dst
+    KINDS += [build_sqr((0, 8), 8, "SQRA" + _d, _src, _dst), build_sqr((8, 12), 8, "SQRB" + _d, _src, _dst)]
+    for _b in range(2):
+        for _k in range(2):
+            KINDS += [build_mul_line(_b, _k, (0, 6), 8, "A" + _d, _src, _dst), build_mul_line(_b, _k, (6, 12), 8, "B" + _d, _src, _dst)]
 KIND = {s.name: i for i, s in enumerate(KINDS)}
 NOP = 0x3f
 LAST = 0x80                                        # flag on the last step of a phase
 # the routine a step kind runs (bits 8 - 9 of a program word): 0 two products per lane, 1 two products with one-slot second
 # operands, 2 one product per lane
 def variant_of(step):
-    return 2 if step.K == 1 else (1 if step.b_single else 0)
+    """0 two products per lane, 1 two products with one-slot second operands, 2 one product per lane, 3 one product per lane and
+    eight lanes per output"""
+    return 3 if step.group == 8 else (2 if step.K == 1 else (1 if step.b_single else 0))
 
 
 def programs():
@@ -325,6 +347,39 @@ def programs():
             steps = [k | (variant_of(KINDS[k]) << 8) for k in steps] or [NOP]
             prog += steps[:-1] + [steps[-1] | LAST]
     return acc, chain
+
+
+def programs3():
+    """(acc A, acc B, chain) programs of the three-wavefront form.  Super-phase p: the chain wave runs iteration p of the loop, the
+    two accumulator waves iteration p - 1 -- one step each per SUB-phase (a barrier after every accumulator step: each of the two needs
+    all of f), the chain's steps dealt out over the sub-phases."""
+    chord_at = [s for s, kind in LS.line_schedule() if kind == "c"]
+    iters = LS.NX.bit_length() - 1
+    progs = ([], [], [])
+    cur = "f"                                      # the copy that holds the accumulator (starts as 1 in page 0)
+    for p in range(iters + 1):
+        a, b, c = [], [], []
+        if p == 0:
+            a, b = [KIND["CK1"], KIND["CK2"]], [NOP, NOP]
+        if p >= 1:
+            s = p - 1
+            names = ["SQR%s", "MUL%d0%%s" % (s & 1)] + (["MUL%d1%%s" % (s & 1)] if s in chord_at else [])
+            for n in names:
+                nxt = "g" if cur == "f" else "f"
+                a.append(KIND[n % "A" + cur + nxt])
+                b.append(KIND[n % "B" + cur + nxt])
+                cur = nxt
+        if p < iters:
+            c += [KIND["L1"], KIND["L2%d" % (p & 1)]]
+            if p in chord_at:
+                c += [KIND["C1"], KIND["C2%d" % (p & 1)], KIND["C3"], KIND["C4"]]
+        n = len(a)
+        per = -(-len(c) // n)
+        for i in range(n):                         # sub-phase i
+            for prog, steps in ((progs[0], [a[i]]), (progs[1], [b[i]]), (progs[2], c[i * per:(i + 1) * per])):
+                steps = [k | (variant_of(KINDS[k]) << 8) if k != NOP else NOP for k in steps] or [NOP]
+                prog += steps[:-1] + [steps[-1] | LAST]
+    return progs + (cur,)
 
 
 # ---- digit-level interpreter ---------------------------------------------------------------------------------------------
@@ -373,7 +428,7 @@ class Machine:
         return tuple((from_limbs(self.rd(line_slot(buf, kind, c, 0))) * rinv % Q, from_limbs(self.rd(line_slot(buf, kind, c, 1))) * rinv % Q)
                      for c in range(3))
 
-    def step(self, kind):
+    def step(self, kind, commit=True):
         rec = self.kinds[kind].rec
         TRASH = self.names.trash
         P = []
@@ -382,15 +437,19 @@ class Machine:
             add = lambda x, y: [u + v for u, v in zip(self.rd(x), self.rd(y))]
             P.append(model_dot([(add(a1, a2), add(b1, b2)), (add(a3, a4), add(b3, b4))]))
         writes = []
+        grp = self.kinds[kind].group
         for lane in range(LANES):
-            q0 = lane & ~3
-            t = [sum(P[q0 + r][j] for r in range(4)) for j in range(L)]
+            q0 = lane & ~(grp - 1)
+            t = [sum(P[q0 + r][j] for r in range(grp)) for j in range(L)]
             v = scale_reduce_norm(t, rec[lane][9])
             if rec[lane][8] != TRASH:
                 self.max_abs = max(self.max_abs, abs(from_limbs(v)) / Q)
             writes.append((rec[lane][8], v))
+        if not commit:
+            return writes
         for a, v in writes:                        # every lane reads before any lane writes
             self.vf[a] = v
+        return writes
 
 
 def is_zero_stored(d):
@@ -398,34 +457,35 @@ def is_zero_stored(d):
     return all(x == 0 for x in d) or list(d) == QD
 
 
-def miller(P, Qa):
-    """the two programs on one pair: f (six (re, im) residues, w-power order) and the validity of the fast formulas"""
+def miller(P, Qa, waves=2, reverse_waves=False):
+    """the programs of the two- or three-wavefront form on one pair: f (six (re, im) residues, w-power order) and the validity of
+    the fast formulas"""
     m = Machine()
     px, py = P
     (xq0, xq1), (yq0, yq1) = Qa
     for name, x in (("PX3N", -3 * px), ("PY", py), ("PY3", 3 * py), ("XQ0", xq0), ("XQ1", xq1), ("YQ0", yq0), ("YQ1", yq1),
                     ("X0", xq0), ("X1", xq1), ("Y0", yq0), ("Y1", yq1), ("Z0", 1), ("Z1", 0), ("f00", 1)):
         m.store_value(name, x % Q)
-    acc, chain = programs()
-    ia = ic = 0
-    while ia < len(acc):
-        # one phase: the chain wave's steps, the accumulator wave's steps (they touch disjoint values), the barrier
-        while True:
-            k = chain[ic]
-            ic += 1
-            if k & 0x3f != NOP:
-                m.step(k & 0x3f)
-            if k & LAST:
-                break
-        while True:
-            k = acc[ia]
-            ia += 1
-            if k & 0x3f != NOP:
-                m.step(k & 0x3f)
-            if k & LAST:
-                break
-    assert ic == len(chain)
+    final = "f"
+    if waves == 2:
+        progs = programs()
+    else:
+        *progs, final = programs3()
+    order = list(range(len(progs)))
+    if reverse_waves:
+        order.reverse()                            # within a phase the waves touch disjoint values: any order gives the same digits
+    at = [0] * len(progs)
+    while at[0] < len(progs[0]):
+        for w in order:                            # one phase: every wave's steps up to its LAST flag, then the barrier
+            while True:
+                k = progs[w][at[w]]
+                at[w] += 1
+                if k & 0x3f != NOP:
+                    m.step(k & 0x3f)
+                if k & LAST:
+                    break
+    assert all(a == len(p) for a, p in zip(at, progs))
     on_twist = is_zero_stored(m.rd(N.slot("D0"))) and is_zero_stored(m.rd(N.slot("D1")))
     z_zero = is_zero_stored(m.rd(N.slot("Z0"))) and is_zero_stored(m.rd(N.slot("Z1")))
-    f = [(m.value("f%d0" % k), m.value("f%d1" % k)) for k in range(6)]
+    f = [(m.value("%s%d0" % (final, k)), m.value("%s%d1" % (final, k))) for k in range(6)]
     return f, on_twist and not z_zero, m.max_abs

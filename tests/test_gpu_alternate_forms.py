@@ -6,6 +6,8 @@ creation (csrc/blsgpu_api.hip), so each gets the reference's vectors.
                             step, which calls of up to 20 480 pairs -- every vector here -- otherwise leave to k_ml_lines4
   BLSGPU_LS_MERGE_WIDE_MAX=0  k_ml_merge (six lanes per value) for every merge level (default: k_ml_merge_wide, one wavefront per
                             output, for levels with few outputs)
+  BLSGPU_MILLER_WIDE3_MAX=0 the wide Miller loop on two wavefronts per pair for calls of every size it takes (default: three wavefronts,
+                            the accumulator split over two of them, up to 256 pairs)
   BLSGPU_MILLER_WIDE_MAX=0  small calls on the wavefront VM's k_miller (four pairs per workgroup + product tree) instead of k_miller_wide
   BLSGPU_VM_EXACT_LANES=0   degenerate blocks of the wavefront-VM kernels recomputed by k_miller_slow
                             (default: k_ml_lines_exact in block mode + k_ml_small in list mode)
@@ -29,6 +31,7 @@ FORMS = {
     "point_chains_on_lane_pairs": ({"BLSGPU_LS_QUAD_MAX": "0"}, True),                       # k_ml_lines2 at these sizes
     "merge_levels_six_lanes_per_value": ({"BLSGPU_LS_MERGE_WIDE_MAX": "0"}, True),          # k_ml_merge for every level
     "vm_slow_program_for_degenerate_blocks": ({"BLSGPU_VM_EXACT_LANES": "0"}, False),
+    "wide_miller_on_two_wavefronts": ({"BLSGPU_MILLER_WIDE3_MAX": "0"}, False),               # k_miller_wide<2> at the sizes k_miller_wide<3> takes by default
     "small_calls_on_the_wavefront_vm": ({"BLSGPU_MILLER_WIDE_MAX": "0"}, False),              # k_miller: round 4's default below 4096 pairs
     "line_stream_workspace_unavailable": ({"BLSGPU_TEST_LS_NOMEM": "1"}, True),
     "workgroups_of_64_threads": ({"BLSGPU_WG256_MAX_WAVES": "0"}, True),                    # round 3's launch shape for every size

@@ -93,6 +93,31 @@ def test_tables_give_the_reference_pairing(oracle, seeded_pairs):
     assert oracle.final_exp(_bytes(LS.to_flat12(f))) == oracle.pairing_multi(g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)], 1)
 
 
+def test_three_wavefront_form(oracle, seeded_pairs):
+    """the accumulator's steps split over two wavefronts (eight lanes per output, one product per lane; every step reads one copy
+    of f and writes the other): the same field element whichever of the waves of a phase runs first"""
+    pa, pb, pc, final = M.programs3()
+    assert sum(1 for k in pa if k & M.LAST) == sum(1 for k in pb if k & M.LAST) == sum(1 for k in pc if k & M.LAST) == 2 + 2 * 63 + 5
+    steps = lambda prog: [k & 0x3f for k in prog if k & 0x3f != M.NOP]
+    assert len(steps(pa)) == 2 + 63 + 68 and len(steps(pb)) == 63 + 68 and len(steps(pc)) == 2 * 63 + 4 * 5
+    assert all(M.KINDS[k].group == 8 for k in steps(pb)) and all(M.KINDS[k].K == 1 for k in steps(pa) + steps(pb) + steps(pc))
+    # a step never writes the copy of f it reads (its partner wave may still be reading it)
+    for k in set(steps(pb)) | set(steps(pa)[2:]):
+        name = M.KINDS[k].name
+        src, dst = name[-2], name[-1]
+        assert {src, dst} == {"f", "g"}
+        assert all(d[0] == dst for d, _, _ in M.KINDS[k].outputs)
+        assert all(t[1][0] == src for _, _, prods in M.KINDS[k].outputs for a, _ in prods for t in a)
+    g1, g2 = seeded_pairs
+    i = 3
+    P, Qa = _pairs(g1[96 * i:], g2[192 * i:], 1)[0]
+    want = oracle.pairing_multi(g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)], 1)
+    for rev in (False, True):
+        f, ok, mx = M.miller(P, Qa, waves=3, reverse_waves=rev)
+        assert ok and mx < 1.02
+        assert oracle.final_exp(_bytes(LS.to_flat12(f))) == want
+
+
 def test_degenerate_pairs_are_reported():
     """Q off the twist, or of an order that ends the chain at Z = 0: the kernel's two tests say so"""
     with open(os.path.join(GOLDEN, "pairing_degenerate.json")) as f:
