@@ -100,10 +100,11 @@ int blsgpu_ctx_set_miller_wide_max(blsgpu_ctx *ctx, size_t pairs);
  * where teams of two quantise better, three elsewhere).  Results are identical either way. */
 int blsgpu_ctx_set_mp3_threshold(blsgpu_ctx *ctx, size_t pairs);
 /* Calls of at least `pairs` pairs whose groups all have at least `min_group` pairs run the LINE-STREAM form of
- * the Miller loops (csrc/blsgpu_ml.hip: the twist-point chains one pair per lane, their 68 lines per pair through
+ * the Miller loops (csrc/blsgpu_ml.hip: the twist-point chains alone, their 68 lines per pair through
  * HBM, the accumulator products six lanes each, Horner over the line indices) -- the same loop as
- * fq_miller_loop, fields_t.py:1091-1111, cut where the data dependency allows.  Default 5120 / 64 (the measured
- * crossover; calls of up to 20 480 pairs run the point chains four lanes per pair); (size_t)-1
+ * fq_miller_loop, fields_t.py:1091-1111, cut where the data dependency allows.  Default 2304 / 64 (the measured
+ * crossover, tools/ls_wide_sweep.py; calls of up to 5120 pairs run the point chains sixteen lanes per pair with the values in
+ * LDS -- csrc/blsgpu_lsw.hip --, up to 20 480 pairs four lanes per pair, above that two); (size_t)-1
  * keeps every call on the wavefront-VM kernels.  Results are identical either way. */
 int blsgpu_ctx_set_ls_threshold(blsgpu_ctx *ctx, size_t pairs, size_t min_group);
 /* Number of accumulators the line-stream product kernel aims at (default 163840): a group's pairs are cut into equal

@@ -19,6 +19,7 @@
 #include "blsgpu_fexp.hip"
 #include "blsgpu_fexpw.hip"
 #include "blsgpu_mlw.hip"
+#include "blsgpu_lsw.hip"
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
 #include "blsgpu_h2cw.hip"
@@ -84,7 +85,7 @@ struct blsgpu_ctx {
     uint32_t* d_msm_part = nullptr;    // MSM partials
     // line-stream multi-pairing (blsgpu_ml.hip): used from ls_threshold pairs per call when every group has at least
     // ls_min_group pairs
-    size_t ls_threshold = 5120;        // measured crossover (tools/ls_crossover.py, round 4 with the point chains on lane quads): 4096 pairs 1.97 (VM) vs 2.04 ms, 6144 pairs 2.40 vs 2.14 ms; 16 384 in round 3
+    size_t ls_threshold = 2304;        // measured crossover (tools/ls_wide_sweep.py, round 5 with the point chains sixteen lanes per pair): 2048 pairs 1.70 (VM) vs 1.70 ms, 3072 pairs 1.93 vs 1.79; 5120 in round 4, 16 384 in round 3
     size_t ls_min_group = 64;
     size_t ls_teams = 163840;          // accumulators k_ml_accum aims at (10 per wavefront: 8 wavefronts per place at two per SIMD)
     void* d_lines = nullptr;           // 68 x pairs line records
@@ -95,6 +96,7 @@ struct blsgpu_ctx {
     size_t bad_cap = 0;
     bool vm_exact_lanes = true;        // degenerate blocks of the VM kernels through the lane kernels (k_ml_lines_exact / k_ml_small) instead of k_miller_slow
     size_t ls_merge_wide_max = 16384;  // merge levels with at most this many outputs run one wavefront per output
+    size_t ls_wide_max = 5120;         // calls of at most this many pairs run the point chains sixteen lanes per pair with the values in LDS (k_ml_lines_wide, blsgpu_lsw.hip); 0: never
     size_t ls_quad_max = 20480;        // calls of at most this many pairs run the point chains on lane QUADS (k_ml_lines4: 0.6 of the depth while lane pairs leave SIMDs empty)
     size_t fexp_team_threshold = 5120; // results per call from which the final exponentiations run six lanes each (blsgpu_fexp.hip); below: one result per wavefront (measured crossover, tools/fexp_latency.py)
     bool fexp_wide = true;             // fewer results than that: one result per wavefront, a product per lane (blsgpu_fexpw.hip); false: the VM program
@@ -531,6 +533,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_FEXP_WIDE_MAX_PARTIALS")) c->fexp_wide_max_partials = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_VM_EXACT_LANES")) c->vm_exact_lanes = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_LS_MERGE_WIDE_MAX")) c->ls_merge_wide_max = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_LS_WIDE_MAX")) c->ls_wide_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_LS_QUAD_MAX")) c->ls_quad_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -1037,7 +1040,10 @@ static int launch_miller_ls(blsgpu_ctx* c, const void* d_g1, const void* d_g2, c
     HIP_TRY(hipMemsetAsync(c->d_degen, 0, sizeof(uint32_t), st));
     {
         KernelTimer kt(c, st, 4);
-        if (n <= c->ls_quad_max) {                       // few pairs: four lanes each, the tangent step's levels shared by the two pairs
+        if (n <= c->ls_wide_max) {                       // a few thousand pairs: sixteen lanes each, the values in LDS, a product per lane
+            hipLaunchKernelGGL(lsw::k_ml_lines_wide, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, (const uint32_t*)d_g1,
+                               (const uint32_t*)d_g2, (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);
+        } else if (n <= c->ls_quad_max) {                // few pairs: four lanes each, the tangent step's levels shared by the two pairs
             const WaveShape ws = wave_shape(c, (4 * n + 63) / 64);
             hipLaunchKernelGGL(ml::k_ml_lines4, dim3(ws.blocks), dim3(ws.threads), 0, st, (const uint32_t*)d_g1,
                                (const uint32_t*)d_g2, (uint32_t)n, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg);

@@ -2,8 +2,9 @@
 workspace cannot be allocated (VERDICT r3 item 1 d / e): each is reachable through an environment knob read at context
 creation (csrc/blsgpu_api.hip), so each gets the reference's vectors.
 
-  BLSGPU_LS_QUAD_MAX=0      k_ml_lines2 (one pair per lane PAIR) for calls of every size: the kernel of bench.py's 524 800-pair
-                            step, which calls of up to 20 480 pairs -- every vector here -- otherwise leave to k_ml_lines4
+  BLSGPU_LS_WIDE_MAX=0      k_ml_lines4 (one pair per lane QUAD) where the default is k_ml_lines_wide (sixteen lanes per pair, up to 10 240 pairs)
+  BLSGPU_LS_QUAD_MAX=0      (with the former) k_ml_lines2 (one pair per lane PAIR) for calls of every size: the kernel of bench.py's
+                            524 800-pair step, which calls of up to 20 480 pairs -- every vector here -- otherwise leave to the other two
   BLSGPU_LS_MERGE_WIDE_MAX=0  k_ml_merge (six lanes per value) for every merge level (default: k_ml_merge_wide, one wavefront per
                             output, for levels with few outputs)
   BLSGPU_MILLER_WIDE3_MAX=0 the wide Miller loop on two wavefronts per pair for calls of every size it takes (default: three wavefronts,
@@ -28,7 +29,8 @@ from test_gpu_linestream import EDGE, _spliced, flags
 pytestmark = pytest.mark.gpu
 
 FORMS = {
-    "point_chains_on_lane_pairs": ({"BLSGPU_LS_QUAD_MAX": "0"}, True),                       # k_ml_lines2 at these sizes
+    "point_chains_on_lane_pairs": ({"BLSGPU_LS_WIDE_MAX": "0", "BLSGPU_LS_QUAD_MAX": "0"}, True),   # k_ml_lines2 at these sizes
+    "point_chains_on_lane_quads": ({"BLSGPU_LS_WIDE_MAX": "0"}, True),                          # k_ml_lines4 (round 4's default below 20 480 pairs)
     "merge_levels_six_lanes_per_value": ({"BLSGPU_LS_MERGE_WIDE_MAX": "0"}, True),          # k_ml_merge for every level
     "vm_slow_program_for_degenerate_blocks": ({"BLSGPU_VM_EXACT_LANES": "0"}, False),
     "wide_miller_on_two_wavefronts": ({"BLSGPU_MILLER_WIDE3_MAX": "0"}, False),               # k_miller_wide<2> at the sizes k_miller_wide<3> takes by default

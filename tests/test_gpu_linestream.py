@@ -22,10 +22,15 @@ def flags(v):
 # kernel of bench.py's 524 800-pair step).  Every test below that takes `ls` runs once per form: "lane_pairs" creates the
 # context with BLSGPU_LS_QUAD_MAX=0, so k_ml_lines2's own flagging path (Q flagged / off the twist / final Z = 0 behind
 # sp::tangent_step) meets the edge and degenerate vectors at these sizes too.
-@pytest.fixture(scope="module", params=["lane_quads", "lane_pairs"])
+# Round 5 added a third form for calls of up to 10 240 pairs: sixteen lanes per pair with the values in LDS (k_ml_lines_wide,
+# csrc/blsgpu_lsw.hip) -- "sixteen_lanes" below is the default selection at these sizes, "lane_quads" switches it off.
+CHAIN_FORMS = {"sixteen_lanes": {}, "lane_quads": {"BLSGPU_LS_WIDE_MAX": "0"}, "lane_pairs": {"BLSGPU_LS_WIDE_MAX": "0", "BLSGPU_LS_QUAD_MAX": "0"}}
+
+
+@pytest.fixture(scope="module", params=list(CHAIN_FORMS))
 def ls(request):
     """an engine of its own whose every multi-pairing runs the line-stream kernels"""
-    e = engine_with_env({"BLSGPU_LS_QUAD_MAX": "0"} if request.param == "lane_pairs" else {})
+    e = engine_with_env(CHAIN_FORMS[request.param])
     e.set_ls_threshold(1, 1)
     return e
 
@@ -176,11 +181,11 @@ def test_miller_product_partials_compose(ls, seeded_pairs, golden):
     assert bytes(out.cpu().numpy()).hex() == golden("pairing.json")["seeded"]["1025"]["out"]
 
 
-@pytest.mark.parametrize("chains", ["lane_quads", "lane_pairs"])
+@pytest.mark.parametrize("chains", list(CHAIN_FORMS))
 def test_small_groups_one_accumulator_per_group(golden, seeded_pairs, oracle, chains):
     """k_ml_small: batches of groups of 1, 2, 3, 7 and 27 pairs (threshold verifies, single signatures), with degenerate
     pairs spliced in, against the oracle group by group"""
-    e = engine_with_env({"BLSGPU_LS_QUAD_MAX": "0"} if chains == "lane_pairs" else {})
+    e = engine_with_env(CHAIN_FORMS[chains])
     e.set_ls_threshold(1, 1 << 30)                     # every group is "small"
     a, b, inf = _spliced(golden, seeded_pairs, count=220, every=13)
     n = len(a) // 96

@@ -73,8 +73,10 @@ class kernel_choice:
         self.engine.set_mp_threshold(self.thr[0])
         self.engine.set_mp3_threshold(self.thr[1])
         self.engine.set_miller_wide_max(self.thr[2])
+        self.engine.set_ls_threshold(None)                      # (calls of >= 2304 pairs would take the line-stream kernels)
 
     def __exit__(self, *a):
+        self.engine.set_ls_threshold(2304, 64)
         self.engine.set_mp_threshold(4096)
         self.engine.set_mp3_threshold(2 ** 64 - 1)              # back to the measured schedule
         self.engine.set_miller_wide_max(1536)

@@ -5,7 +5,7 @@ k_ml_lines2 on lane pairs, the kernel of bench.py's step; then k_ml_lines_exact 
 (k_ml_small) and the final exponentiation six lanes per result (k_fexp_team) or one per wavefront (k_fexp_wide, fused
 with the Horner kernel where the call ends in it), on random subsets of the seeded pairs with the degenerate inputs of
 tools/soak_parity.py sprinkled in (zero coordinates, off-twist points, low-order points, flags), random chunking, every
-result against the CPU oracle.  usage: python tools/soak_linestream.py [trials] [pairs|quads]  (default: both forms at random)"""
+result against the CPU oracle.  usage: python tools/soak_linestream.py [trials] [pairs|quads|wide]  (default: the three forms of the point chains at random)"""
 import json
 import os
 import random
@@ -19,9 +19,9 @@ for p in (os.path.join(ROOT, "python-bls_amd"), os.path.join(ROOT, "oracle")):
 
 def main():
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    only_chains = {"pairs": 0, "quads": None}.get(sys.argv[2], "bad") if len(sys.argv) > 2 else None
+    only_chains = {"pairs": 0, "quads": None, "wide": "wide"}.get(sys.argv[2], "bad") if len(sys.argv) > 2 else None
     if only_chains == "bad":
-        sys.exit("second argument: pairs | quads")
+        sys.exit("second argument: pairs | quads | wide")
     if len(sys.argv) > 2 and sys.argv[2] == "quads":
         only_chains = "default"
     import oracle as O
@@ -75,12 +75,16 @@ def main():
     def engine(min_group, teams, fexp, quad_max):
         key = (min_group, teams, fexp, quad_max)
         if key not in engines:
-            if quad_max is None:
-                os.environ.pop("BLSGPU_LS_QUAD_MAX", None)
-            else:
-                os.environ["BLSGPU_LS_QUAD_MAX"] = str(quad_max)       # read at context creation (csrc/blsgpu_api.hip)
+            # (read at context creation, csrc/blsgpu_api.hip) quad_max 0: lane pairs; None: lane quads; "wide": sixteen lanes per pair
+            os.environ.pop("BLSGPU_LS_QUAD_MAX", None)
+            os.environ.pop("BLSGPU_LS_WIDE_MAX", None)
+            if quad_max != "wide":
+                os.environ["BLSGPU_LS_WIDE_MAX"] = "0"
+                if quad_max is not None:
+                    os.environ["BLSGPU_LS_QUAD_MAX"] = str(quad_max)
             e = _native.Engine(0)
             os.environ.pop("BLSGPU_LS_QUAD_MAX", None)
+            os.environ.pop("BLSGPU_LS_WIDE_MAX", None)
             e.set_ls_threshold(1, min_group)
             e.set_ls_teams(teams)
             e.set_fexp_team_threshold(fexp)
@@ -91,8 +95,8 @@ def main():
     for t in range(trials):
         rate = rng.choice([0.0, 0.05, 0.3, 1.0])
         fexp = rng.choice([1, None])
-        quad_max = rng.choice([0, None]) if only_chains is None else (None if only_chains == "default" else only_chains)
-        form = "lane pairs" if quad_max == 0 else "lane quads"
+        quad_max = rng.choice([0, None, "wide"]) if only_chains is None else (None if only_chains == "default" else only_chains)
+        form = "lane pairs" if quad_max == 0 else ("sixteen lanes" if quad_max == "wide" else "lane quads")
         if t % 2 == 0:                                  # one multi-pairing through the per-line products
             n = rng.choice([1, 2, 5, 16, 17, 63, 64, 65, 200, 257, 600, 1025])
             a, b, f = pick(n, rate)

@@ -21,6 +21,9 @@ def main():
     from bls_py import _native
     O.build()
     eng = _native.Engine(0)
+    os.environ["BLSGPU_MILLER_WIDE3_MAX"] = "0"        # (read at context creation) the wide Miller loop on two wavefronts at every size
+    eng2 = _native.Engine(0)
+    del os.environ["BLSGPU_MILLER_WIDE3_MAX"]
     gold = os.path.join(ROOT, "tests", "golden")
     g1 = open(os.path.join(gold, "pairs_seed1_g1.bin"), "rb").read()
     g2 = open(os.path.join(gold, "pairs_seed1_g2.bin"), "rb").read()
@@ -69,11 +72,14 @@ def main():
 
     for t in range(trials):
         mode = t % 3
-        if mode == 0:                                   # one multi-pairing, one-pair kernel
-            n = rng.choice([1, 2, 3, 5, 63, 64, 65, 127, 200, 257])
+        if mode == 0:                                   # one multi-pairing, one pair per wavefront / workgroup: k_miller (VM), k_miller_wide<3>, <2>
+            n = rng.choice([1, 2, 3, 5, 63, 64, 65, 127, 200, 257, 600])
             a, b, f = pick(n, t % 2 == 1)
-            eng.set_mp_threshold(1 << 40)
-            got = eng.pairing_multi(a, b, n, f)
+            e = rng.choice([eng, eng2])
+            e.set_mp_threshold(1 << 40)
+            e.set_miller_wide_max(rng.choice([0, 1 << 30, 1 << 30]))
+            got = e.pairing_multi(a, b, n, f)
+            e.set_miller_wide_max(1536)
             want = O.pairing_multi(a, b, n, threads=16, inf=f)
             ok = got == want
         elif mode == 1:                                 # one multi-pairing, three-pair kernel
@@ -87,9 +93,12 @@ def main():
         else:                                           # batch of equal-sized groups
             gsz, groups = rng.choice([(1, 40), (2, 33), (5, 17), (23, 9), (24, 9), (25, 8), (67, 5), (130, 3)])
             a, b, f = pick(gsz * groups, t % 2 == 0)
-            eng.set_mp_threshold(rng.choice([0, 4096, 1 << 40]))
-            eng.set_mp3_threshold(rng.choice([0, 2 ** 64 - 1, 1 << 40]))
-            got = eng.pairing_multi_batch(a, b, gsz, groups, f)
+            e = rng.choice([eng, eng2])
+            e.set_mp_threshold(rng.choice([0, 4096, 1 << 40]))
+            e.set_mp3_threshold(rng.choice([0, 2 ** 64 - 1, 1 << 40]))
+            e.set_miller_wide_max(rng.choice([0, 1536]))
+            got = e.pairing_multi_batch(a, b, gsz, groups, f)
+            e.set_miller_wide_max(1536)
             want = b"".join(O.pairing_multi(a[96 * gsz * g:96 * gsz * (g + 1)], b[192 * gsz * g:192 * gsz * (g + 1)], gsz, threads=16,
                                             inf=f[2 * gsz * g:2 * gsz * (g + 1)])
                             for g in range(groups))
