@@ -65,6 +65,7 @@ struct blsgpu_ctx {
     size_t mp3_threshold = (size_t)-1; // ... with three pairs per wavefront from here on, two below; -1: the measured schedule
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
+    size_t pow2_max = 32768;           // fixed-exponent powers (hash to G2, decompression): up to this many values per launch two wavefronts per 64 values (k_pow2: 0.32 ms against 0.47); 0: never
     size_t h2c_wide_max = 2048;        // up to this many messages the cofactor clearing runs one message per WAVEFRONT with a product per lane (blsgpu_h2cw.hip: the latency form); 0: never
     size_t h2c_reg_threshold = 8192;   // messages from which cofactor clearing runs in registers (one message per lane PAIR; measured: DESIGN.md 2c)
     size_t h2c_lane_threshold = 2048;  // messages from which the three encoding stages run one encoding per lane (k_h2c_sw0/1/2)
@@ -222,8 +223,12 @@ struct StreamGuard {
 static int launch_pow(blsgpu_ctx* c, uint32_t* img, uint32_t img_slots, uint32_t base_off, uint32_t acc_off, size_t teams, uint32_t cnt,
                       hipStream_t st) {
     size_t total = teams * cnt;
-    hipLaunchKernelGGL(blsgpu::k_pow, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, img_slots, base_off, acc_off, cnt,
-                       (uint32_t)total);
+    if (total <= c->pow2_max)          // a batch that leaves SIMDs empty: two wavefronts per 64 values (the squarings a chain of their own)
+        hipLaunchKernelGGL(blsgpu::k_pow2, dim3((unsigned)((total + 127) / 128)), dim3(256), 0, st, img, img_slots, base_off, acc_off, cnt,
+                           (uint32_t)total);
+    else
+        hipLaunchKernelGGL(blsgpu::k_pow, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, img_slots, base_off, acc_off, cnt,
+                           (uint32_t)total);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -537,6 +542,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_LS_QUAD_MAX")) c->ls_quad_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_POW2_MAX")) c->pow2_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_WIDE_MAX")) c->h2c_wide_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_QUAD_MAX")) c->h2c_quad_max = (size_t)strtoull(e, nullptr, 10);

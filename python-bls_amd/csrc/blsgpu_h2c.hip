@@ -143,6 +143,76 @@ __global__ void __launch_bounds__(256) k_pow(uint32_t* __restrict__ img, uint32_
 ;
 #endif
 
+// The same powers for a batch that leaves SIMDs empty (round 5): TWO wavefronts per 64 values.  k_pow is one lane's chain of 379
+// squarings + ~110 products (0.47 ms whether for 32 768 values or for one: hashing ONE message pays it twice).  Right to left in
+// base 4 the squarings are a chain of their own -- p_j = b^(4^j), two squarings per digit -- and the products  B_d <- B_d p_j  (d = the
+// exponent's digit j) only READ it: wave 0 squares and posts p_j in LDS, wave 1 multiplies the posted powers into three buckets one
+// digit behind (the digits are the same for every lane: a uniform branch picks the bucket) and ends with b^e = B_1 B_2^2 B_3^3 in
+// four products.  The chain is 378 squarings (105 + 196 multiply-adds each) and nothing else: 0.32 ms.
+// (256-thread workgroups, two sets of 64 values each: four wavefronts, one per SIMD of a CU -- 128-thread workgroups get stacked on
+// two SIMDs of a CU, profiles/r04_workgroup_shape.txt)
+__global__ void __launch_bounds__(256) k_pow2(uint32_t* __restrict__ img, uint32_t img_slots, uint32_t base_off, uint32_t acc_off,
+                                              uint32_t cnt, uint32_t total)
+#if BLSGPU_EMIT(BLSGPU_TU_H2C)
+{
+    __shared__ int32_t posts[2][2][r28::NL][64];                 // per set: p_j of its 64 values, two buffers
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t set = wv >> 1, wave = wv & 1u;
+    int32_t (*post)[r28::NL][64] = posts[set];
+    const uint32_t vr = (blockIdx.x * 2u + set) * 64u + lane;
+    const uint32_t v = vr < total ? vr : total - 1u;               // (spare lanes repeat the last value and write nothing)
+    const uint32_t team = v / cnt, k = v % cnt;
+    const uint32_t* src = img + ((size_t)team * img_slots + base_off + k) * 12;
+    uint32_t* dst = img + ((size_t)team * img_slots + acc_off + k) * 12;
+    constexpr uint32_t DIGITS = (BLSVM_POW_E_BITS + 1) / 2;
+    auto digit = [&](uint32_t j) { return (BLSVM_POW_E[(2u * j) >> 5] >> ((2u * j) & 31u)) & 3u; };      // (bit 2 j never straddles a word)
+    r28::fe p;
+    if (wave == 0u) {
+        uint32_t x[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) x[j] = src[j];
+        p = r28::from_vm(x);
+    }
+    r28::fe B1 = r28::fe_one(), B2 = r28::fe_one(), B3 = r28::fe_one();
+#pragma unroll 1
+    for (uint32_t j = 0; j < DIGITS; j++) {
+        if (wave == 0u) {
+#pragma unroll
+            for (int l = 0; l < r28::NL; l++) post[j & 1u][l][lane] = p.v[l];
+        }
+        __syncthreads();
+        if (wave == 0u) {
+            if (j + 1u < DIGITS) p = r28::sqr(r28::sqr(p));
+        } else {
+            const uint32_t d = digit(j);
+            if (d != 0u) {
+                r28::fe q;
+#pragma unroll
+                for (int l = 0; l < r28::NL; l++) q.v[l] = post[j & 1u][l][lane];
+                if (d == 1u) B1 = r28::mul(B1, q);
+                else if (d == 2u) B2 = r28::mul(B2, q);
+                else B3 = r28::mul(B3, q);
+            }
+        }
+    }
+    if (wave == 1u) {
+        r28::fe run = r28::mul(B3, B2);
+        r28::fe acc = r28::mul(B3, run);
+        run = r28::mul(run, B1);
+        acc = r28::mul(acc, run);
+        if (vr < total) {
+            uint32_t y[12];
+            r28::to_vm(y, acc);
+#pragma unroll
+            for (int j = 0; j < 12; j++) dst[j] = y[j];
+        }
+    }
+}
+#else
+;
+#endif
+
 __device__ __forceinline__ void img_load(uint32_t* team, const uint32_t* __restrict__ img, uint32_t state0, uint32_t nslots, uint32_t lane) {
     for (uint32_t d = lane; d < nslots * 12; d += 64) team[state0 * 12 + d] = img[d];
 }
