@@ -23,6 +23,7 @@
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
 #include "blsgpu_h2cw.hip"
+#include "blsgpu_probe.hip"
 
 #if BLSGPU_EMIT(BLSGPU_TU_HOST)
 namespace {

@@ -57,15 +57,6 @@ __device__ __forceinline__ fe load_coord(const uint32_t* __restrict__ src) {    
     for (int w = 0; w < 12; w++) c[11 - w] = bswap32(src[w]);
     return r28::from_raw(c);
 }
-__device__ __forceinline__ void store_line(int32_t* __restrict__ rec, const int32_t* l0a, const int32_t* l0b, const fe& l2a, const fe& l2b,
-                                           const fe& l3a, const fe& l3b) {
-#pragma unroll
-    for (int j = 0; j < NL; j++) {
-        rec[j] = l0a[j]; rec[NL + j] = l0b[j];
-        rec[2 * NL + j] = l2a.v[j]; rec[3 * NL + j] = l2b.v[j];
-        rec[4 * NL + j] = l3a.v[j]; rec[5 * NL + j] = l3b.v[j];
-    }
-}
 
 // ---- stage A on LANE PAIRS: an Fq2 value split over two adjacent lanes ---------------------------------------------
 // The even lane holds the real part, the odd lane the imaginary part; the partner's part is one DPP move per limb away
@@ -724,6 +715,8 @@ __device__ __forceinline__ void set_one(int32_t* __restrict__ fre, int32_t* __re
 // of P3, and a carry pass on each part of the result (differences of reduced values).  Measured on the bench's step
 // (profiles/r05_accum_variants_ab.txt): k_ml_accum 22.3 -> 20.2 ms per 524 800 pairs -- the ratio of the two instruction
 // streams (3805 -> 3450), which DESIGN.md had argued away on a register estimate for two rounds.
+// the line record of the constant 1 (coefficient 0 = R mod q, every other part zero)
+static __device__ const int32_t __attribute__((aligned(16))) ML_LINE_ONE[LINE_DW] = BLS28_ONE;
 struct Pub2 { int32_t re[NL], im[NL], xre[NL], xim[NL]; };
 struct Xop2 { int32_t re[NL], im[NL]; };
 __device__ __forceinline__ void fetch2_rt(Xop2& X, const Pub2& P, const Team& t, uint32_t J) {
@@ -794,7 +787,8 @@ __global__ void __launch_bounds__(256, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const i
         const uint32_t ii = use ? i : 0u;
         uint32_t jA, jB;
         line_positions(L, bad[first + ii], jA, jB);
-        const int4* rec = reinterpret_cast<const int4*>(base + (size_t)ii * LINE_DW);
+        // a team past its last pair multiplies by the line "1" (same residues, no 28 selects on the way out)
+        const int4* rec = reinterpret_cast<const int4*>(use ? base + (size_t)ii * LINE_DW : ML_LINE_ONE);
         int32_t y[6][NL];
         {
             int4 q[LINE_DW / 4];
@@ -807,12 +801,7 @@ __global__ void __launch_bounds__(256, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const i
                 y[(e + 2) / NL][(e + 2) % NL] = q[k].z; y[(e + 3) / NL][(e + 3) % NL] = q[k].w;
             }
         }
-        int32_t re[NL], im[NL];
-#pragma unroll
-        for (int k = 0; k < NL; k++) { re[k] = fre[k]; im[k] = fim[k]; }
-        mul_line_k3(re, im, t, jA, jB, y);
-#pragma unroll
-        for (int k = 0; k < NL; k++) { fre[k] = use ? re[k] : fre[k]; fim[k] = use ? im[k] : fim[k]; }
+        mul_line_k3(fre, fim, t, jA, jB, y);
     }
     if (valid) {
         int32_t* o = out + (size_t)id * DENSE_DW + t.c * 2 * NL;

@@ -428,7 +428,7 @@ class Machine:
         return tuple((from_limbs(self.rd(line_slot(buf, kind, c, 0))) * rinv % Q, from_limbs(self.rd(line_slot(buf, kind, c, 1))) * rinv % Q)
                      for c in range(3))
 
-    def step(self, kind, commit=True):
+    def step(self, kind):
         rec = self.kinds[kind].rec
         TRASH = self.names.trash
         P = []
@@ -445,8 +445,6 @@ class Machine:
             if rec[lane][8] != TRASH:
                 self.max_abs = max(self.max_abs, abs(from_limbs(v)) / Q)
             writes.append((rec[lane][8], v))
-        if not commit:
-            return writes
         for a, v in writes:                        # every lane reads before any lane writes
             self.vf[a] = v
         return writes
