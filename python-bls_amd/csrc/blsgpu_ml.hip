@@ -770,6 +770,9 @@ __global__ void __launch_bounds__(256, BLSGPU_ML_ACCUM_WAVES) k_ml_accum(const i
                                                                             int32_t* __restrict__ out)
 #if BLSGPU_EMIT(BLSGPU_TU_ML)
 {
+#if BLSGPU_ML_ACCUM_WAVES == 1
+    asm volatile("" ::: "a63");           // measurement build: an allocation past 256 registers (229 + 64 accumulation registers) holds the SIMD at one wavefront
+#endif
     const Team t = team_of_lane();
     const uint32_t id = wave_index() * TEAMS + t.slot;
     const bool valid = t.slot < (uint32_t)TEAMS && id < nteams;
