@@ -20,6 +20,7 @@
 #include "blsgpu_fexpw.hip"
 #include "blsgpu_mlw.hip"
 #include "blsgpu_lsw.hip"
+#include "blsgpu_g1w.hip"
 #include "blsgpu_msm.hip"
 #include "blsgpu_h2c.hip"
 #include "blsgpu_h2cw.hip"
@@ -67,6 +68,7 @@ struct blsgpu_ctx {
     size_t pip_threshold = 4096;       // points from which a single sum uses the bucket method
     size_t pip_group_threshold = 48;   // points per sum from which a batch of sums does
     size_t pow2_max = 32768;           // fixed-exponent powers (hash to G2, decompression): up to this many values per launch two wavefronts per 64 values (k_pow2: 0.32 ms against 0.47); 0: never
+    bool msm_wide_tail = true;         // the sorted-bucket G1 sum: window sums and the Horner over the windows on the wide machine (k_msm_horner_wide: 0.9 ms against the wavefront VM's 1.45); false: k_srt_windows + k_msm_pip_horner<1>
     size_t h2c_wide_max = 2048;        // up to this many messages the cofactor clearing runs one message per WAVEFRONT with a product per lane (blsgpu_h2cw.hip: the latency form); 0: never
     size_t h2c_reg_threshold = 8192;   // messages from which cofactor clearing runs in registers (one message per lane PAIR; measured: DESIGN.md 2c)
     size_t h2c_lane_threshold = 2048;  // messages from which the three encoding stages run one encoding per lane (k_h2c_sw0/1/2)
@@ -310,7 +312,7 @@ static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars
     const size_t PJ = blsgpu::SRT_PJ;
     const size_t o_prep = take(n * blsgpu::L28_AFF), o_cnt = take(nkeys), o_start = take(nkeys + 1), o_cur = take(nkeys), o_max = take(4),
                  o_idx = take((size_t)nwin * n), o_bsum = take(nkeys * PJ), o_hp = take(lanes * PJ), o_hk = take(lanes),
-                 o_b0 = take(nsum * nch * PJ), o_b1 = take(nsum * ((nch + 7) / 8) * PJ), o_win = take((size_t)nwin * 36), o_live = take((n + 3) / 4),
+                 o_b0 = take(nsum * nch * PJ), o_b1 = take(nsum * ((nch + 7) / 8) * PJ), o_win = take((size_t)nwin * PJ), o_live = take((n + 3) / 4),
                  o_wtot = take(2 * (size_t)nwin), o_long = take(nkeys + 4);
     if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, off)) return rc_;
     uint32_t* W = c->d_buckets;
@@ -343,15 +345,26 @@ static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars
     uint32_t *src = W + o_b0, *dst = W + o_b1;
     for (size_t cur = nch; cur > 1;) {                        // runs of 8 partial sums per lane until one is left per (window, bit)
         const size_t nfold = (cur + 7) / 8, ftotal = nsum * nfold;
-        hipLaunchKernelGGL(blsgpu::k_msm_lane_fold<1>, dim3((unsigned)((ftotal + 63) / 64)), dim3(64), 0, st, src, (uint32_t)cur, 8u,
-                           (uint32_t)nfold, (uint32_t)ftotal, dst, nfold == 1 ? 1u : 0u);   // the last fold: the VM's form
+        if (c->msm_wide_tail && ftotal <= 4096 && (cur <= 8 || cur % 8 == 0))
+            // few runs left: one wavefront per run, an addition two steps of the wide machine (a lane's own addition is ~6000 instructions)
+            hipLaunchKernelGGL(blsgpu::g1w::k_msm_horner_wide<0>, dim3((unsigned)ftotal), dim3(64), 0, st, src, (uint32_t)(cur < 8 ? cur : 8), 0u, dst,
+                               (uint8_t*)nullptr);
+        else
+            hipLaunchKernelGGL(blsgpu::k_msm_lane_fold<1>, dim3((unsigned)((ftotal + 63) / 64)), dim3(64), 0, st, src, (uint32_t)cur, 8u,
+                               (uint32_t)nfold, (uint32_t)ftotal, dst, nfold == 1 && !c->msm_wide_tail ? 1u : 0u);   // the last fold: the VM's form for the VM's tail
         HIP_TRY(hipGetLastError());
         uint32_t* t = src; src = dst; dst = t;
         cur = nfold;
     }
-    hipLaunchKernelGGL(blsgpu::k_srt_windows, dim3(nwin), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, src, cb, W + o_win);
-    hipLaunchKernelGGL(blsgpu::k_msm_pip_horner<1>, dim3(1), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, W + o_win, nwin, cb,
-                       (uint32_t*)d_out, (uint8_t*)d_out_inf);
+    if (c->msm_wide_tail) {
+        // W_w = sum_b 2^b S_(w,b), one wavefront per window; then sum_w 2^(cb w) W_w on one wavefront (blsgpu_g1w.hip)
+        hipLaunchKernelGGL(blsgpu::g1w::k_msm_horner_wide<0>, dim3(nwin), dim3(64), 0, st, src, cb, 1u, W + o_win, (uint8_t*)nullptr);
+        hipLaunchKernelGGL(blsgpu::g1w::k_msm_horner_wide<1>, dim3(1), dim3(64), 0, st, W + o_win, nwin, cb, (uint32_t*)d_out, (uint8_t*)d_out_inf);
+    } else {
+        hipLaunchKernelGGL(blsgpu::k_srt_windows, dim3(nwin), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, src, cb, W + o_win);
+        hipLaunchKernelGGL(blsgpu::k_msm_pip_horner<1>, dim3(1), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, W + o_win, nwin, cb,
+                           (uint32_t*)d_out, (uint8_t*)d_out_inf);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -544,6 +557,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_PIP_THRESHOLD")) c->pip_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_PIP_GROUP_THRESHOLD")) c->pip_group_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_POW2_MAX")) c->pow2_max = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_MSM_WIDE_TAIL")) c->msm_wide_tail = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_H2C_WIDE_MAX")) c->h2c_wide_max = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_REG_THRESHOLD")) c->h2c_reg_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_QUAD_MAX")) c->h2c_quad_max = (size_t)strtoull(e, nullptr, 10);

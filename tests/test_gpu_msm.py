@@ -366,9 +366,13 @@ def test_batch_horner_on_lane_quads_workgroup_shapes(lane_engine, seeded_pairs):
         assert e64.g2_msm(pts, sc, k, groups) == lane_engine.g2_msm(pts, sc, k, groups)
 
 
-@pytest.fixture(scope="module")
-def sorted_engine():
-    """An engine whose single G1 sums with scalars use the sorted buckets (k_srt_*) from 1 point on."""
+@pytest.fixture(scope="module", params=["tail_on_the_wide_machine", "tail_on_the_wavefront_vm"])
+def sorted_engine(request):
+    """An engine whose single G1 sums with scalars use the sorted buckets (k_srt_*) from 1 point on -- once with the default tail
+    (window sums and the Horner over the windows on k_msm_horner_wide) and once with the wavefront VM's (k_srt_windows +
+    k_msm_pip_horner<1>, BLSGPU_MSM_WIDE_TAIL=0)."""
+    if request.param == "tail_on_the_wavefront_vm":
+        return _engine_with_values({"BLSGPU_MSM_SORT_THRESHOLD": "1", "BLSGPU_MSM_WIDE_TAIL": "0"})
     return _engine_with(("BLSGPU_MSM_SORT_THRESHOLD",))
 
 
