@@ -41,6 +41,7 @@ def main():
         "default": engine_with({}),
         "sorted": engine_with({"BLSGPU_MSM_SORT_THRESHOLD": "1"}),
         "sorted8": engine_with({"BLSGPU_MSM_SORT_THRESHOLD": "1", "BLSGPU_MSM_SORT_BITS": "8"}),
+        "sorted_vm_tail": engine_with({"BLSGPU_MSM_SORT_THRESHOLD": "1", "BLSGPU_MSM_WIDE_TAIL": "0"}),    # (round 5: the default tail is k_msm_horner_wide)
         "lane": engine_with({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_LANE_THRESHOLD": "1",
                              "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40)}),
         "lds": engine_with({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40),
