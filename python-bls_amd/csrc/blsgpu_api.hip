@@ -78,7 +78,7 @@ struct blsgpu_ctx {
     bool test_ls_nomem = false;        // test hook (BLSGPU_TEST_LS_NOMEM=1): the line-stream workspace "cannot be allocated"
     void* d_h2c_ws = nullptr;          // the lane-private point slots of k_h2c_clear_pairs
     size_t h2c_ws_cap = 0;
-    size_t msm_sort_threshold = 16384;  // points from which one G1 sum with scalars uses sorted buckets (k_srt_*)
+    size_t msm_sort_threshold = 1;      // points from which one G1 sum with scalars uses sorted buckets (k_srt_*): since the tail runs on the wide machine (round 5) they win at every size -- 1 point 1.24 ms against 1.63, 8192 points 1.45 against 2.59 (profiles/r05_c5_window_bits.txt)
     size_t horner_np_threshold = 1024; // G2 sums per call from which the window Horner runs several sums per team
     size_t horner_quads_threshold = 2; // G2 sums per call (lane-pair bucket kernel) from which the window Horner runs one sum per lane quad
     size_t wg256_max_waves = 4096;     // register kernels: launches of up to this many wavefronts go out as 256-thread workgroups (blsgpu_tu.h)
@@ -294,38 +294,46 @@ constexpr int MSM_WAVES = 4;
 // _dev path (no synchronisation, usable under stream capture).  Returns 1 only when the key list would not fit 32 bits;
 // the caller then takes the fixed-window path.
 static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* d_out_inf, hipStream_t st) {
-    // Window bits: with 131 072 equal pieces a run covers 131072 / (2^cb windows) pieces whatever n is -- 0.8 for
-    // 13 bits, 1.5 for 12, 5 for 10 -- and a run of more than three pieces costs a whole wavefront in
-    // k_srt_fix_long, so only 12 and 13 bits (or very few keys: <= 7 bits) are cheap.  Measured (tools/c5_probe.py,
-    // profiles/r02_schedule_experiments.txt): 12 bits up to 2^18 points, 13 from there.
-    uint32_t cb = n >= 262144 ? 13 : 12;
+    // Window bits: with 131 072 equal pieces a run covers 131072 / (keys per window x windows) pieces whatever n is, and a run of
+    // more than three pieces costs a whole wavefront in k_srt_fix_long.  With signed digits (2^(cb-1) keys per window) 13 bits are
+    // the best width at every size the sorted path serves (tools/c5_probe.py under BLSGPU_MSM_SORT_BITS, profiles/r05_c5_window_bits.txt:
+    // 2^20 points 5.71 / 5.42 / 5.46 ms for 12 / 13 / 14 bits, 16 384 points 1.88 / 1.52 / 1.68).
+    uint32_t cb = 13;
     if (const char* e = getenv("BLSGPU_MSM_SORT_BITS")) cb = (uint32_t)strtoul(e, nullptr, 10);
     if (cb < 5 || cb > blsgpu::SRT_MAXBITS) return fail(-EINVAL, "BLSGPU_MSM_SORT_BITS out of range");
-    const uint32_t nwin = (256 + cb - 1) / cb;
-    const size_t nkeys = (size_t)nwin << cb;
-    if ((size_t)nwin * n > 0xFFFFFFF0ull) return 1;
-    const size_t nch = ((size_t)1 << (cb - 1)) / blsgpu::SRT_BITADDS, nsum = (size_t)nwin * cb;
+    // signed digits (blsgpu_msm.hip): 2^(cb-1) keys per window; 258 <= cb x windows keeps the recoded scalar inside the windows
+    const uint32_t kb = cb - 1, nwin = (258 + cb - 1) / cb;
+    const size_t nkeys = (size_t)nwin << kb;
+    if ((size_t)nwin * n > 0xFFFFFFF0ull || n >= 0x80000000ull) return 1;
+    const size_t nch = ((size_t)1 << (cb - 2)) / blsgpu::SRT_BITADDS, nsum = (size_t)nwin * cb;
     const size_t lanes = blsgpu::SRT_LANES;
-    // workspace: prep | cnt | start (+1) | cursor | maxcnt, total | idx | bsum | headpart | headkey | bit sums (two buffers) | winsums
+    // workspace: prep | recoded scalars | cnt | start (+1) | cursor | maxcnt, total | idx | bsum | headpart | headkey | bit sums (two buffers) | winsums
     size_t off = 0;
     auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
     const size_t PJ = blsgpu::SRT_PJ;
-    const size_t o_prep = take(n * blsgpu::L28_AFF), o_cnt = take(nkeys), o_start = take(nkeys + 1), o_cur = take(nkeys), o_max = take(4),
-                 o_idx = take((size_t)nwin * n), o_bsum = take(nkeys * PJ), o_hp = take(lanes * PJ), o_hk = take(lanes),
-                 o_b0 = take(nsum * nch * PJ), o_b1 = take(nsum * ((nch + 7) / 8) * PJ), o_win = take((size_t)nwin * PJ), o_live = take((n + 3) / 4),
+    const size_t o_prep = take(n * blsgpu::SRT_AFF), o_rec = take(n * blsgpu::SRT_SCW), o_cnt = take(nkeys), o_start = take(nkeys + 1), o_cur = take(nkeys),
+                 o_max = take(4), o_idx = take((size_t)nwin * n), o_bsum = take(nkeys * PJ), o_hp = take(lanes * PJ), o_hk = take(lanes),
+                 o_b0 = take(nsum * nch * PJ), o_b1 = take(nsum * ((nch + 7) / 8) * PJ + PJ), o_win = take((size_t)nwin * PJ), o_live = take((n + 3) / 4),
                  o_wtot = take(2 * (size_t)nwin), o_long = take(nkeys + 4);
     if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, off)) return rc_;
     uint32_t* W = c->d_buckets;
-    const uint32_t* sc = (const uint32_t*)d_scalars;
     HIP_TRY(hipMemsetAsync(W + o_cnt, 0, nkeys * 4, st));
     HIP_TRY(hipMemsetAsync(W + o_long, 0, 16, st));          // counter of the long runs (the key list follows it)
     uint8_t* live = (uint8_t*)(W + o_live);
-    hipLaunchKernelGGL(blsgpu::k_lane_prep<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (uint32_t)n, W + o_prep, live);
+    blsgpu::SrtBias bias;
+    for (uint32_t j = 0; j < blsgpu::SRT_SCW; j++) bias.w[j] = 0;
+    for (uint32_t w = 0; w < nwin; w++) {
+        const uint32_t pos = cb * w + cb - 1;
+        bias.w[pos >> 5] |= 1u << (pos & 31);
+    }
+    hipLaunchKernelGGL(blsgpu::k_srt_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t)n, bias,
+                       W + o_prep, live, W + o_rec);
     HIP_TRY(hipGetLastError());
+    const uint32_t* sc = W + o_rec;
     const dim3 sgrid((unsigned)((n + blsgpu::SRT_SLICE - 1) / blsgpu::SRT_SLICE), nwin);
     hipLaunchKernelGGL(blsgpu::k_srt_count, sgrid, dim3(1024), 0, st, sc, live, (uint32_t)n, cb, W + o_cnt);
-    hipLaunchKernelGGL(blsgpu::k_srt_scan_window, dim3(nwin), dim3(1024), 0, st, W + o_cnt, cb, W + o_start, W + o_wtot, W + o_wtot + nwin);
-    hipLaunchKernelGGL(blsgpu::k_srt_scan_add, dim3(nwin), dim3(1024), 0, st, nwin, cb, W + o_wtot, W + o_wtot + nwin, W + o_start, W + o_cur,
+    hipLaunchKernelGGL(blsgpu::k_srt_scan_window, dim3(nwin), dim3(1024), 0, st, W + o_cnt, kb, W + o_start, W + o_wtot, W + o_wtot + nwin);
+    hipLaunchKernelGGL(blsgpu::k_srt_scan_add, dim3(nwin), dim3(1024), 0, st, nwin, kb, W + o_wtot, W + o_wtot + nwin, W + o_start, W + o_cur,
                        W + o_max);
     HIP_TRY(hipGetLastError());
     // No read-back, no host decision (round 3): whatever the digit distribution, a long run is finished by a wavefront of
@@ -343,6 +351,10 @@ static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars
     hipLaunchKernelGGL(blsgpu::k_srt_bits, dim3((unsigned)((btotal + 63) / 64)), dim3(64), 0, st, W + o_bsum, nwin, cb, (uint32_t)btotal, W + o_b0);
     HIP_TRY(hipGetLastError());
     uint32_t *src = W + o_b0, *dst = W + o_b1;
+    if (nch == 1 && !c->msm_wide_tail) {                      // (5-bit windows: nothing to fold, but the VM's tail reads its own form)
+        hipLaunchKernelGGL(blsgpu::k_msm_lane_fold<1>, dim3((unsigned)((nsum + 63) / 64)), dim3(64), 0, st, src, 1u, 1u, 1u, (uint32_t)nsum, dst, 1u);
+        src = dst;
+    }
     for (size_t cur = nch; cur > 1;) {                        // runs of 8 partial sums per lane until one is left per (window, bit)
         const size_t nfold = (cur + 7) / 8, ftotal = nsum * nfold;
         if (c->msm_wide_tail && ftotal <= 4096 && (cur <= 8 || cur % 8 == 0))

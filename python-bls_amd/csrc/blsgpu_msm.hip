@@ -993,8 +993,8 @@ __global__ void __launch_bounds__(64) k_msm_lane_fold(const uint32_t* __restrict
 
 // ---------------------------------------------------------------------------
 // Sorted buckets: ONE large G1 sum with scalars (BLS.aggregate_pub_keys(secure) at scale, bls.py:203-223 --
-// BASELINE config 5).  Windows of `cb` bits (13 for 2^20 points: 20 windows instead of 64); key = window * 2^cb +
-// digit.  A counting sort (k_srt_count, k_srt_scan_*, k_srt_scatter) lists the point indices by key; the list is cut
+// BASELINE config 5).  Windows of `cb` bits (20 windows instead of 64), SIGNED digits (below); key = window * 2^(cb-1) +
+// |digit| - 1.  A counting sort (k_srt_count, k_srt_scan_*, k_srt_scatter) lists the point indices by key; the list is cut
 // into EQUAL pieces, one per lane (k_srt_accum): a lane keeps its running bucket sum in registers and adds affine
 // points to it (complete mixed addition, two wavefronts per SIMD), writing a sum out whenever the key changes.  A
 // bucket whose run begins in the lane is written by that lane alone; the piece of a run that continues from the lane
@@ -1003,30 +1003,76 @@ __global__ void __launch_bounds__(64) k_msm_lane_fold(const uint32_t* __restrict
 // chain over 8191 buckets), W_w = sum_b 2^b S_b (k_srt_windows) -- then Horner over the windows.
 // Same value as the reference's double-and-add summed over the points (fields_t.py:705-740); parity is on the
 // affine result.  Points at infinity ((0,0)) and zero digits are left out of the list.  Points and sums are in the
-// L28 form of fp28.h (k_lane_prep<1>); the last fold hands the VM its own form.
+// L28 form of fp28.h (k_srt_prep); the tail is blsgpu_g1w.hip's (or, BLSGPU_MSM_WIDE_TAIL=0, the VM's: the last fold hands it its own form).
 constexpr uint32_t SRT_LANES = 2048u * 64u;                   // two wavefronts per SIMD
 
-// digit of window w straight from the big-endian scalar (one or two of its eight words)
-__device__ __forceinline__ uint32_t srt_digit_at(const uint32_t* __restrict__ sc, uint32_t w, uint32_t cb) {
+// SIGNED digits (round 5): s = sum_w d_w 2^(cb w) with d_w in [-2^(cb-1), 2^(cb-1)) -- the digits of s + C, C = sum_w 2^(cb-1) 2^(cb w),
+// are d_w + 2^(cb-1) in [0, 2^cb) -- so a window has 2^(cb-1) buckets |d| = 1 .. 2^(cb-1) (key index |d| - 1) that take +-P (the list
+// entry carries the sign, the prepared point its -y): half the bucket sums to reduce, half the histogram, and one more bit per
+// window in the same LDS.  258 <= cb x windows keeps s + C below 2^(cb x windows) for every s < 2^256.
+constexpr uint32_t SRT_SCW = 9;                               // words of s + C, least significant first
+constexpr uint32_t SRT_AFF = 3 * r28::NL;                     // a prepared point: x, y, -y (L28)
+struct SrtBias { uint32_t w[SRT_SCW]; };                      // C
+
+// affine big-endian points (96 bytes, (0, 0) = infinity) -> x, y, -y in the L28 form + live flags; big-endian scalars -> s + C
+__global__ void __launch_bounds__(256) k_srt_prep(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars, uint32_t n, SrtBias C,
+                                                  uint32_t* __restrict__ prep, uint8_t* __restrict__ live, uint32_t* __restrict__ rec)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t any = 0;
+    r28::fe y;
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        uint32_t c[12];
+#pragma unroll
+        for (int w = 0; w < 12; w++) { c[11 - w] = bswap32(pts[(size_t)i * 24 + k * 12 + w]); any |= c[11 - w]; }
+        y = r28::from_raw(c);
+        r28::st(y, prep + (size_t)i * SRT_AFF + k * r28::NL);
+    }
+    r28::st(r28::norm(r28::neg(y)), prep + (size_t)i * SRT_AFF + 2 * r28::NL);
+    live[i] = any ? 1 : 0;
+    uint64_t t = 0;
+#pragma unroll
+    for (int j = 0; j < (int)SRT_SCW; j++) {
+        t += (uint64_t)(j < 8 ? bswap32(scalars[(size_t)i * 8 + 7 - j]) : 0u) + C.w[j];
+        rec[(size_t)i * SRT_SCW + j] = (uint32_t)t;
+        t >>= 32;
+    }
+}
+#else
+;
+#endif
+
+// biased digit of window w of a recoded scalar (one or two of its nine words)
+__device__ __forceinline__ uint32_t srt_digit_at(const uint32_t* __restrict__ rec, uint32_t w, uint32_t cb) {
     const uint32_t o = w * cb, j = o >> 5, sft = o & 31u;
-    uint32_t v = bswap32(sc[7u - j]) >> sft;
-    if (sft + cb > 32u && j < 7u) v |= bswap32(sc[6u - j]) << (32u - sft);
+    uint32_t v = rec[j] >> sft;
+    if (sft + cb > 32u && j + 1u < SRT_SCW) v |= rec[j + 1u] << (32u - sft);
     return v & ((1u << cb) - 1u);
+}
+// biased digit -> key index inside the window (|d| - 1) and the sign; false for d = 0
+__device__ __forceinline__ bool srt_key(uint32_t v, uint32_t cb, uint32_t& k, uint32_t& sign) {
+    const uint32_t half = 1u << (cb - 1u);
+    sign = v < half ? 1u : 0u;
+    k = (sign ? half - v : v - half) - 1u;
+    return v != half;
 }
 
 // Counting sort by key, histograms in LDS.  Workgroup (slice, window) owns SRT_SLICE consecutive points and the
 // 2^cb digits of one window: k_srt_count adds its histogram to cnt[]; k_srt_scatter rebuilds the histogram, reserves a
 // range of every non-empty bucket's run with ONE global atomic per bucket, and hands the positions out from LDS.
 constexpr uint32_t SRT_SLICE = 65536;
-constexpr uint32_t SRT_MAXBITS = 13;                          // 2^13 u32 of LDS per workgroup
+constexpr uint32_t SRT_MAXBITS = 14;                          // 2^13 u32 of LDS per workgroup (2^(cb-1) keys per window)
 
-__device__ __forceinline__ void srt_histogram(uint32_t* hist, const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ live,
+__device__ __forceinline__ void srt_histogram(uint32_t* hist, const uint32_t* __restrict__ rec, const uint8_t* __restrict__ live,
                                               uint32_t lo, uint32_t hi, uint32_t w, uint32_t cb) {
-    for (uint32_t k = threadIdx.x; k < (1u << cb); k += blockDim.x) hist[k] = 0;
+    for (uint32_t k = threadIdx.x; k < (1u << (cb - 1u)); k += blockDim.x) hist[k] = 0;
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t d = live[i] ? srt_digit_at(scalars + (size_t)i * 8, w, cb) : 0u;
-        if (d) atomicAdd(&hist[d], 1u);
+        uint32_t k, sign;
+        if (live[i] && srt_key(srt_digit_at(rec + (size_t)i * SRT_SCW, w, cb), cb, k, sign)) atomicAdd(&hist[k], 1u);
     }
     __syncthreads();
 }
@@ -1034,11 +1080,11 @@ __global__ void __launch_bounds__(1024) k_srt_count(const uint32_t* __restrict__
                                                     uint32_t cb, uint32_t* __restrict__ cnt)
 #if BLSGPU_EMIT(BLSGPU_TU_MSM)
 {
-    __shared__ uint32_t hist[1u << SRT_MAXBITS];
-    const uint32_t w = blockIdx.y, lo = blockIdx.x * SRT_SLICE, hi = min(n, lo + SRT_SLICE);
+    __shared__ uint32_t hist[1u << (SRT_MAXBITS - 1)];
+    const uint32_t w = blockIdx.y, lo = blockIdx.x * SRT_SLICE, hi = min(n, lo + SRT_SLICE), kb = cb - 1u;
     srt_histogram(hist, scalars, live, lo, hi, w, cb);
-    for (uint32_t k = threadIdx.x; k < (1u << cb); k += blockDim.x)
-        if (hist[k]) atomicAdd(&cnt[(w << cb) + k], hist[k]);
+    for (uint32_t k = threadIdx.x; k < (1u << kb); k += blockDim.x)
+        if (hist[k]) atomicAdd(&cnt[(w << kb) + k], hist[k]);
 }
 #else
 ;
@@ -1106,15 +1152,15 @@ __global__ void __launch_bounds__(1024) k_srt_scatter(const uint32_t* __restrict
                                                       uint32_t cb, uint32_t* __restrict__ cursor, uint32_t* __restrict__ idx)
 #if BLSGPU_EMIT(BLSGPU_TU_MSM)
 {
-    __shared__ uint32_t hist[1u << SRT_MAXBITS];
-    const uint32_t w = blockIdx.y, lo = blockIdx.x * SRT_SLICE, hi = min(n, lo + SRT_SLICE);
+    __shared__ uint32_t hist[1u << (SRT_MAXBITS - 1)];
+    const uint32_t w = blockIdx.y, lo = blockIdx.x * SRT_SLICE, hi = min(n, lo + SRT_SLICE), kb = cb - 1u;
     srt_histogram(hist, scalars, live, lo, hi, w, cb);
-    for (uint32_t k = threadIdx.x; k < (1u << cb); k += blockDim.x)
-        if (hist[k]) hist[k] = atomicAdd(&cursor[(w << cb) + k], hist[k]);        // first list position of this slice's entries
+    for (uint32_t k = threadIdx.x; k < (1u << kb); k += blockDim.x)
+        if (hist[k]) hist[k] = atomicAdd(&cursor[(w << kb) + k], hist[k]);        // first list position of this slice's entries
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t d = live[i] ? srt_digit_at(scalars + (size_t)i * 8, w, cb) : 0u;
-        if (d) idx[atomicAdd(&hist[d], 1u)] = i;
+        uint32_t k, sign;
+        if (live[i] && srt_key(srt_digit_at(scalars + (size_t)i * SRT_SCW, w, cb), cb, k, sign)) idx[atomicAdd(&hist[k], 1u)] = i | (sign << 31);
     }
 }
 #else
@@ -1157,12 +1203,9 @@ __global__ void __launch_bounds__(64, BLSGPU_SRT_WAVES) k_srt_accum(const uint32
                 acc = r28::pt_inf<fe>();
                 do { key++; nxt = start[key + 1]; } while (nxt <= p);
             }
-#ifdef BLSGPU_EXP_NOGATHER
-            const uint32_t* pt = prep + (size_t)(p & 1023u) * L28_AFF;
-#else
-            const uint32_t* pt = prep + (size_t)idx[p] * L28_AFF;
-#endif
-            const fe x2 = r28::ld(pt), y2 = r28::ld(pt + r28::NL);
+            const uint32_t e = idx[p];                         // point index, bit 31: the digit is negative (add -P)
+            const uint32_t* pt = prep + (size_t)(e & 0x7FFFFFFFu) * SRT_AFF;
+            const fe x2 = r28::ld(pt), y2 = r28::ld(pt + r28::NL + (e >> 31) * r28::NL);
             r28::pmadd(acc, x2, y2);
         }
         if (head) { r28::pt_st(acc, headpart + (size_t)L * SRT_PJ); hk = key; }
@@ -1237,9 +1280,9 @@ __global__ void __launch_bounds__(64) k_srt_fix_long(const uint32_t* __restrict_
 ;
 #endif
 
-// lane (window w, bit b, item j): the SRT_BITADDS buckets of window w whose digits are the numbers m = SRT_BITADDS j ..
-// + SRT_BITADDS - 1 with a 1 inserted at bit b (the m-th digit that has bit b) -> out[(w * cb + b) * nitem + j]; every lane
-// the same number of additions, 2^(cb-1) / SRT_BITADDS items per (window, bit)
+// lane (window w, bit b, item j): the SRT_BITADDS buckets of window w whose values |d| are the numbers m = SRT_BITADDS j .. + SRT_BITADDS - 1
+// with a 1 inserted at bit b (the m-th value below 2^(cb-1) that has bit b) -> out[(w * cb + b) * nitem + j]; every lane the same
+// number of additions, 2^(cb-2) / SRT_BITADDS items per (window, bit).  Bit cb - 1 is the one bucket |d| = 2^(cb-1) (item 0).
 constexpr uint32_t SRT_BITADDS = 8;
 __global__ void __launch_bounds__(64) k_srt_bits(const uint32_t* __restrict__ bsum, uint32_t nwin, uint32_t cb, uint32_t total,
                                                  uint32_t* __restrict__ out)
@@ -1248,13 +1291,17 @@ __global__ void __launch_bounds__(64) k_srt_bits(const uint32_t* __restrict__ bs
     using r28::fe;
     const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= total) return;
-    const uint32_t nitem = (1u << (cb - 1u)) / SRT_BITADDS;
+    const uint32_t kb = cb - 1u, nitem = (1u << (cb - 2u)) / SRT_BITADDS;
     const uint32_t j = L % nitem, b = (L / nitem) % cb, w = L / (nitem * cb);
     r28::ptT<fe> acc = r28::pt_inf<fe>();
+    if (b == kb) {
+        if (j == 0u) acc = r28::pt_ld<fe>(bsum + ((size_t)(w << kb) + (1u << kb) - 1u) * SRT_PJ);
+    } else {
 #pragma unroll 1
-    for (uint32_t m = j * SRT_BITADDS; m < (j + 1u) * SRT_BITADDS; m++) {
-        const uint32_t d = ((m >> b) << (b + 1u)) | (1u << b) | (m & ((1u << b) - 1u));
-        acc = r28::padd(acc, r28::pt_ld<fe>(bsum + ((size_t)(w << cb) + d) * SRT_PJ));
+        for (uint32_t m = j * SRT_BITADDS; m < (j + 1u) * SRT_BITADDS; m++) {
+            const uint32_t v = ((m >> b) << (b + 1u)) | (1u << b) | (m & ((1u << b) - 1u));
+            acc = r28::padd(acc, r28::pt_ld<fe>(bsum + ((size_t)(w << kb) + v - 1u) * SRT_PJ));
+        }
     }
     r28::pt_st(acc, out + (size_t)L * SRT_PJ);
 }
@@ -1303,6 +1350,7 @@ __attribute__((used)) static const void* const blsgpu_instances_msm[] = {
     (const void*)&k_msm_pip_horner<1>,
     (const void*)&k_msm_pip_horner<2>,
     (const void*)&k_lane_prep<1>,
+    (const void*)&k_srt_prep,
     (const void*)&k_lane_prep<2>,
     (const void*)&k_msm_lane<1>,
     (const void*)&k_msm_lane<2>,
