@@ -1048,12 +1048,13 @@ def run_c5(env, args):
             "steps": reps, "warmup": 1, "ms_per_step": dtm * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: ONE G1 multi-scalar sum over %d different PRF points, %d per GPU; sorted buckets: "
-                                   "13-bit windows, counting sort of the (window, digit) keys, equal pieces of the sorted list per lane "
-                                   "(complete mixed additions on 28-bit limbs in registers), bit sums of the buckets, Horner (DESIGN.md 2d)" % (total, n),
+                                   "13-bit windows of signed digits, counting sort of the (window, |digit|) keys, equal pieces of the sorted list per lane "
+                                   "(complete mixed additions on 28-bit limbs in registers), bit sums of the buckets, folds / window sums / Horner "
+                                   "on one wavefront per chain with a product per lane (DESIGN.md 2d)" % (total, n),
                        "name": "c5", "parallelism": "points split %d ways + all-gather of 100 B per rank" % env.world,
                        "steps_in_flight": S, "check": check},
             "one_step_alone_ms": dt_alone * 1e3, "value_alone": total / dt_alone_max,
-            "roofline": {"bound": "valu-int32-mac", "kernel": "k_srt_accum (+ k_lane_prep, k_srt_count/scan/scatter/fix/bits, fold, windows, horner)",
+            "roofline": {"bound": "valu-int32-mac", "kernel": "k_srt_accum (+ k_srt_prep, k_srt_count/scan/scatter/fix/bits, k_msm_lane_fold, k_msm_horner_wide)",
                          "peak": PEAK_TMACS, "unit": "TMAC/s", "achieved": mac / dtm / 1e12 / env.world, "frac": mac / dtm / 1e12 / PEAK_TMACS / env.world,
                          "traffic": config_traffic("c5")[0], "traffic_source": config_traffic("c5")[1],
                          "executed_TMACs": executed / dtm / 1e12 if total == 1 << 20 and env.world == 1 else None,
