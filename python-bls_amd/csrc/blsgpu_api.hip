@@ -79,6 +79,8 @@ struct blsgpu_ctx {
     void* d_h2c_ws = nullptr;          // the lane-private point slots of k_h2c_clear_pairs
     size_t h2c_ws_cap = 0;
     size_t msm_sort_threshold = 1;      // points from which one G1 sum with scalars uses sorted buckets (k_srt_*): since the tail runs on the wide machine (round 5) they win at every size -- 1 point 1.24 ms against 1.63, 8192 points 1.45 against 2.59 (profiles/r05_c5_window_bits.txt)
+    size_t msm_sort2_threshold = 1;     // the same for ONE G2 sum with scalars (round 5: BLS.aggregate_sigs(secure) as a multi-scalar sum)
+    static uint32_t msm_sort2_bits(size_t n) { return n >= 16384 ? 13 : (n >= 512 ? 11 : 9); }   // window bits of the G2 path by size (tools/g2_single_sum_probe.py, profiles/r05_g2_single_sum.txt)
     size_t horner_np_threshold = 1024; // G2 sums per call from which the window Horner runs several sums per team
     size_t horner_quads_threshold = 2; // G2 sums per call (lane-pair bucket kernel) from which the window Horner runs one sum per lane quad
     size_t wg256_max_waves = 4096;     // register kernels: launches of up to this many wavefronts go out as 256-thread workgroups (blsgpu_tu.h)
@@ -290,29 +292,32 @@ int decompress_host(blsgpu_ctx* c, const uint8_t* in, size_t n, uint8_t* out, ui
 namespace {
 constexpr int MSM_WAVES = 4;
 
-// One large G1 sum with scalars by sorted buckets (blsgpu_msm.hip, k_srt_*): enqueues on `st` and returns, like every
-// _dev path (no synchronisation, usable under stream capture).  Returns 1 only when the key list would not fit 32 bits;
-// the caller then takes the fixed-window path.
-static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* d_out_inf, hipStream_t st) {
+// One sum with scalars by sorted buckets (blsgpu_msm.hip, k_srt_*; G1 a unit per lane, G2 per lane pair): enqueues on `st` and
+// returns, like every _dev path (no synchronisation, usable under stream capture).  Returns 1 only when the key list would not fit
+// 32 bits; the caller then takes the fixed-window path.
+template <int DEG>
+static int msm_sorted(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t n, void* d_out, void* d_out_inf, hipStream_t st) {
+    typedef blsgpu::SrtG<DEG> G;
     // Window bits: with 131 072 equal pieces a run covers 131072 / (keys per window x windows) pieces whatever n is, and a run of
     // more than three pieces costs a whole wavefront in k_srt_fix_long.  With signed digits (2^(cb-1) keys per window) 13 bits are
     // the best width at every size the sorted path serves (tools/c5_probe.py under BLSGPU_MSM_SORT_BITS, profiles/r05_c5_window_bits.txt:
     // 2^20 points 5.71 / 5.42 / 5.46 ms for 12 / 13 / 14 bits, 16 384 points 1.88 / 1.52 / 1.68).
-    uint32_t cb = 13;
-    if (const char* e = getenv("BLSGPU_MSM_SORT_BITS")) cb = (uint32_t)strtoul(e, nullptr, 10);
+    uint32_t cb = DEG == 1 ? (n < 512 ? 7u : 13u) : c->msm_sort2_bits(n);   // (a few points: 37 windows of 64 keys, 1.06 ms for one point against 1.24)
+    if (const char* e = getenv(DEG == 1 ? "BLSGPU_MSM_SORT_BITS" : "BLSGPU_MSM_SORT2_BITS")) cb = (uint32_t)strtoul(e, nullptr, 10);
     if (cb < 5 || cb > blsgpu::SRT_MAXBITS) return fail(-EINVAL, "BLSGPU_MSM_SORT_BITS out of range");
     // signed digits (blsgpu_msm.hip): 2^(cb-1) keys per window; 258 <= cb x windows keeps the recoded scalar inside the windows
     const uint32_t kb = cb - 1, nwin = (258 + cb - 1) / cb;
     const size_t nkeys = (size_t)nwin << kb;
     if ((size_t)nwin * n > 0xFFFFFFF0ull || n >= 0x80000000ull) return 1;
     const size_t nch = ((size_t)1 << (cb - 2)) / blsgpu::SRT_BITADDS, nsum = (size_t)nwin * cb;
-    const size_t lanes = blsgpu::SRT_LANES;
+    const size_t units = blsgpu::SRT_LANES / G::LP;
+    const bool wide = DEG == 2 || c->msm_wide_tail;           // (G2 has no tail on the wavefront VM)
     // workspace: prep | recoded scalars | cnt | start (+1) | cursor | maxcnt, total | idx | bsum | headpart | headkey | bit sums (two buffers) | winsums
     size_t off = 0;
     auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
-    const size_t PJ = blsgpu::SRT_PJ;
-    const size_t o_prep = take(n * blsgpu::SRT_AFF), o_rec = take(n * blsgpu::SRT_SCW), o_cnt = take(nkeys), o_start = take(nkeys + 1), o_cur = take(nkeys),
-                 o_max = take(4), o_idx = take((size_t)nwin * n), o_bsum = take(nkeys * PJ), o_hp = take(lanes * PJ), o_hk = take(lanes),
+    const size_t PJ = G::PJ;
+    const size_t o_prep = take(n * G::AFF), o_rec = take(n * blsgpu::SRT_SCW), o_cnt = take(nkeys), o_start = take(nkeys + 1), o_cur = take(nkeys),
+                 o_max = take(4), o_idx = take((size_t)nwin * n), o_bsum = take(nkeys * PJ), o_hp = take(units * PJ), o_hk = take(units),
                  o_b0 = take(nsum * nch * PJ), o_b1 = take(nsum * ((nch + 7) / 8) * PJ + PJ), o_win = take((size_t)nwin * PJ), o_live = take((n + 3) / 4),
                  o_wtot = take(2 * (size_t)nwin), o_long = take(nkeys + 4);
     if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, off)) return rc_;
@@ -326,8 +331,8 @@ static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars
         const uint32_t pos = cb * w + cb - 1;
         bias.w[pos >> 5] |= 1u << (pos & 31);
     }
-    hipLaunchKernelGGL(blsgpu::k_srt_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t)n, bias,
-                       W + o_prep, live, W + o_rec);
+    hipLaunchKernelGGL(blsgpu::k_srt_prep<DEG>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t)n,
+                       bias, W + o_prep, live, W + o_rec);
     HIP_TRY(hipGetLastError());
     const uint32_t* sc = W + o_rec;
     const dim3 sgrid((unsigned)((n + blsgpu::SRT_SLICE - 1) / blsgpu::SRT_SLICE), nwin);
@@ -340,38 +345,46 @@ static int msm_sorted_g1(blsgpu_ctx* c, const void* d_pts, const void* d_scalars
     // k_srt_fix_long -- all-equal scalars cost ~100 additions per lane there (a millisecond), and only a batch whose scalars
     // leave all windows but one empty is slow (still correct, and still faster than the fixed windows it used to fall back to).
     hipLaunchKernelGGL(blsgpu::k_srt_scatter, sgrid, dim3(1024), 0, st, sc, live, (uint32_t)n, cb, W + o_cur, W + o_idx);
-    hipLaunchKernelGGL(blsgpu::k_srt_accum, dim3((unsigned)(lanes / 64)), dim3(64), 0, st, W + o_prep, W + o_idx, W + o_start, (uint32_t)nkeys,
-                       (uint32_t)lanes, W + o_bsum, W + o_hp, W + o_hk);
+    const auto blocks = [&](size_t nunits) { return dim3((unsigned)((nunits * G::LP + 63) / 64)); };
+    hipLaunchKernelGGL(blsgpu::k_srt_accum<DEG>, blocks(units), dim3(64), 0, st, W + o_prep, W + o_idx, W + o_start, (uint32_t)nkeys, (uint32_t)units,
+                       W + o_bsum, W + o_hp, W + o_hk);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(blsgpu::k_srt_fix, dim3((unsigned)((nkeys + 63) / 64)), dim3(64), 0, st, W + o_start, (uint32_t)nkeys, (uint32_t)lanes,
-                       W + o_hp, W + o_hk, W + o_bsum, W + o_long, W + o_long + 4);
-    hipLaunchKernelGGL(blsgpu::k_srt_fix_long, dim3(1024), dim3(64), 0, st, W + o_start, (uint32_t)nkeys, (uint32_t)lanes, W + o_hp, W + o_bsum,
+    hipLaunchKernelGGL(blsgpu::k_srt_fix<DEG>, blocks(nkeys), dim3(64), 0, st, W + o_start, (uint32_t)nkeys, (uint32_t)units, W + o_hp, W + o_hk, W + o_bsum,
                        W + o_long, W + o_long + 4);
+    hipLaunchKernelGGL(blsgpu::k_srt_fix_long<DEG>, dim3(1024), dim3(64), 0, st, W + o_start, (uint32_t)nkeys, (uint32_t)units, W + o_hp, W + o_bsum, W + o_long,
+                       W + o_long + 4);
     const size_t btotal = nsum * nch;
-    hipLaunchKernelGGL(blsgpu::k_srt_bits, dim3((unsigned)((btotal + 63) / 64)), dim3(64), 0, st, W + o_bsum, nwin, cb, (uint32_t)btotal, W + o_b0);
+    hipLaunchKernelGGL(blsgpu::k_srt_bits<DEG>, blocks(btotal), dim3(64), 0, st, W + o_bsum, nwin, cb, (uint32_t)btotal, W + o_b0);
     HIP_TRY(hipGetLastError());
     uint32_t *src = W + o_b0, *dst = W + o_b1;
-    if (nch == 1 && !c->msm_wide_tail) {                      // (5-bit windows: nothing to fold, but the VM's tail reads its own form)
+    // the tail on the wide machine: result = sum_i 2^(c i) P_i over a list, one wavefront per list (blsgpu_g1w.hip, blsgpu_h2cw.hip)
+    const auto horner = [&](size_t lists, const uint32_t* in, uint32_t npts, uint32_t cbits, uint32_t* out) {
+        if (DEG == 1) hipLaunchKernelGGL(blsgpu::g1w::k_msm_horner_wide<0>, dim3((unsigned)lists), dim3(64), 0, st, in, npts, cbits, out, (uint8_t*)nullptr);
+        else hipLaunchKernelGGL(blsgpu::h2cw::k_msm_horner_wide2<0>, dim3((unsigned)lists), dim3(64), 0, st, in, npts, cbits, out, (uint8_t*)nullptr);
+    };
+    if (nch == 1 && !wide) {                                  // (5-bit windows: nothing to fold, but the VM's tail reads its own form)
         hipLaunchKernelGGL(blsgpu::k_msm_lane_fold<1>, dim3((unsigned)((nsum + 63) / 64)), dim3(64), 0, st, src, 1u, 1u, 1u, (uint32_t)nsum, dst, 1u);
         src = dst;
     }
-    for (size_t cur = nch; cur > 1;) {                        // runs of 8 partial sums per lane until one is left per (window, bit)
+    for (size_t cur = nch; cur > 1;) {                        // runs of 8 partial sums per unit until one is left per (window, bit)
         const size_t nfold = (cur + 7) / 8, ftotal = nsum * nfold;
-        if (c->msm_wide_tail && ftotal <= 4096 && (cur <= 8 || cur % 8 == 0))
+        if (wide && ftotal <= 4096 && (cur <= 8 || cur % 8 == 0))
             // few runs left: one wavefront per run, an addition two steps of the wide machine (a lane's own addition is ~6000 instructions)
-            hipLaunchKernelGGL(blsgpu::g1w::k_msm_horner_wide<0>, dim3((unsigned)ftotal), dim3(64), 0, st, src, (uint32_t)(cur < 8 ? cur : 8), 0u, dst,
-                               (uint8_t*)nullptr);
+            horner(ftotal, src, (uint32_t)(cur < 8 ? cur : 8), 0u, dst);
+        else if (wide)
+            hipLaunchKernelGGL(blsgpu::k_srt_fold<DEG>, blocks(ftotal), dim3(64), 0, st, src, (uint32_t)cur, 8u, (uint32_t)nfold, (uint32_t)ftotal, dst);
         else
             hipLaunchKernelGGL(blsgpu::k_msm_lane_fold<1>, dim3((unsigned)((ftotal + 63) / 64)), dim3(64), 0, st, src, (uint32_t)cur, 8u,
-                               (uint32_t)nfold, (uint32_t)ftotal, dst, nfold == 1 && !c->msm_wide_tail ? 1u : 0u);   // the last fold: the VM's form for the VM's tail
+                               (uint32_t)nfold, (uint32_t)ftotal, dst, nfold == 1 ? 1u : 0u);   // the last fold: the VM's form for the VM's tail
         HIP_TRY(hipGetLastError());
         uint32_t* t = src; src = dst; dst = t;
         cur = nfold;
     }
-    if (c->msm_wide_tail) {
-        // W_w = sum_b 2^b S_(w,b), one wavefront per window; then sum_w 2^(cb w) W_w on one wavefront (blsgpu_g1w.hip)
-        hipLaunchKernelGGL(blsgpu::g1w::k_msm_horner_wide<0>, dim3(nwin), dim3(64), 0, st, src, cb, 1u, W + o_win, (uint8_t*)nullptr);
-        hipLaunchKernelGGL(blsgpu::g1w::k_msm_horner_wide<1>, dim3(1), dim3(64), 0, st, W + o_win, nwin, cb, (uint32_t*)d_out, (uint8_t*)d_out_inf);
+    if (wide) {
+        // W_w = sum_b 2^b S_(w,b), one wavefront per window; then sum_w 2^(cb w) W_w on one wavefront
+        horner(nwin, src, cb, 1u, W + o_win);
+        if (DEG == 1) hipLaunchKernelGGL(blsgpu::g1w::k_msm_horner_wide<1>, dim3(1), dim3(64), 0, st, W + o_win, nwin, cb, (uint32_t*)d_out, (uint8_t*)d_out_inf);
+        else hipLaunchKernelGGL(blsgpu::h2cw::k_msm_horner_wide2<1>, dim3(1), dim3(64), 0, st, W + o_win, nwin, cb, (uint32_t*)d_out, (uint8_t*)d_out_inf);
     } else {
         hipLaunchKernelGGL(blsgpu::k_srt_windows, dim3(nwin), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, src, cb, W + o_win);
         hipLaunchKernelGGL(blsgpu::k_msm_pip_horner<1>, dim3(1), dim3(64), (size_t)blsgpu::TEAM_BYTES, st, c->tabs, W + o_win, nwin, cb,
@@ -393,8 +406,8 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
         return 0;
     }
     if (k > 0x7FFFFFFFull || groups > 0x7FFFFFFFull || k * groups > 0xFFFFFFF0ull) return fail(-EINVAL, "msm too large");
-    if (DEG == 1 && groups == 1 && d_scalars && k >= c->msm_sort_threshold) {
-        const int rc_ = msm_sorted_g1(c, d_pts, d_scalars, k, d_out, d_out_inf, st);
+    if (groups == 1 && d_scalars && k >= (DEG == 1 ? c->msm_sort_threshold : c->msm_sort2_threshold)) {
+        const int rc_ = msm_sorted<DEG>(c, d_pts, d_scalars, k, d_out, d_out_inf, st);
         if (rc_ != 1) return rc_;
     }
     if ((groups == 1 && k >= c->pip_threshold) || (groups > 1 && groups <= 65535 && k >= c->pip_group_threshold)) {
@@ -578,6 +591,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_H2C_JACOBI_THRESHOLD")) c->h2c_jacobi_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_H2C_LANE_THRESHOLD")) c->h2c_lane_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_MSM_SORT2_THRESHOLD")) c->msm_sort2_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_NP_THRESHOLD")) c->horner_np_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_QUADS_THRESHOLD")) c->horner_quads_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_WG256_MAX_WAVES")) c->wg256_max_waves = (size_t)strtoull(e, nullptr, 10);

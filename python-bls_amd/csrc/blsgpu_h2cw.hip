@@ -131,5 +131,95 @@ __global__ void __launch_bounds__(64) k_h2c_clear_wide(VmTables T, const uint32_
 #else
 ;
 #endif
+
+// ---- the window Horner of a G2 sum on the same tables (round 5) -------------------------------------------------------------------
+// result = sum_i 2^(c i) P_i over a short list of projective G2 points, Horner from the top: the tail of the sorted-bucket G2 sum
+// (BLS.aggregate_sigs(secure), bls.py:225-261, as one multi-scalar sum) -- the last folds (c = 0), the window sums (c = 1, one
+// wavefront per window) and the sum over the windows (c = 13) -- what blsgpu_g1w.hip's k_msm_horner_wide is for G1.  The
+// accumulator is point 0 of the clearing's value file, the addend slot point 0, the steps its DBL1 / DBL2 / ADD1_0p / ADD2 (complete
+// formulas: infinity anywhere, a doubling inside an addition, P + (-P) need no branch); vmgen/h2cw_model.horner is this loop on the
+// tables (tests/test_h2cw_model.py).
+// in: gridDim.x lists of npts projective points in the L28 form (X.re X.im Y.re Y.im Z.re Z.im, 84 dwords; index 0 the lowest term).
+// AFFINE = 0: out = the sum in the same form; AFFINE = 1: out = 192 bytes canonical affine (x.c0, x.c1, y.c0, y.c1 big-endian), (0, 0)
+// and out_inf[g] = 1 for infinity.
+template <int AFFINE>
+__global__ void __launch_bounds__(64) k_msm_horner_wide2(const uint32_t* __restrict__ in, uint32_t npts, uint32_t cbits, uint32_t* __restrict__ out,
+                                                         uint8_t* __restrict__ out_inf)
+#if BLSGPU_EMIT(BLSGPU_TU_FXW)
+{
+    constexpr uint32_t PJ_DW = 6 * NL;
+    __shared__ int32_t vfile[VF_DW];
+    char* vf = reinterpret_cast<char*>(vfile);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = blockIdx.x;
+    for (uint32_t i = lane; i < (uint32_t)VF_DW; i += 64u) vfile[i] = 0;
+    // quad c < 6 stores value c of a point (X.re X.im Y.re Y.im Z.re Z.im) in its four multiples
+    const uint32_t qd = lane >> 2, vr = lane & 3u;
+    const int32_t variant = vr == 0u ? 1 : (vr == 1u ? -1 : (vr == 2u ? 2 : -2));
+    const uint32_t* P = in + (size_t)g * npts * PJ_DW + (qd < 6u ? qd : 0u) * NL;
+    int32_t t[NL], V[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) t[j] = (int32_t)P[(size_t)(npts - 1u) * PJ_DW + j];
+    mlw::srn(V, t, variant);
+    __syncthreads();                                              // (one wavefront: the zeroing above is done before anything is stored)
+    const uint32_t A0 = H2CW_POINT[0], S0 = H2CW_POINT[1];
+    if (qd < 6u) mlw::st14(vf, A0 + 16u * qd + 4u * vr, V);
+    const mlw::Rec d1 = load_rec(H2CW_KIND_DBL1, lane), d2 = load_rec(H2CW_KIND_DBL2, lane), a1 = load_rec(H2CW_KIND_ADD1_0p, lane),
+                   a2 = load_rec(H2CW_KIND_ADD2, lane);
+#pragma unroll 1
+    for (int i = (int)npts - 2; i >= 0; i--) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) t[j] = (int32_t)P[(size_t)i * PJ_DW + j];            // (in flight behind the doublings)
+#pragma unroll 1
+        for (uint32_t s = 0; s < cbits; s++) {
+            mlw::wstep<1, false>(vf, d1);
+            mlw::wstep<1, false>(vf, d2);
+        }
+        mlw::srn(V, t, variant);
+        if (qd < 6u) mlw::st14(vf, S0 + 16u * qd + 4u * vr, V);
+        mlw::wstep<1, false>(vf, a1);
+        mlw::wstep<1, false>(vf, a2);
+    }
+    if (!AFFINE) {
+        if (qd < 6u && vr == 0u) {
+            const fe c = ld_fe(vf, A0 + 16u * qd);
+#pragma unroll
+            for (int j = 0; j < NL; j++) out[(size_t)g * PJ_DW + qd * NL + j] = (uint32_t)c.v[j];
+        }
+        return;
+    }
+    // affine: (X, Y) / Z with 1 / Z = conj(Z) / N(Z); Z = 0 gives (0, 0) (the tail of k_h2c_clear_wide)
+    const fe z0 = ld_fe(vf, A0 + 64u), z1 = ld_fe(vf, A0 + 80u);
+    const fe n = r28::dot2(z0, z0, z1, z1);
+    uint32_t nv[12], niv[12];
+    r28::to_vm(nv, n);
+    bls::fq_inv_var(niv, nv);
+    const fe ninv = r28::from_vm(niv);
+    const fe zi0 = r28::mul(z0, ninv), zi1 = r28::mul(r28::neg(z1), ninv);
+    const uint32_t lk = lane & 3u;                                // lane k < 4: part k of (x.re, x.im, y.re, y.im)
+    const uint32_t base = A0 + ((lk & 2u) ? 32u : 0u);
+    const fe c0 = ld_fe(vf, base), c1 = ld_fe(vf, base + 16u);
+    const bool im = (lk & 1u) != 0u;
+    const fe nc1 = r28::norm(r28::neg(c1));
+    fe p, q, b1;
+#pragma unroll
+    for (int j = 0; j < NL; j++) { p.v[j] = im ? zi1.v[j] : zi0.v[j]; q.v[j] = im ? zi0.v[j] : zi1.v[j]; b1.v[j] = im ? c1.v[j] : nc1.v[j]; }
+    uint32_t y[12];
+    r28::to_raw(y, r28::dot2(c0, p, b1, q));
+    uint32_t any = 0;
+#pragma unroll
+    for (int wd = 0; wd < 12; wd++) {
+        any |= y[wd];
+        if (lane < 4u) out[(size_t)g * 48 + lane * 12u + wd] = bswap32(y[11 - wd]);
+    }
+    const uint64_t nz = __ballot(any != 0u && lane < 4u);
+    if (out_inf && lane == 0u) out_inf[g] = nz == 0 ? 1 : 0;
+}
+#else
+;
+#endif
+#if BLSGPU_TU == BLSGPU_TU_FXW
+__attribute__((used)) static const void* const blsgpu_instances_h2cw[] = {(const void*)&k_msm_horner_wide2<0>, (const void*)&k_msm_horner_wide2<1>};
+#endif
 }  // namespace h2cw
 }  // namespace blsgpu

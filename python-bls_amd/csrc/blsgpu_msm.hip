@@ -1011,10 +1011,46 @@ constexpr uint32_t SRT_LANES = 2048u * 64u;                   // two wavefronts 
 // entry carries the sign, the prepared point its -y): half the bucket sums to reduce, half the histogram, and one more bit per
 // window in the same LDS.  258 <= cb x windows keeps s + C below 2^(cb x windows) for every s < 2^256.
 constexpr uint32_t SRT_SCW = 9;                               // words of s + C, least significant first
-constexpr uint32_t SRT_AFF = 3 * r28::NL;                     // a prepared point: x, y, -y (L28)
 struct SrtBias { uint32_t w[SRT_SCW]; };                      // C
+// The group a sorted-bucket sum runs in (round 5: G2 too -- BLS.aggregate_sigs(secure), bls.py:225-261, as one multi-scalar sum):
+// G1 one piece / key / item per LANE on r28's point arithmetic, G2 one per LANE PAIR on sp2's (an Fq2 value split over two adjacent
+// lanes: no scratch, two wavefronts per SIMD).  AFF: dwords of a prepared point (x, y, -y), PJ: of a projective sum, both L28.
+template <int DEG> struct SrtG;
+template <> struct SrtG<1> {
+    typedef r28::ptT<r28::fe> P;
+    static constexpr uint32_t LP = 1, AFF = 3 * r28::NL, PJ = L28_PJ;
+    static __device__ __forceinline__ P inf() { return r28::pt_inf<r28::fe>(); }
+    static __device__ __forceinline__ P ld(const uint32_t* __restrict__ p) { return r28::pt_ld<r28::fe>(p); }
+    static __device__ __forceinline__ void st(const P& a, uint32_t* __restrict__ p) { r28::pt_st(a, p); }
+    static __device__ __forceinline__ P add(const P& a, const P& b) { return r28::padd(a, b); }
+    static __device__ __forceinline__ void madd(P& a, const uint32_t* __restrict__ pt, uint32_t neg) {        // a += (x, neg ? -y : y)
+        const r28::fe x2 = r28::ld(pt), y2 = r28::ld(pt + r28::NL + neg * r28::NL);
+        r28::pmadd(a, x2, y2);
+    }
+    static __device__ __forceinline__ void xor_lanes(P& o, const P& a, int off) {
+#pragma unroll
+        for (int q = 0; q < r28::NL; q++) { o.X.v[q] = __shfl_xor(a.X.v[q], off); o.Y.v[q] = __shfl_xor(a.Y.v[q], off); o.Z.v[q] = __shfl_xor(a.Z.v[q], off); }
+    }
+};
+template <> struct SrtG<2> {
+    typedef sp2::pt P;
+    static constexpr uint32_t LP = 2, AFF = 6 * r28::NL, PJ = 2 * L28_PJ;
+    static __device__ __forceinline__ P inf() { return sp2::pt_inf(); }
+    static __device__ __forceinline__ P ld(const uint32_t* __restrict__ p) { return sp2::pt_ld(p); }
+    static __device__ __forceinline__ void st(const P& a, uint32_t* __restrict__ p) { sp2::pt_st(a, p); }
+    static __device__ __forceinline__ P add(const P& a, const P& b) { return sp2::padd(a, b); }
+    static __device__ __forceinline__ void madd(P& a, const uint32_t* __restrict__ pt, uint32_t neg) {
+        const sp2::h x2 = sp2::ldh(pt), y2 = sp2::ldh(pt + 2 * r28::NL + neg * 2 * r28::NL);
+        sp2::pmadd(a, x2, y2);
+    }
+    static __device__ __forceinline__ void xor_lanes(P& o, const P& a, int off) {              // the same part of the pair `off` pairs away
+#pragma unroll
+        for (int q = 0; q < r28::NL; q++) { o.X.v[q] = __shfl_xor(a.X.v[q], 2 * off); o.Y.v[q] = __shfl_xor(a.Y.v[q], 2 * off); o.Z.v[q] = __shfl_xor(a.Z.v[q], 2 * off); }
+    }
+};
 
-// affine big-endian points (96 bytes, (0, 0) = infinity) -> x, y, -y in the L28 form + live flags; big-endian scalars -> s + C
+// affine big-endian points (96 DEG bytes, (0, 0) = infinity) -> x, y, -y in the L28 form + live flags; big-endian scalars -> s + C
+template <int DEG>
 __global__ void __launch_bounds__(256) k_srt_prep(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars, uint32_t n, SrtBias C,
                                                   uint32_t* __restrict__ prep, uint8_t* __restrict__ live, uint32_t* __restrict__ rec)
 #if BLSGPU_EMIT(BLSGPU_TU_MSM)
@@ -1022,16 +1058,16 @@ __global__ void __launch_bounds__(256) k_srt_prep(const uint32_t* __restrict__ p
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t any = 0;
-    r28::fe y;
+    uint32_t* dst = prep + (size_t)i * SrtG<DEG>::AFF;
 #pragma unroll 1
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 2 * DEG; k++) {
         uint32_t c[12];
 #pragma unroll
-        for (int w = 0; w < 12; w++) { c[11 - w] = bswap32(pts[(size_t)i * 24 + k * 12 + w]); any |= c[11 - w]; }
-        y = r28::from_raw(c);
-        r28::st(y, prep + (size_t)i * SRT_AFF + k * r28::NL);
+        for (int w = 0; w < 12; w++) { c[11 - w] = bswap32(pts[(size_t)i * 24 * DEG + k * 12 + w]); any |= c[11 - w]; }
+        const r28::fe v = r28::from_raw(c);
+        r28::st(v, dst + k * r28::NL);
+        if (k >= DEG) r28::st(r28::norm(r28::neg(v)), dst + (k + DEG) * r28::NL);          // a part of y: its negative behind y
     }
-    r28::st(r28::norm(r28::neg(y)), prep + (size_t)i * SRT_AFF + 2 * r28::NL);
     live[i] = any ? 1 : 0;
     uint64_t t = 0;
 #pragma unroll
@@ -1167,22 +1203,23 @@ __global__ void __launch_bounds__(1024) k_srt_scatter(const uint32_t* __restrict
 ;
 #endif
 
-// lane l sums list entries [l per, (l + 1) per): see the header of this section.  headkey[l] = key of the piece
-// that continues a run begun before the lane (or ~0), headpart[l] its sum.
+// unit l (a lane, or a lane pair for G2) sums list entries [l per, (l + 1) per): see the header of this section.  headkey[l] = key of
+// the piece that continues a run begun before the unit (or ~0), headpart[l] its sum.
 #ifndef BLSGPU_SRT_WAVES
 #define BLSGPU_SRT_WAVES 2
 #endif
 constexpr uint32_t SRT_PJ = L28_PJ;                           // dwords of a G1 sum (L28)
+template <int DEG>
 __global__ void __launch_bounds__(64, BLSGPU_SRT_WAVES) k_srt_accum(const uint32_t* __restrict__ prep, const uint32_t* __restrict__ idx,
-                                                     const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
+                                                     const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nunits,
                                                      uint32_t* __restrict__ bsum, uint32_t* __restrict__ headpart,
                                                      uint32_t* __restrict__ headkey)
 #if BLSGPU_EMIT(BLSGPU_TU_MSM)
 {
-    using r28::fe;
-    const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
-    if (L >= nlanes) return;
-    const uint32_t total = start[nkeys], per = (total + nlanes - 1u) / nlanes;
+    typedef SrtG<DEG> G;
+    const uint32_t L = (blockIdx.x * blockDim.x + threadIdx.x) / G::LP;
+    if (L >= nunits) return;
+    const uint32_t total = start[nkeys], per = (total + nunits - 1u) / nunits;
     const uint32_t p0 = min(total, L * per), p1 = min(total, p0 + per);
     uint32_t hk = 0xFFFFFFFFu;
     if (p0 < p1) {
@@ -1193,23 +1230,21 @@ __global__ void __launch_bounds__(64, BLSGPU_SRT_WAVES) k_srt_accum(const uint32
         }
         uint32_t key = lo, nxt = start[key + 1];
         bool head = start[key] < p0;
-        r28::ptT<fe> acc = r28::pt_inf<fe>();
+        typename G::P acc = G::inf();
 #pragma unroll 1
         for (uint32_t p = p0; p < p1; p++) {
             if (p == nxt) {                                   // the run of `key` ends here
-                if (head) { r28::pt_st(acc, headpart + (size_t)L * SRT_PJ); hk = key; }
-                else r28::pt_st(acc, bsum + (size_t)key * SRT_PJ);
+                if (head) { G::st(acc, headpart + (size_t)L * G::PJ); hk = key; }
+                else G::st(acc, bsum + (size_t)key * G::PJ);
                 head = false;
-                acc = r28::pt_inf<fe>();
+                acc = G::inf();
                 do { key++; nxt = start[key + 1]; } while (nxt <= p);
             }
             const uint32_t e = idx[p];                         // point index, bit 31: the digit is negative (add -P)
-            const uint32_t* pt = prep + (size_t)(e & 0x7FFFFFFFu) * SRT_AFF;
-            const fe x2 = r28::ld(pt), y2 = r28::ld(pt + r28::NL + (e >> 31) * r28::NL);
-            r28::pmadd(acc, x2, y2);
+            G::madd(acc, prep + (size_t)(e & 0x7FFFFFFFu) * G::AFF, e >> 31);
         }
-        if (head) { r28::pt_st(acc, headpart + (size_t)L * SRT_PJ); hk = key; }
-        else r28::pt_st(acc, bsum + (size_t)key * SRT_PJ);
+        if (head) { G::st(acc, headpart + (size_t)L * G::PJ); hk = key; }
+        else G::st(acc, bsum + (size_t)key * G::PJ);
     }
     headkey[L] = hk;
 }
@@ -1217,62 +1252,63 @@ __global__ void __launch_bounds__(64, BLSGPU_SRT_WAVES) k_srt_accum(const uint32
 ;
 #endif
 
-// one lane per key: empty buckets become infinity, the pieces of later lanes are added to the bucket.  A run of more
+// one unit per key: empty buckets become infinity, the pieces of later units are added to the bucket.  A run of more
 // than SRT_LONG pieces (the top window of 255-bit scalars has 2^8 digits for 2^20 points) goes to k_srt_fix_long.
 constexpr uint32_t SRT_LONG = 3;
-__global__ void __launch_bounds__(64) k_srt_fix(const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
+template <int DEG>
+__global__ void __launch_bounds__(64) k_srt_fix(const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nunits,
                                                 const uint32_t* __restrict__ headpart, const uint32_t* __restrict__ headkey,
                                                 uint32_t* __restrict__ bsum, uint32_t* __restrict__ nlong, uint32_t* __restrict__ longkeys)
 #if BLSGPU_EMIT(BLSGPU_TU_MSM)
 {
-    using r28::fe;
-    const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    typedef SrtG<DEG> G;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, key = tid / G::LP;
     if (key >= nkeys) return;
-    const uint32_t total = start[nkeys], per = (total + nlanes - 1u) / nlanes;
+    const uint32_t total = start[nkeys], per = (total + nunits - 1u) / nunits;
     const uint32_t s = start[key], e = start[key + 1];
-    if (s == e) { r28::pt_st(r28::pt_inf<fe>(), bsum + (size_t)key * SRT_PJ); return; }
+    if (s == e) { G::st(G::inf(), bsum + (size_t)key * G::PJ); return; }
     const uint32_t l0 = s / per, l1 = (e - 1u) / per;
     if (l0 == l1) return;
-    if (l1 - l0 > SRT_LONG) { longkeys[atomicAdd(nlong, 1u)] = key; return; }
-    r28::ptT<fe> acc = r28::pt_ld<fe>(bsum + (size_t)key * SRT_PJ);
+    if (l1 - l0 > SRT_LONG) {
+        if (tid % G::LP == 0u) longkeys[atomicAdd(nlong, 1u)] = key;
+        return;
+    }
+    typename G::P acc = G::ld(bsum + (size_t)key * G::PJ);
 #pragma unroll 1
     for (uint32_t l = l0 + 1; l <= l1; l++)
-        if (headkey[l] == key) acc = r28::padd(acc, r28::pt_ld<fe>(headpart + (size_t)l * SRT_PJ));
-    r28::pt_st(acc, bsum + (size_t)key * SRT_PJ);
+        if (headkey[l] == key) acc = G::add(acc, G::ld(headpart + (size_t)l * G::PJ));
+    G::st(acc, bsum + (size_t)key * G::PJ);
 }
 #else
 ;
 #endif
 
-// one wavefront per long run: lane j sums the pieces l0 + 1 + j, + 64, ..; butterfly over the lanes; lane 0 adds the bucket
-__global__ void __launch_bounds__(64) k_srt_fix_long(const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nlanes,
+// one wavefront per long run: unit j sums the pieces l0 + 1 + j, + 64 / LP, ..; butterfly over the units; unit 0 adds the bucket
+template <int DEG>
+__global__ void __launch_bounds__(64) k_srt_fix_long(const uint32_t* __restrict__ start, uint32_t nkeys, uint32_t nunits,
                                                      const uint32_t* __restrict__ headpart, uint32_t* __restrict__ bsum,
                                                      const uint32_t* __restrict__ nlong, const uint32_t* __restrict__ longkeys)
 #if BLSGPU_EMIT(BLSGPU_TU_MSM)
 {
-    using r28::fe;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = start[nkeys], per = (total + nlanes - 1u) / nlanes, cnt = *nlong;
+    typedef SrtG<DEG> G;
+    constexpr uint32_t UNITS = 64u / G::LP;
+    const uint32_t unit = (threadIdx.x & 63u) / G::LP;
+    const uint32_t total = start[nkeys], per = (total + nunits - 1u) / nunits, cnt = *nlong;
     for (uint32_t k = blockIdx.x; k < cnt; k += gridDim.x) {
         const uint32_t key = longkeys[k];
         const uint32_t l0 = start[key] / per, l1 = (start[key + 1] - 1u) / per;
-        r28::ptT<fe> acc = r28::pt_inf<fe>();
+        typename G::P acc = G::inf();
 #pragma unroll 1
-        for (uint32_t l = l0 + 1u + lane; l <= l1; l += 64u) acc = r28::padd(acc, r28::pt_ld<fe>(headpart + (size_t)l * SRT_PJ));
+        for (uint32_t l = l0 + 1u + unit; l <= l1; l += UNITS) acc = G::add(acc, G::ld(headpart + (size_t)l * G::PJ));
 #pragma unroll 1
-        for (int off = 32; off > 0; off >>= 1) {
-            r28::ptT<fe> o;
-#pragma unroll
-            for (int q = 0; q < r28::NL; q++) {
-                o.X.v[q] = __shfl_xor(acc.X.v[q], off);
-                o.Y.v[q] = __shfl_xor(acc.Y.v[q], off);
-                o.Z.v[q] = __shfl_xor(acc.Z.v[q], off);
-            }
-            acc = r28::padd(acc, o);
+        for (int off = (int)UNITS / 2; off > 0; off >>= 1) {
+            typename G::P o;
+            G::xor_lanes(o, acc, off);
+            acc = G::add(acc, o);
         }
-        if (lane == 0) {
-            acc = r28::padd(acc, r28::pt_ld<fe>(bsum + (size_t)key * SRT_PJ));
-            r28::pt_st(acc, bsum + (size_t)key * SRT_PJ);
+        if (unit == 0) {
+            acc = G::add(acc, G::ld(bsum + (size_t)key * G::PJ));
+            G::st(acc, bsum + (size_t)key * G::PJ);
         }
     }
 }
@@ -1280,30 +1316,51 @@ __global__ void __launch_bounds__(64) k_srt_fix_long(const uint32_t* __restrict_
 ;
 #endif
 
-// lane (window w, bit b, item j): the SRT_BITADDS buckets of window w whose values |d| are the numbers m = SRT_BITADDS j .. + SRT_BITADDS - 1
-// with a 1 inserted at bit b (the m-th value below 2^(cb-1) that has bit b) -> out[(w * cb + b) * nitem + j]; every lane the same
+// unit (window w, bit b, item j): the SRT_BITADDS buckets of window w whose values |d| are the numbers m = SRT_BITADDS j .. + SRT_BITADDS - 1
+// with a 1 inserted at bit b (the m-th value below 2^(cb-1) that has bit b) -> out[(w * cb + b) * nitem + j]; every unit the same
 // number of additions, 2^(cb-2) / SRT_BITADDS items per (window, bit).  Bit cb - 1 is the one bucket |d| = 2^(cb-1) (item 0).
 constexpr uint32_t SRT_BITADDS = 8;
+template <int DEG>
 __global__ void __launch_bounds__(64) k_srt_bits(const uint32_t* __restrict__ bsum, uint32_t nwin, uint32_t cb, uint32_t total,
                                                  uint32_t* __restrict__ out)
 #if BLSGPU_EMIT(BLSGPU_TU_MSM)
 {
-    using r28::fe;
-    const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+    typedef SrtG<DEG> G;
+    const uint32_t L = (blockIdx.x * blockDim.x + threadIdx.x) / G::LP;
     if (L >= total) return;
     const uint32_t kb = cb - 1u, nitem = (1u << (cb - 2u)) / SRT_BITADDS;
     const uint32_t j = L % nitem, b = (L / nitem) % cb, w = L / (nitem * cb);
-    r28::ptT<fe> acc = r28::pt_inf<fe>();
+    typename G::P acc = G::inf();
     if (b == kb) {
-        if (j == 0u) acc = r28::pt_ld<fe>(bsum + ((size_t)(w << kb) + (1u << kb) - 1u) * SRT_PJ);
+        if (j == 0u) acc = G::ld(bsum + ((size_t)(w << kb) + (1u << kb) - 1u) * G::PJ);
     } else {
 #pragma unroll 1
         for (uint32_t m = j * SRT_BITADDS; m < (j + 1u) * SRT_BITADDS; m++) {
             const uint32_t v = ((m >> b) << (b + 1u)) | (1u << b) | (m & ((1u << b) - 1u));
-            acc = r28::padd(acc, r28::pt_ld<fe>(bsum + ((size_t)(w << kb) + v - 1u) * SRT_PJ));
+            acc = G::add(acc, G::ld(bsum + ((size_t)(w << kb) + v - 1u) * G::PJ));
         }
     }
-    r28::pt_st(acc, out + (size_t)L * SRT_PJ);
+    G::st(acc, out + (size_t)L * G::PJ);
+}
+#else
+;
+#endif
+
+// out[w * nfold + f] = sum of partials[w * chunks + f * per .. + per): one run per unit (k_msm_lane_fold on SrtG: G2 on lane pairs)
+template <int DEG>
+__global__ void __launch_bounds__(64) k_srt_fold(const uint32_t* __restrict__ partials, uint32_t chunks, uint32_t per, uint32_t nfold,
+                                                 uint32_t total, uint32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
+    typedef SrtG<DEG> G;
+    const uint32_t L = (blockIdx.x * blockDim.x + threadIdx.x) / G::LP;
+    if (L >= total) return;
+    const uint32_t w = L / nfold, f = L % nfold;
+    const uint32_t lo = f * per, hi = min(chunks, lo + per);
+    typename G::P acc = G::inf();
+#pragma unroll 1
+    for (uint32_t i = lo; i < hi; i++) acc = G::add(acc, G::ld(partials + ((size_t)w * chunks + i) * G::PJ));
+    G::st(acc, out + ((size_t)w * nfold + f) * G::PJ);
 }
 #else
 ;
@@ -1350,7 +1407,10 @@ __attribute__((used)) static const void* const blsgpu_instances_msm[] = {
     (const void*)&k_msm_pip_horner<1>,
     (const void*)&k_msm_pip_horner<2>,
     (const void*)&k_lane_prep<1>,
-    (const void*)&k_srt_prep,
+    (const void*)&k_srt_prep<1>, (const void*)&k_srt_prep<2>,
+    (const void*)&k_srt_accum<1>, (const void*)&k_srt_accum<2>, (const void*)&k_srt_fix<1>, (const void*)&k_srt_fix<2>,
+    (const void*)&k_srt_fix_long<1>, (const void*)&k_srt_fix_long<2>, (const void*)&k_srt_bits<1>, (const void*)&k_srt_bits<2>,
+    (const void*)&k_srt_fold<1>, (const void*)&k_srt_fold<2>,
     (const void*)&k_lane_prep<2>,
     (const void*)&k_msm_lane<1>,
     (const void*)&k_msm_lane<2>,

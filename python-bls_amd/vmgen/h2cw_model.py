@@ -186,3 +186,24 @@ def clear(S0, S1, psix, psiy):
         else:
             m.step(w & 0x3f)
     return tuple((m.value("A" + c + "0"), m.value("A" + c + "1")) for c in "XYZ"), m.max_abs
+
+
+def horner(points, cbits):
+    """the window Horner of a G2 sum on the same tables (csrc/blsgpu_h2cw.hip k_msm_horner_wide2: the accumulator and slot point 0,
+    kinds DBL1 / DBL2 / ADD1_0p / ADD2): points = homogeneous ((x0, x1), (y0, y1), (z0, z1)), index 0 the lowest; returns
+    sum_i 2^(cbits i) points[i] (homogeneous) and the largest |stored value| / q"""
+    m = Machine(N, KINDS)
+
+    def put(base, P):
+        for c, v in zip(POINT, (P[0][0], P[0][1], P[1][0], P[1][1], P[2][0], P[2][1])):
+            m.store_value(base + c, v % Q)
+    put("A", points[-1])
+    for P in reversed(points[:-1]):
+        for _ in range(cbits):
+            m.step(KIND["DBL1"])
+            m.step(KIND["DBL2"])
+        put("S0", P)
+        m.step(KIND["ADD1_0p"])
+        m.step(KIND["ADD2"])
+    return tuple((m.value("A" + c + "0"), m.value("A" + c + "1")) for c in "XYZ"), m.max_abs
+

@@ -30,7 +30,7 @@ def either_engine(request, engine):
 @pytest.fixture(scope="module")
 def fixed_window_engine():
     """the default selection without the sorted buckets: the independent kernels a sorted-bucket result is compared with"""
-    return _engine_with_values({"BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40)})
+    return _engine_with_values({"BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40), "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40)})
 
 
 def test_scalar_multiples_of_generators(either_engine, golden):
@@ -133,6 +133,7 @@ def _engine_with(names):
     fixture's kernel family also serves the single G1 sums with scalars"""
     values = {k: "1" for k in names}
     values.setdefault("BLSGPU_MSM_SORT_THRESHOLD", str(1 << 40))
+    values.setdefault("BLSGPU_MSM_SORT2_THRESHOLD", str(1 << 40))
     return _engine_with_values(values)
 
 
@@ -304,7 +305,7 @@ def lane_np_engine():
     k_msm_pip_horner): what the lane path ran before the Horner on lane quads, kept under test as the unselected form."""
     return _engine_with_values({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_LANE_THRESHOLD": "1",
                                 "BLSGPU_HORNER_NP_THRESHOLD": "1", "BLSGPU_HORNER_QUADS_THRESHOLD": "1000000000",
-                                "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40)})
+                                "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40), "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40)})
 
 
 @pytest.mark.parametrize("k,groups", [(3, 2), (5, 4), (4, 16), (3, 17), (2, 33), (67, 7)])
@@ -522,3 +523,53 @@ def test_c5_full_size_distinct_points(engine, golden):
     got, _ = engine.g1_msm(pts, None, n, 1)
     want, _ = engine.g1_msm(gen1, [sum(a) % N_ORDER], 1, 1)
     assert got == want
+
+
+# ---- ONE G2 sum with scalars on the sorted buckets (round 5: BLS.aggregate_sigs(secure), bls.py:225-261, as a multi-scalar sum) ----
+@pytest.fixture(scope="module", params=["default_window_bits", "5_bit_windows", "11_bit_windows", "13_bit_windows"])
+def sorted_g2_engine(request):
+    """The default selection sends every single G2 sum with scalars to the sorted buckets (k_srt_*<2> on lane pairs, the tail on
+    k_msm_horner_wide2); the window width follows the size by default, the other rows pin it (every fold shape of the tail)."""
+    if request.param == "default_window_bits":
+        return _engine_with_values({})
+    return _engine_with_values({"BLSGPU_MSM_SORT2_BITS": request.param.split("_")[0]})
+
+
+def _neg_g2(P):
+    return P[:96] + b"".join(((Q - int.from_bytes(P[96 + 48 * j:144 + 48 * j], "big")) % Q).to_bytes(48, "big") for j in range(2))
+
+
+@pytest.mark.parametrize("k", [1, 2, 65, 700])
+def test_sorted_buckets_g2_vs_oracle(sorted_g2_engine, oracle, seeded_pairs, k):
+    """random, short, zero and extreme scalars, a point at infinity, a repeated point and a point with its negative in the same
+    buckets, against the oracle's double-and-add"""
+    _, g2 = seeded_pairs
+    rnd = random.Random(k * 29 + 3)
+    pts = bytearray((g2 * 2)[192 * 5:192 * (5 + k)])
+    sc = [rnd.choice([rnd.randrange(N), rnd.randrange(N), rnd.randrange(1 << 40), 0, N - 1, 1, (1 << 256) - 1]) for _ in range(k)]
+    if k >= 65:
+        pts[192 * 7:192 * 8] = bytes(192)                       # infinity in the list
+        pts[192 * 9:192 * 10] = pts[192 * 8:192 * 9]            # the same point twice ...
+        sc[9] = sc[8] = rnd.randrange(N)                        # ... in the same buckets (doubling inside the addition)
+        pts[192 * 12:192 * 13] = _neg_g2(bytes(pts[192 * 11:192 * 12]))
+        sc[12] = sc[11] = rnd.randrange(N)                      # P and -P in the same buckets
+    got, inf = sorted_g2_engine.g2_msm(bytes(pts), sc, k, 1)
+    want, _ = oracle.g2_msm(bytes(pts), sc, k)
+    assert got == want and inf[0] == (want == bytes(192))
+
+
+def test_sorted_buckets_g2_degenerate_and_long_runs(sorted_g2_engine, fixed_window_engine, golden, seeded_pairs):
+    P = bytes.fromhex(golden("points.json")["g2"][3]["p"])
+    assert sorted_g2_engine.g2_msm(P + _neg_g2(P), [5, 5], 2) == (bytes(192), [True])
+    assert sorted_g2_engine.g2_msm(P * 3, [0, 0, 0], 3) == (bytes(192), [True])
+    assert sorted_g2_engine.g2_msm(P + bytes(192), [7, 9], 2) == fixed_window_engine.g2_msm(P, [7], 1)
+    assert sorted_g2_engine.g2_msm(P * 40, [N - 1] * 40, 40) == fixed_window_engine.g2_msm(P, [(N - 1) * 40 % N], 1)
+    # ONE scalar for thousands of points: every window's list is a single run over many of the equal pieces (k_srt_fix_long<2>)
+    _, g2 = seeded_pairs
+    k = 3000
+    pts = (g2 * 3)[:192 * k]
+    plain, _ = fixed_window_engine.g2_msm(pts, None, k, 1)
+    for s in (0x1234567, N - 2):
+        want, _ = fixed_window_engine.g2_msm(plain, [s], 1, 1)
+        assert sorted_g2_engine.g2_msm(pts, [s] * k, k, 1) == (want, [False])
+

@@ -58,6 +58,38 @@ def test_infinity_and_opposite_encodings():
     assert _affine(R) == tuple(want)
 
 
+def test_window_horner_of_a_g2_sum_on_the_same_tables():
+    """csrc/blsgpu_h2cw.hip k_msm_horner_wide2 (the tail of the sorted-bucket G2 sum: bls.py:225-261 as one multi-scalar sum):
+    sum_i 2^(c i) P_i with infinity in the list, an addend equal to the running sum and one opposite to it"""
+    import random
+    rng = random.Random(5)
+    F = H.F2
+    G = tuple(H.hash_to_g2_prehashed(hashlib.sha256(b"g2-horner").digest(), hash512))
+    mul = lambda k: H.jac_to_affine(F, H.jac_mul(F, H.aff_to_jac(F, G), k))
+    P, S = mul(rng.randrange(1, H.N)), mul(rng.randrange(1, H.N))
+    two_p = H.jac_to_affine(F, H.jac_double(F, H.aff_to_jac(F, P)))
+    neg = lambda A: (A[0], H.f2_neg(A[1]))
+
+    def hom(A):
+        if A is None:
+            return ((0, 0), (1, 0), (0, 0))
+        z = (rng.randrange(1, H.Q), rng.randrange(H.Q))
+        return (H.f2_mul(A[0], z), H.f2_mul(A[1], z), z)
+
+    def want(pts, c):
+        acc = None
+        for i, A in enumerate(pts):
+            if A is not None:
+                t = H.jac_mul(F, H.aff_to_jac(F, A), 1 << (c * i))
+                acc = t if acc is None else H.jac_add(F, acc, t)
+        return None if acc is None else tuple(H.jac_to_affine(F, acc))
+    for pts, c in (([P, S, None, P], 3), ([two_p, P], 1), ([neg(two_p), P], 1), ([None, None], 2), ([S, neg(two_p), P], 1)):
+        R, mx = M.horner([hom(A) for A in pts], c)
+        assert mx < 1.02
+        got = _affine(R)
+        assert (None if got is None else tuple(got)) == want(pts, c), (pts, c)
+
+
 def test_generated_tables_are_current():
     from vmgen import gen_h2cw
     import tempfile

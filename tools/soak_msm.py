@@ -43,9 +43,11 @@ def main():
         "sorted8": engine_with({"BLSGPU_MSM_SORT_THRESHOLD": "1", "BLSGPU_MSM_SORT_BITS": "8"}),
         "sorted_vm_tail": engine_with({"BLSGPU_MSM_SORT_THRESHOLD": "1", "BLSGPU_MSM_WIDE_TAIL": "0"}),    # (round 5: the default tail is k_msm_horner_wide)
         "lane": engine_with({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_LANE_THRESHOLD": "1",
-                             "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40)}),
+                             "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40), "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40)}),
+        "sorted2_5": engine_with({"BLSGPU_MSM_SORT2_BITS": "5"}),                 # (round 5: ONE G2 sum with scalars on the sorted buckets, the default)
+        "sorted2_13": engine_with({"BLSGPU_MSM_SORT2_BITS": "13"}),
         "lds": engine_with({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40),
-                            "BLSGPU_HORNER_NP_THRESHOLD": "1"}),
+                            "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40), "BLSGPU_HORNER_NP_THRESHOLD": "1"}),
     }
     rng = random.Random(20261004)
     bad, t0 = 0, time.time()
@@ -87,7 +89,14 @@ def main():
         return sc
 
     for t in range(trials):
-        if t % 3 < 2:                                   # one G1 sum: every kernel family
+        if t % 4 == 3:                                  # one G2 sum with scalars: sorted buckets (default widths, 5 and 13 bits) and the fixed windows
+            k = rng.choice([1, 2, 3, 64, 65, 257, 700, 1500])
+            pts, sc = points(k, 2), scalars(k)
+            want, winf = O.g2_msm(pts, sc, k)
+            res = {nm: engines[nm].g2_msm(pts, sc, k, 1) for nm in ("default", "sorted2_5", "sorted2_13", "lane", "lds")}
+            ok = all(r[0] == want and r[1][0] == (want == bytes(192)) for r in res.values())
+            what = "G2 sum of %d" % k
+        elif t % 3 < 2:                                 # one G1 sum: every kernel family
             k = rng.choice([1, 2, 3, 64, 65, 257, 700, 1500, 3000, 5000])
             pts, sc = points(k, 1), scalars(k)
             want, winf = O.g1_msm(pts, sc, k)
