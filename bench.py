@@ -725,7 +725,46 @@ def secondary(env, args, eng, gen1, gen2):
             out[name].update(combine_ms=ln["combine_s"] * 1e3, verify_ms=ln["verify_s"] * 1e3)
     out["verify_pipeline"] = run_verify_pipeline(env, eng)
     out["verify_single_signature"] = run_verify_single(env, eng)
+    out["g2_sum"] = run_g2_sum(env, eng, gen2)
     return out
+
+
+def run_g2_sum(env, eng, gen2, n=16384):
+    """ONE G2 sum with scalars -- BLS.aggregate_sigs(secure) (bls.py:225-261) as a multi-scalar sum, SURVEY 8(f) rank 2 -- on
+    device-resident buffers: n different points a_i G2 with PRF scalars t_i through the default selection (sorted buckets on lane
+    pairs), checked by  sum t_i (a_i G2) == (sum t_i a_i) G2  with the right-hand side from an engine WITHOUT the
+    sorted buckets (the fixed-window kernels), which is also timed on the same input."""
+    torch = env.torch
+    from bls_py import _native
+    a = [prf_scalar(b"blsgpu/g2sum/a", 0, i) for i in range(n)]
+    t = [prf_scalar(b"blsgpu/g2sum/t", 0, i) for i in range(n)]
+    pts, _ = eng.g2_msm(gen2 * n, a, 1, n)
+    old = {k: os.environ.get(k) for k in ("BLSGPU_MSM_SORT2_THRESHOLD",)}
+    os.environ["BLSGPU_MSM_SORT2_THRESHOLD"] = str(1 << 40)
+    try:
+        fixed = _native.Engine(env.local_dev)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    want, _ = fixed.g2_msm(gen2, [sum(x * y for x, y in zip(a, t)) % N_ORDER], 1, 1)
+    dp, ds = env.up(pts), env.up(b"".join(x.to_bytes(32, "big") for x in t))
+    out = torch.zeros(192, dtype=torch.uint8, device=env.dev)
+    inf = torch.zeros(1, dtype=torch.uint8, device=env.dev)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for name, e in (("sorted", eng), ("fixed_windows", fixed)):
+        out.zero_()
+        dt = device_timed(env, lambda: e.lib.blsgpu_g2_msm_dev(e.h, dp.data_ptr(), ds.data_ptr(), n, 1, out.data_ptr(), inf.data_ptr(), st), 3)
+        if bytes(out.cpu().numpy()) != want:
+            raise SystemExit("g2_sum (%s): sum t_i (a_i G2) != (sum t_i a_i) G2 -- bench invalid" % name)
+        res[name] = dt
+    return {"value": n / res["sorted"], "unit": "points/s", "ms": res["sorted"] * 1e3, "fixed_window_kernels_ms": res["fixed_windows"] * 1e3,
+            "check": "sum t_i (a_i G2) == (sum t_i a_i) G2, right-hand side from the fixed-window kernels; both paths give it",
+            "workload": "ONE G2 multi-scalar sum of %d points with 256-bit scalars (aggregate_sigs(secure) as a multi-scalar sum): sorted buckets, "
+                        "13-bit windows of signed digits, a piece of the sorted list per lane pair, the tail one wavefront per chain" % n}
 
 
 def run_verify_single(env, eng):
