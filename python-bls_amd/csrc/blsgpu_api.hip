@@ -80,6 +80,7 @@ struct blsgpu_ctx {
     size_t h2c_ws_cap = 0;
     size_t msm_sort_threshold = 1;      // points from which one G1 sum with scalars uses sorted buckets (k_srt_*): since the tail runs on the wide machine (round 5) they win at every size -- 1 point 1.24 ms against 1.63, 8192 points 1.45 against 2.59 (profiles/r05_c5_window_bits.txt)
     size_t msm_sort2_threshold = 1;     // the same for ONE G2 sum with scalars (round 5: BLS.aggregate_sigs(secure) as a multi-scalar sum)
+    size_t msm_plain_threshold = 2;     // points from which ONE plain sum (no scalars) runs on the register kernels (k_sum_chunks + folds; round 5) instead of the wavefront VM's k_msm
     static uint32_t msm_sort2_bits(size_t n) { return n >= 16384 ? 13 : (n >= 512 ? 11 : 9); }   // window bits of the G2 path by size (tools/g2_single_sum_probe.py, profiles/r05_g2_single_sum.txt)
     size_t horner_np_threshold = 1024; // G2 sums per call from which the window Horner runs several sums per team
     size_t horner_quads_threshold = 2; // G2 sums per call (lane-pair bucket kernel) from which the window Horner runs one sum per lane quad
@@ -394,6 +395,49 @@ static int msm_sorted(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, s
     return 0;
 }
 
+// One plain sum of n points (no scalars) -- BLS.aggregate_pub_keys / aggregate_sigs without exponents (bls.py:203-261): a chunk of
+// the list per unit (k_sum_chunks: complete mixed additions in registers), then runs of eight partial sums until eight are left
+// (k_srt_fold, or one wavefront per run on the wide machine once at most 4096 runs are left), then the last run with the affine
+// conversion.  Enqueues on `st` and returns.
+template <int DEG>
+static int msm_plain(blsgpu_ctx* c, const void* d_pts, size_t n, void* d_out, void* d_out_inf, hipStream_t st) {
+    typedef blsgpu::SrtG<DEG> G;
+    const size_t units_max = blsgpu::SRT_LANES / G::LP;
+    size_t U = (n + 3) / 4;                                   // four points per unit while units are free (a small sum is a latency)
+    if (U > units_max) U = units_max;
+    const size_t chunk = (n + U - 1) / U;
+    U = (n + chunk - 1) / chunk;
+    size_t off = 0;
+    auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
+    const size_t PJ = G::PJ;
+    const size_t o_prep = take(n * blsgpu::L28_AFF * DEG), o_live = take((n + 3) / 4), o_b0 = take(U * PJ), o_b1 = take(((U + 7) / 8) * PJ + PJ);
+    if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, off)) return rc_;
+    uint32_t* W = c->d_buckets;
+    uint8_t* live = (uint8_t*)(W + o_live);
+    hipLaunchKernelGGL(blsgpu::k_lane_prep<DEG>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (uint32_t)n, W + o_prep, live);
+    const auto blocks = [&](size_t nunits) { return dim3((unsigned)((nunits * G::LP + 63) / 64)); };
+    hipLaunchKernelGGL(blsgpu::k_sum_chunks<DEG>, blocks(U), dim3(64), 0, st, W + o_prep, live, (uint32_t)n, (uint32_t)chunk, (uint32_t)U, W + o_b0);
+    HIP_TRY(hipGetLastError());
+    uint32_t *src = W + o_b0, *dst = W + o_b1;
+    size_t cur = U;
+    while (cur > 8) {
+        const size_t nfold = (cur + 7) / 8;
+        if (nfold <= 4096 && cur % 8 == 0) {
+            if (DEG == 1) hipLaunchKernelGGL(blsgpu::g1w::k_msm_horner_wide<0>, dim3((unsigned)nfold), dim3(64), 0, st, src, 8u, 0u, dst, (uint8_t*)nullptr);
+            else hipLaunchKernelGGL(blsgpu::h2cw::k_msm_horner_wide2<0>, dim3((unsigned)nfold), dim3(64), 0, st, src, 8u, 0u, dst, (uint8_t*)nullptr);
+        } else {
+            hipLaunchKernelGGL(blsgpu::k_srt_fold<DEG>, blocks(nfold), dim3(64), 0, st, src, (uint32_t)cur, 8u, (uint32_t)nfold, (uint32_t)nfold, dst);
+        }
+        HIP_TRY(hipGetLastError());
+        uint32_t* t = src; src = dst; dst = t;
+        cur = nfold;
+    }
+    if (DEG == 1) hipLaunchKernelGGL(blsgpu::g1w::k_msm_horner_wide<1>, dim3(1), dim3(64), 0, st, src, (uint32_t)cur, 0u, (uint32_t*)d_out, (uint8_t*)d_out_inf);
+    else hipLaunchKernelGGL(blsgpu::h2cw::k_msm_horner_wide2<1>, dim3(1), dim3(64), 0, st, src, (uint32_t)cur, 0u, (uint32_t*)d_out, (uint8_t*)d_out_inf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int DEG>
 int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, size_t groups, void* d_out,
             void* d_out_inf, hipStream_t st) {
@@ -406,6 +450,7 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
         return 0;
     }
     if (k > 0x7FFFFFFFull || groups > 0x7FFFFFFFull || k * groups > 0xFFFFFFF0ull) return fail(-EINVAL, "msm too large");
+    if (groups == 1 && !d_scalars && k >= c->msm_plain_threshold) return msm_plain<DEG>(c, d_pts, k, d_out, d_out_inf, st);
     if (groups == 1 && d_scalars && k >= (DEG == 1 ? c->msm_sort_threshold : c->msm_sort2_threshold)) {
         const int rc_ = msm_sorted<DEG>(c, d_pts, d_scalars, k, d_out, d_out_inf, st);
         if (rc_ != 1) return rc_;
@@ -592,6 +637,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_H2C_LANE_THRESHOLD")) c->h2c_lane_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT2_THRESHOLD")) c->msm_sort2_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_MSM_PLAIN_THRESHOLD")) c->msm_plain_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_NP_THRESHOLD")) c->horner_np_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_QUADS_THRESHOLD")) c->horner_quads_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_WG256_MAX_WAVES")) c->wg256_max_waves = (size_t)strtoull(e, nullptr, 10);

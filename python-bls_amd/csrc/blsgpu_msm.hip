@@ -1366,6 +1366,29 @@ __global__ void __launch_bounds__(64) k_srt_fold(const uint32_t* __restrict__ pa
 ;
 #endif
 
+// ---- plain sums of many points (no scalars): BLS.aggregate_pub_keys / aggregate_sigs without exponents (bls.py:203-261) --------
+// unit u (a lane; a lane pair for G2) adds the live points [u chunk, (u + 1) chunk) of the prepared list (k_lane_prep: x, y in the
+// L28 form) with complete mixed additions -> out[u]; the partial sums are folded by k_srt_fold / the wide machine (blsgpu_api.hip
+// msm_plain).  The wavefront VM's k_msm served these sums until round 5 at 50 M (G1) / 28 M (G2) points/s.
+template <int DEG>
+__global__ void __launch_bounds__(64, 2) k_sum_chunks(const uint32_t* __restrict__ prep, const uint8_t* __restrict__ live, uint32_t n, uint32_t chunk,
+                                                      uint32_t nunits, uint32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
+    typedef SrtG<DEG> G;
+    const uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) / G::LP;
+    if (u >= nunits) return;
+    const uint32_t lo = u * chunk, hi = min(n, lo + chunk);
+    typename G::P acc = G::inf();
+#pragma unroll 1
+    for (uint32_t i = lo; i < hi; i++)
+        if (live[i]) G::madd(acc, prep + (size_t)i * L28_AFF * DEG, 0u);          // (x, y) adjacent: the prepared point of the sorted buckets without its -y
+    G::st(acc, out + (size_t)u * G::PJ);
+}
+#else
+;
+#endif
+
 // W_w = sum_b 2^b S_(w,b): one team per window, Horner over the bits
 __global__ void __launch_bounds__(64) k_srt_windows(VmTables T, const uint32_t* __restrict__ bitsums, uint32_t cb, uint32_t* __restrict__ winsums)
 #if BLSGPU_EMIT(BLSGPU_TU_MSM)
@@ -1410,7 +1433,7 @@ __attribute__((used)) static const void* const blsgpu_instances_msm[] = {
     (const void*)&k_srt_prep<1>, (const void*)&k_srt_prep<2>,
     (const void*)&k_srt_accum<1>, (const void*)&k_srt_accum<2>, (const void*)&k_srt_fix<1>, (const void*)&k_srt_fix<2>,
     (const void*)&k_srt_fix_long<1>, (const void*)&k_srt_fix_long<2>, (const void*)&k_srt_bits<1>, (const void*)&k_srt_bits<2>,
-    (const void*)&k_srt_fold<1>, (const void*)&k_srt_fold<2>,
+    (const void*)&k_srt_fold<1>, (const void*)&k_srt_fold<2>, (const void*)&k_sum_chunks<1>, (const void*)&k_sum_chunks<2>,
     (const void*)&k_lane_prep<2>,
     (const void*)&k_msm_lane<1>,
     (const void*)&k_msm_lane<2>,

@@ -30,7 +30,8 @@ def either_engine(request, engine):
 @pytest.fixture(scope="module")
 def fixed_window_engine():
     """the default selection without the sorted buckets: the independent kernels a sorted-bucket result is compared with"""
-    return _engine_with_values({"BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40), "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40)})
+    return _engine_with_values({"BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40), "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40),
+                                "BLSGPU_MSM_PLAIN_THRESHOLD": str(1 << 40)})
 
 
 def test_scalar_multiples_of_generators(either_engine, golden):
@@ -134,6 +135,7 @@ def _engine_with(names):
     values = {k: "1" for k in names}
     values.setdefault("BLSGPU_MSM_SORT_THRESHOLD", str(1 << 40))
     values.setdefault("BLSGPU_MSM_SORT2_THRESHOLD", str(1 << 40))
+    values.setdefault("BLSGPU_MSM_PLAIN_THRESHOLD", str(1 << 40))
     return _engine_with_values(values)
 
 
@@ -572,4 +574,42 @@ def test_sorted_buckets_g2_degenerate_and_long_runs(sorted_g2_engine, fixed_wind
     for s in (0x1234567, N - 2):
         want, _ = fixed_window_engine.g2_msm(plain, [s], 1, 1)
         assert sorted_g2_engine.g2_msm(pts, [s] * k, k, 1) == (want, [False])
+
+
+# ---- ONE plain sum of many points (no scalars) on the register kernels (round 5: k_sum_chunks + folds + the wide machine's tail) ----
+@pytest.mark.parametrize("deg", [1, 2])
+@pytest.mark.parametrize("k", [2, 3, 9, 33, 64, 65, 700, 5000, 40000])
+def test_plain_sums_vs_oracle(engine, fixed_window_engine, oracle, seeded_pairs, k, deg):
+    """BLS.aggregate_pub_keys / aggregate_sigs without exponents (bls.py:203-261) as one sum: points at infinity in the list, a
+    point twice in a row (a doubling inside the mixed addition), a point followed by its negative, ragged chunk and fold counts;
+    against the oracle and against the wavefront VM's k_msm (the engine without the register path)."""
+    src, sz = (seeded_pairs[0], 96) if deg == 1 else (seeded_pairs[1], 192)
+    npts = len(src) // sz
+    rnd = random.Random(k * 7 + deg)
+    pts = bytearray(b"".join(src[sz * (i % npts):sz * (i % npts + 1)] for i in (rnd.randrange(npts) for _ in range(k))))
+    if k >= 9:
+        pts[sz * 2:sz * 3] = bytes(sz)                               # infinity
+        pts[sz * 4:sz * 5] = pts[sz * 3:sz * 4]                      # the same point twice in one chunk
+        P = bytes(pts[sz * 6:sz * 7])
+        h = 48 * deg
+        pts[sz * 7:sz * 8] = P[:h] + b"".join(((Q - int.from_bytes(P[h + 48 * j:h + 48 * j + 48], "big")) % Q).to_bytes(48, "big") for j in range(deg))
+    pts = bytes(pts)
+    f = (lambda e: e.g1_msm(pts, None, k, 1)) if deg == 1 else (lambda e: e.g2_msm(pts, None, k, 1))
+    got = f(engine)
+    assert got == f(fixed_window_engine)
+    if k <= 5000:
+        want, _ = (oracle.g1_msm if deg == 1 else oracle.g2_msm)(pts, None, k)
+        assert got == (want, [want == bytes(sz)])
+
+
+def test_plain_sums_that_are_infinity(engine, golden):
+    p = golden("points.json")
+    for deg, key in ((1, "g1"), (2, "g2")):
+        sz, h = 96 * deg, 48 * deg
+        P = bytes.fromhex(p[key][3]["p"])
+        negP = P[:h] + b"".join(((Q - int.from_bytes(P[h + 48 * j:h + 48 * j + 48], "big")) % Q).to_bytes(48, "big") for j in range(deg))
+        f = engine.g1_msm if deg == 1 else engine.g2_msm
+        assert f((P + negP) * 40, None, 80, 1) == (bytes(sz), [True])
+        assert f(bytes(sz) * 100, None, 100, 1) == (bytes(sz), [True])
+        assert f(bytes(sz) * 99 + P, None, 100, 1) == (P, [False])
 

@@ -43,7 +43,8 @@ def main():
         "sorted8": engine_with({"BLSGPU_MSM_SORT_THRESHOLD": "1", "BLSGPU_MSM_SORT_BITS": "8"}),
         "sorted_vm_tail": engine_with({"BLSGPU_MSM_SORT_THRESHOLD": "1", "BLSGPU_MSM_WIDE_TAIL": "0"}),    # (round 5: the default tail is k_msm_horner_wide)
         "lane": engine_with({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_LANE_THRESHOLD": "1",
-                             "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40), "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40)}),
+                             "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40), "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40),
+                             "BLSGPU_MSM_PLAIN_THRESHOLD": str(1 << 40)}),
         "sorted2_5": engine_with({"BLSGPU_MSM_SORT2_BITS": "5"}),                 # (round 5: ONE G2 sum with scalars on the sorted buckets, the default)
         "sorted2_13": engine_with({"BLSGPU_MSM_SORT2_BITS": "13"}),
         "lds": engine_with({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40),
@@ -89,7 +90,15 @@ def main():
         return sc
 
     for t in range(trials):
-        if t % 4 == 3:                                  # one G2 sum with scalars: sorted buckets (default widths, 5 and 13 bits) and the fixed windows
+        if t % 5 == 4:                                  # one PLAIN sum (no scalars): the register kernels (default) and the wavefront VM's k_msm
+            deg = rng.choice([1, 2])
+            k = rng.choice([2, 3, 5, 9, 64, 65, 257, 700, 1500, 4000])
+            pts = points(k, deg)
+            want, winf = (O.g1_msm if deg == 1 else O.g2_msm)(pts, None, k)
+            res = [(e.g1_msm if deg == 1 else e.g2_msm)(pts, None, k, 1) for e in (engines["default"], engines["lane"])]
+            ok = all(r[0] == want and r[1][0] == (want == bytes(96 * deg)) for r in res)
+            what = "plain G%d sum of %d" % (deg, k)
+        elif t % 4 == 3:                                # one G2 sum with scalars: sorted buckets (default widths, 5 and 13 bits) and the fixed windows
             k = rng.choice([1, 2, 3, 64, 65, 257, 700, 1500])
             pts, sc = points(k, 2), scalars(k)
             want, winf = O.g2_msm(pts, sc, k)
