@@ -81,6 +81,8 @@ struct blsgpu_ctx {
     size_t msm_sort_threshold = 1;      // points from which one G1 sum with scalars uses sorted buckets (k_srt_*): since the tail runs on the wide machine (round 5) they win at every size -- 1 point 1.24 ms against 1.63, 8192 points 1.45 against 2.59 (profiles/r05_c5_window_bits.txt)
     size_t msm_sort2_threshold = 1;     // the same for ONE G2 sum with scalars (round 5: BLS.aggregate_sigs(secure) as a multi-scalar sum)
     size_t msm_plain_threshold = 2;     // points from which ONE plain sum (no scalars) runs on the register kernels (k_sum_chunks + folds; round 5) instead of the wavefront VM's k_msm
+    size_t smul_min_groups = 4096;      // sums per call from which a batch of SMALL sums with scalars (scalar multiplications: groups x 1 point) runs one group per lane / lane pair (k_smul, round 5) instead of the wavefront VM's k_msm
+    size_t smul_max_k = 8;              // ... for sums of up to this many points
     static uint32_t msm_sort2_bits(size_t n) { return n >= 16384 ? 13 : (n >= 512 ? 11 : 9); }   // window bits of the G2 path by size (tools/g2_single_sum_probe.py, profiles/r05_g2_single_sum.txt)
     size_t horner_np_threshold = 1024; // G2 sums per call from which the window Horner runs several sums per team
     size_t horner_quads_threshold = 2; // G2 sums per call (lane-pair bucket kernel) from which the window Horner runs one sum per lane quad
@@ -438,6 +440,24 @@ static int msm_plain(blsgpu_ctx* c, const void* d_pts, size_t n, void* d_out, vo
     return 0;
 }
 
+// A batch of scalar multiplications / of small sums with scalars: one group per unit (k_smul).  Enqueues on `st` and returns.
+template <int DEG>
+static int msm_small_groups(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, size_t groups, void* d_out, void* d_out_inf, hipStream_t st) {
+    typedef blsgpu::SrtG<DEG> G;
+    const size_t n = k * groups, upw = 64 / G::LP, units = (groups + upw - 1) / upw * upw;          // whole wavefronts of units
+    size_t off = 0;
+    auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
+    const size_t o_prep = take(n * blsgpu::L28_AFF * DEG), o_live = take((n + 3) / 4), o_tab = take(units * k * blsgpu::SMUL_T * G::PJ);
+    if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, off)) return rc_;
+    uint32_t* W = c->d_buckets;
+    uint8_t* live = (uint8_t*)(W + o_live);
+    hipLaunchKernelGGL(blsgpu::k_lane_prep<DEG>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (uint32_t)n, W + o_prep, live);
+    hipLaunchKernelGGL(blsgpu::k_smul<DEG>, dim3((unsigned)(units * G::LP / 64)), dim3(64), 0, st, W + o_prep, live, (const uint32_t*)d_scalars, (uint32_t)k,
+                       (uint32_t)groups, W + o_tab, (uint32_t*)d_out, (uint8_t*)d_out_inf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int DEG>
 int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, size_t groups, void* d_out,
             void* d_out_inf, hipStream_t st) {
@@ -451,6 +471,7 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
     }
     if (k > 0x7FFFFFFFull || groups > 0x7FFFFFFFull || k * groups > 0xFFFFFFF0ull) return fail(-EINVAL, "msm too large");
     if (groups == 1 && !d_scalars && k >= c->msm_plain_threshold) return msm_plain<DEG>(c, d_pts, k, d_out, d_out_inf, st);
+    if (d_scalars && groups >= c->smul_min_groups && k <= c->smul_max_k) return msm_small_groups<DEG>(c, d_pts, d_scalars, k, groups, d_out, d_out_inf, st);
     if (groups == 1 && d_scalars && k >= (DEG == 1 ? c->msm_sort_threshold : c->msm_sort2_threshold)) {
         const int rc_ = msm_sorted<DEG>(c, d_pts, d_scalars, k, d_out, d_out_inf, st);
         if (rc_ != 1) return rc_;
@@ -638,6 +659,8 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT2_THRESHOLD")) c->msm_sort2_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_PLAIN_THRESHOLD")) c->msm_plain_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_SMUL_MIN_GROUPS")) c->smul_min_groups = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_SMUL_MAX_K")) c->smul_max_k = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_NP_THRESHOLD")) c->horner_np_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_HORNER_QUADS_THRESHOLD")) c->horner_quads_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_WG256_MAX_WAVES")) c->wg256_max_waves = (size_t)strtoull(e, nullptr, 10);

@@ -1031,6 +1031,27 @@ template <> struct SrtG<1> {
 #pragma unroll
         for (int q = 0; q < r28::NL; q++) { o.X.v[q] = __shfl_xor(a.X.v[q], off); o.Y.v[q] = __shfl_xor(a.Y.v[q], off); o.Z.v[q] = __shfl_xor(a.Z.v[q], off); }
     }
+    static __device__ __forceinline__ P dbl(const P& a) { return r28::pdbl(a); }
+    // (X, Y) / Z as 96 canonical big-endian bytes, (0, 0) and the flag for Z = 0 (one safegcd inversion per lane)
+    static __device__ __forceinline__ void affine_out(const P& a, uint32_t* __restrict__ out, uint8_t* __restrict__ inf, bool store) {
+        uint32_t zv[12], ziv[12];
+        r28::to_vm(zv, a.Z);
+        bls::fq_inv(ziv, zv);
+        const r28::fe zi = r28::from_vm(ziv);
+        const r28::fe c[2] = {r28::mul(a.X, zi), r28::mul(a.Y, zi)};
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            uint32_t y[12];
+            r28::to_raw(y, c[k]);
+#pragma unroll
+            for (int w = 0; w < 12; w++) {
+                any |= y[w];
+                if (store) out[k * 12 + w] = bswap32(y[11 - w]);
+            }
+        }
+        if (inf && store) *inf = any ? 0 : 1;
+    }
 };
 template <> struct SrtG<2> {
     typedef sp2::pt P;
@@ -1046,6 +1067,42 @@ template <> struct SrtG<2> {
     static __device__ __forceinline__ void xor_lanes(P& o, const P& a, int off) {              // the same part of the pair `off` pairs away
 #pragma unroll
         for (int q = 0; q < r28::NL; q++) { o.X.v[q] = __shfl_xor(a.X.v[q], 2 * off); o.Y.v[q] = __shfl_xor(a.Y.v[q], 2 * off); o.Z.v[q] = __shfl_xor(a.Z.v[q], 2 * off); }
+    }
+    static __device__ __forceinline__ P dbl(const P& a) { return sp2::pdbl(a); }
+    // (X, Y) / Z with 1 / Z = conj(Z) / N(Z) as 192 canonical big-endian bytes (x.c0, x.c1, y.c0, y.c1; each lane of the pair its
+    // parts), (0, 0) and the flag for Z = 0 -- the tail of k_msm_horner_quads on a lane pair
+    static __device__ __forceinline__ void affine_out(const P& a, uint32_t* __restrict__ out, uint8_t* __restrict__ inf, bool store) {
+        using namespace sp2;
+        const uint32_t part = odd() ? 1u : 0u;
+        const h zp = swp(a.Z);
+        r28::fe n;
+        bls28::fp28_dot2(n.v, a.Z.v, a.Z.v, zp.v, zp.v);
+        uint32_t nv[12], niv[12];
+        r28::to_vm(nv, n);
+        bls::fq_inv(niv, nv);
+        const r28::fe ninv = r28::from_vm(niv);
+        S<1> zc;
+#pragma unroll
+        for (int j = 0; j < r28::NL; j++) zc.v[j] = part ? -a.Z.v[j] : a.Z.v[j];
+        const h zi = mulf(zc, ninv);
+        const Rop<1> rzi = right(zi);
+        const h xa = mul(left(a.X), rzi), ya = mul(left(a.Y), rzi);
+        const h* o[2] = {&xa, &ya};
+        uint32_t any = 0;
+        for (int k = 0; k < 2; k++) {
+            r28::fe t;
+#pragma unroll
+            for (int j = 0; j < r28::NL; j++) t.v[j] = o[k]->v[j];
+            uint32_t y[12];
+            r28::to_raw(y, t);
+#pragma unroll
+            for (int w = 0; w < 12; w++) {
+                any |= y[w];
+                if (store) out[(2 * k + part) * 12 + w] = bswap32(y[11 - w]);
+            }
+        }
+        any |= (uint32_t)__shfl_xor((int)any, 1);
+        if (inf && store && part == 0u) *inf = any ? 0 : 1;
     }
 };
 
@@ -1389,6 +1446,58 @@ __global__ void __launch_bounds__(64, 2) k_sum_chunks(const uint32_t* __restrict
 ;
 #endif
 
+// ---- batches of scalar multiplications and of SMALL sums with scalars (round 5) -------------------------------------------------------
+// groups x k points with k of a few (key generation, sk H(m) for many messages, pk_i e_i per message in BLS.verify's
+// secure aggregation, bls.py:177-192) ran the wavefront VM's double-and-add at 0.58 M (G1) / 0.48 M (G2) scalar multiplications a
+// second whatever the count.  Here ONE GROUP PER UNIT (a lane; a lane pair for G2): fixed 4-bit windows from the top, the multiples
+// 0 .. 15 of each of the group's points in a table of the unit's own in HBM (fifteen mixed additions; entry 0 is infinity, so the
+// loop has no branch on a digit), 63 x 4 doublings and 64 k complete additions in registers, then the affine conversion with the
+// lane's own inversion.  Same value as the reference's double-and-add (fields_t.py:705-740; scalars are taken as the 256-bit
+// integers they are).  Spare units of the last wavefront repeat the last group and write nothing.
+constexpr uint32_t SMUL_T = 16;
+template <int DEG>
+__global__ void __launch_bounds__(64, 2) k_smul(const uint32_t* __restrict__ prep, const uint8_t* __restrict__ live, const uint32_t* __restrict__ scalars,
+                                                uint32_t k, uint32_t groups, uint32_t* __restrict__ table, uint32_t* __restrict__ out,
+                                                uint8_t* __restrict__ out_inf)
+#if BLSGPU_EMIT(BLSGPU_TU_MSM)
+{
+    typedef SrtG<DEG> G;
+    const uint32_t unit = (blockIdx.x * blockDim.x + threadIdx.x) / G::LP;
+    const bool real = unit < groups;
+    const uint32_t g = real ? unit : groups - 1u;
+    uint32_t* T = table + (size_t)unit * k * SMUL_T * G::PJ;
+#pragma unroll 1
+    for (uint32_t i = 0; i < k; i++) {
+        const size_t pi = (size_t)g * k + i;
+        const bool lv = live[pi] != 0;
+        typename G::P m = G::inf();
+        G::st(m, T + (size_t)i * SMUL_T * G::PJ);
+#pragma unroll 1
+        for (uint32_t d = 1; d < SMUL_T; d++) {
+            if (lv) G::madd(m, prep + pi * L28_AFF * DEG, 0u);
+            G::st(m, T + ((size_t)i * SMUL_T + d) * G::PJ);
+        }
+    }
+    typename G::P acc = G::inf();
+#pragma unroll 1
+    for (int w = 63; w >= 0; w--) {
+        if (w != 63) {
+#pragma unroll 1
+            for (int t = 0; t < 4; t++) acc = G::dbl(acc);
+        }
+#pragma unroll 1
+        for (uint32_t i = 0; i < k; i++) {
+            const uint32_t word = bswap32(scalars[((size_t)g * k + i) * 8 + 7u - ((uint32_t)w >> 3)]);
+            const uint32_t d = (word >> (((uint32_t)w & 7u) * 4u)) & 15u;
+            acc = G::add(acc, G::ld(T + ((size_t)i * SMUL_T + d) * G::PJ));
+        }
+    }
+    G::affine_out(acc, out + (size_t)g * 24 * DEG, out_inf ? out_inf + g : nullptr, real);
+}
+#else
+;
+#endif
+
 // W_w = sum_b 2^b S_(w,b): one team per window, Horner over the bits
 __global__ void __launch_bounds__(64) k_srt_windows(VmTables T, const uint32_t* __restrict__ bitsums, uint32_t cb, uint32_t* __restrict__ winsums)
 #if BLSGPU_EMIT(BLSGPU_TU_MSM)
@@ -1433,7 +1542,7 @@ __attribute__((used)) static const void* const blsgpu_instances_msm[] = {
     (const void*)&k_srt_prep<1>, (const void*)&k_srt_prep<2>,
     (const void*)&k_srt_accum<1>, (const void*)&k_srt_accum<2>, (const void*)&k_srt_fix<1>, (const void*)&k_srt_fix<2>,
     (const void*)&k_srt_fix_long<1>, (const void*)&k_srt_fix_long<2>, (const void*)&k_srt_bits<1>, (const void*)&k_srt_bits<2>,
-    (const void*)&k_srt_fold<1>, (const void*)&k_srt_fold<2>, (const void*)&k_sum_chunks<1>, (const void*)&k_sum_chunks<2>,
+    (const void*)&k_srt_fold<1>, (const void*)&k_srt_fold<2>, (const void*)&k_sum_chunks<1>, (const void*)&k_sum_chunks<2>, (const void*)&k_smul<1>, (const void*)&k_smul<2>,
     (const void*)&k_lane_prep<2>,
     (const void*)&k_msm_lane<1>,
     (const void*)&k_msm_lane<2>,

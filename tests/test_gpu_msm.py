@@ -31,7 +31,7 @@ def either_engine(request, engine):
 def fixed_window_engine():
     """the default selection without the sorted buckets: the independent kernels a sorted-bucket result is compared with"""
     return _engine_with_values({"BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40), "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40),
-                                "BLSGPU_MSM_PLAIN_THRESHOLD": str(1 << 40)})
+                                "BLSGPU_MSM_PLAIN_THRESHOLD": str(1 << 40), "BLSGPU_SMUL_MIN_GROUPS": str(1 << 40)})
 
 
 def test_scalar_multiples_of_generators(either_engine, golden):
@@ -136,6 +136,7 @@ def _engine_with(names):
     values.setdefault("BLSGPU_MSM_SORT_THRESHOLD", str(1 << 40))
     values.setdefault("BLSGPU_MSM_SORT2_THRESHOLD", str(1 << 40))
     values.setdefault("BLSGPU_MSM_PLAIN_THRESHOLD", str(1 << 40))
+    values.setdefault("BLSGPU_SMUL_MIN_GROUPS", str(1 << 40))
     return _engine_with_values(values)
 
 
@@ -612,4 +613,43 @@ def test_plain_sums_that_are_infinity(engine, golden):
         assert f((P + negP) * 40, None, 80, 1) == (bytes(sz), [True])
         assert f(bytes(sz) * 100, None, 100, 1) == (bytes(sz), [True])
         assert f(bytes(sz) * 99 + P, None, 100, 1) == (P, [False])
+
+
+# ---- batches of scalar multiplications / of small sums with scalars: one group per lane or lane pair (k_smul, round 5) ----
+@pytest.fixture(scope="module")
+def smul_engine():
+    """k_smul from one group on (the default takes it from 4096 groups of at most 8 points)"""
+    return _engine_with_values({"BLSGPU_SMUL_MIN_GROUPS": "1"})
+
+
+@pytest.mark.parametrize("deg", [1, 2])
+@pytest.mark.parametrize("k,groups", [(1, 1), (1, 70), (3, 33), (8, 5), (1, 5000), (2, 4100)])
+def test_batches_of_small_sums_with_scalars(smul_engine, engine, fixed_window_engine, oracle, seeded_pairs, k, groups, deg):
+    """key generation, sk H(m) for many messages, pk_i e_i per message (bls.py:177-192): random, short, zero and extreme scalars
+    (2^256 - 1 is taken as the integer it is, fields_t.py:705-740), points at infinity, a sum of P and -P with equal scalars, ragged
+    last wavefronts -- against the oracle (the first groups) and against the wavefront VM's double-and-add (all of them); the last
+    two rows also through the default selection."""
+    src, sz = (seeded_pairs[0], 96) if deg == 1 else (seeded_pairs[1], 192)
+    npts = len(src) // sz
+    rnd = random.Random(k * 1000 + groups + deg)
+    n = k * groups
+    pts = bytearray(b"".join(src[sz * j:sz * (j + 1)] for j in (rnd.randrange(npts) for _ in range(n))))
+    sc = [rnd.choice([rnd.randrange(N), rnd.randrange(N), rnd.randrange(1 << 40), 0, N - 1, 1, (1 << 256) - 1, 1 << 255, 15, 16]) for _ in range(n)]
+    if n >= 40:
+        pts[sz * 5:sz * 6] = bytes(sz)                                   # infinity
+    if k >= 2 and groups >= 3:                                          # group 2: P, -P with one scalar -> infinity (when k = 2)
+        P = bytes(pts[sz * 2 * k:sz * (2 * k + 1)])
+        h = 48 * deg
+        pts[sz * (2 * k + 1):sz * (2 * k + 2)] = P[:h] + b"".join(((Q - int.from_bytes(P[h + 48 * j:h + 48 * j + 48], "big")) % Q).to_bytes(48, "big") for j in range(deg))
+        sc[2 * k + 1] = sc[2 * k] = rnd.randrange(N)
+    pts = bytes(pts)
+    f = (lambda e: e.g1_msm(pts, sc, k, groups)) if deg == 1 else (lambda e: e.g2_msm(pts, sc, k, groups))
+    got, inf = f(smul_engine)
+    assert (got, inf) == f(fixed_window_engine)
+    if groups >= 4096:
+        assert (got, inf) == f(engine)
+    om = oracle.g1_msm if deg == 1 else oracle.g2_msm
+    for g in range(min(groups, 12)):
+        want, _ = om(pts[sz * k * g:sz * k * (g + 1)], sc[k * g:k * (g + 1)], k)
+        assert got[sz * g:sz * (g + 1)] == want and inf[g] == (want == bytes(sz)), g
 

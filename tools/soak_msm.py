@@ -44,9 +44,10 @@ def main():
         "sorted_vm_tail": engine_with({"BLSGPU_MSM_SORT_THRESHOLD": "1", "BLSGPU_MSM_WIDE_TAIL": "0"}),    # (round 5: the default tail is k_msm_horner_wide)
         "lane": engine_with({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_LANE_THRESHOLD": "1",
                              "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40), "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40),
-                             "BLSGPU_MSM_PLAIN_THRESHOLD": str(1 << 40)}),
+                             "BLSGPU_MSM_PLAIN_THRESHOLD": str(1 << 40), "BLSGPU_SMUL_MIN_GROUPS": str(1 << 40)}),
         "sorted2_5": engine_with({"BLSGPU_MSM_SORT2_BITS": "5"}),                 # (round 5: ONE G2 sum with scalars on the sorted buckets, the default)
         "sorted2_13": engine_with({"BLSGPU_MSM_SORT2_BITS": "13"}),
+        "smul": engine_with({"BLSGPU_SMUL_MIN_GROUPS": "1"}),                     # (round 5: batches of small sums with scalars, one group per lane / lane pair)
         "lds": engine_with({"BLSGPU_PIP_THRESHOLD": "1", "BLSGPU_PIP_GROUP_THRESHOLD": "1", "BLSGPU_MSM_SORT_THRESHOLD": str(1 << 40),
                             "BLSGPU_MSM_SORT2_THRESHOLD": str(1 << 40), "BLSGPU_HORNER_NP_THRESHOLD": "1"}),
     }
@@ -90,7 +91,20 @@ def main():
         return sc
 
     for t in range(trials):
-        if t % 5 == 4:                                  # one PLAIN sum (no scalars): the register kernels (default) and the wavefront VM's k_msm
+        if t % 7 == 6:                                  # a batch of small sums with scalars: k_smul against the wavefront VM's double-and-add and the oracle
+            deg = rng.choice([1, 2])
+            k, groups = rng.choice([(1, 1), (1, 33), (1, 200), (2, 65), (3, 20), (8, 9)])
+            n = k * groups
+            pts, sc = points(n, deg), scalars(n)
+            sz = 96 * deg
+            om = O.g1_msm if deg == 1 else O.g2_msm
+            want = [om(pts[sz * k * g:sz * k * (g + 1)], sc[k * g:k * (g + 1)], k)[0] for g in range(groups)]
+            ok = True
+            for nm in ("smul", "lane"):
+                out, inf = (engines[nm].g1_msm if deg == 1 else engines[nm].g2_msm)(pts, sc, k, groups)
+                ok = ok and all(out[sz * g:sz * (g + 1)] == want[g] and inf[g] == (want[g] == bytes(sz)) for g in range(groups))
+            what = "%d G%d sums of %d with scalars" % (groups, deg, k)
+        elif t % 5 == 4:                                # one PLAIN sum (no scalars): the register kernels (default) and the wavefront VM's k_msm
             deg = rng.choice([1, 2])
             k = rng.choice([2, 3, 5, 9, 64, 65, 257, 700, 1500, 4000])
             pts = points(k, deg)
