@@ -104,6 +104,7 @@ struct blsgpu_ctx {
     void* d_bad = nullptr;             // one byte per pair: left to the slow program
     size_t bad_cap = 0;
     bool vm_exact_lanes = true;        // degenerate blocks of the VM kernels through the lane kernels (k_ml_lines_exact / k_ml_small) instead of k_miller_slow
+    bool miller_exact_lanes = true;    // blsgpu_miller_loop_batch (one exact Fq12 per pair) on the lane kernels (k_ml_lines_exact + k_ml_small, round 5) instead of the VM's k_miller_exact
     size_t ls_merge_wide_max = 16384;  // merge levels with at most this many outputs run one wavefront per output
     size_t ls_wide_max = 5120;         // calls of at most this many pairs run the point chains sixteen lanes per pair with the values in LDS (k_ml_lines_wide, blsgpu_lsw.hip); 0: never
     size_t ls_quad_max = 20480;        // calls of at most this many pairs run the point chains on lane QUADS (k_ml_lines4: 0.6 of the depth while lane pairs leave SIMDs empty)
@@ -658,6 +659,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_H2C_LANE_THRESHOLD")) c->h2c_lane_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT2_THRESHOLD")) c->msm_sort2_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("BLSGPU_MILLER_EXACT_LANES")) c->miller_exact_lanes = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_MSM_PLAIN_THRESHOLD")) c->msm_plain_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_SMUL_MIN_GROUPS")) c->smul_min_groups = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_SMUL_MAX_K")) c->smul_max_k = (size_t)strtoull(e, nullptr, 10);
@@ -1368,6 +1370,35 @@ BLSGPU_EXPORT int blsgpu_miller_loop_batch_dev(blsgpu_ctx* c, const void* d_g1, 
     if (n > 0x7FFFFFF0ull) return fail(-EINVAL, "n too large");
     HIP_TRY(hipSetDevice(c->device));
     StreamGuard sg(c, (hipStream_t)stream);
+    if (c->miller_exact_lanes) {
+        // Round 5: the lane kernels instead of the VM's reference-faithful program (one pair per wavefront, 68 lane-serial inversions:
+        // 7 ms for one pair, 158 k pairs/s): every pair on the work list, k_ml_lines_exact writes its 68 lines with the reference's
+        // own formulas (a pair per lane pair), k_ml_small multiplies them up with one six-lane accumulator per pair, in slices that
+        // keep the line records below 6 GB.
+        using namespace blsgpu;
+        const hipStream_t st = (hipStream_t)stream;
+        const size_t slice = 262144;
+        const size_t m0 = n < slice ? n : slice;
+        if (grow_buffer(c, &c->d_lines, &c->lines_cap, m0 * ml::LINES * ml::LINE_DW * 4) == 0 && grow_buffer(c, &c->d_bad, &c->bad_cap, m0) == 0 &&
+            grow_elems(c, &c->d_degen, &c->degen_cap, m0 + 2) == 0 && ensure_workspace(c, 2 * m0) == 0) {
+            for (size_t lo = 0; lo < n; lo += slice) {
+                const size_t m = n - lo < slice ? n - lo : slice;
+                const uint32_t* p1 = (const uint32_t*)d_g1 + lo * 24;
+                const uint32_t* p2 = (const uint32_t*)d_g2 + lo * 48;
+                DegenList dg{c->d_degen, c->d_degen + 1, d_inf ? (const uint8_t*)d_inf + 2 * lo : nullptr};
+                hipLaunchKernelGGL(ml::k_ml_list_all, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (uint32_t)m, c->d_degen, c->d_degen + 1);
+                hipLaunchKernelGGL(ml::k_ml_lines_exact, dim3(2048), dim3(64), 0, st, p1, p2, (uint32_t)m, (int32_t*)c->d_lines, (uint8_t*)c->d_bad, dg, 0u, 0u, 0u);
+                const WaveShape ws = wave_shape(c, (m + ml::TEAMS - 1) / ml::TEAMS);
+                hipLaunchKernelGGL(ml::k_ml_small, dim3(ws.blocks), dim3(ws.threads), 0, st, (const int32_t*)c->d_lines, (const uint8_t*)c->d_bad, (uint32_t)m, 1u,
+                                   (uint32_t)m, c->d_part[0], 144u, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                hipLaunchKernelGGL(ml::k_ml_partials_to_bytes, dim3((unsigned)((m * 12 + 255) / 256)), dim3(256), 0, st, c->d_part[0], (uint32_t)(m * 12),
+                                   (uint32_t*)d_out + lo * 144);
+                HIP_TRY(hipGetLastError());
+            }
+            return 0;
+        }
+        (void)hipGetLastError();                               // no room for the line records: the VM's program below
+    }
     const unsigned grid = (unsigned)(n < 16384 ? n : 16384);
     hipLaunchKernelGGL(blsgpu::k_miller_exact, dim3(grid), dim3(64), (size_t)blsgpu::SLOW_TEAM_BYTES, (hipStream_t)stream, c->tabs,
                        (const uint32_t*)d_g1, (const uint32_t*)d_g2, (const uint8_t*)d_inf, (uint32_t)n, (uint32_t*)d_out);

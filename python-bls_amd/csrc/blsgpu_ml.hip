@@ -579,6 +579,36 @@ __global__ void __launch_bounds__(64) k_ml_lines_exact(const uint32_t* __restric
 ;
 #endif
 
+// ---- blsgpu_miller_loop_batch on the lane kernels (round 5): every pair listed, one accumulator per pair ------------------------------
+// The work list of ALL n pairs (count, then 0 .. n - 1): k_ml_lines_exact then writes every pair's line records with the reference's
+// own formulas and k_ml_small (groups of one) multiplies them up -- the reference's fq_miller_loop value itself.
+__global__ void __launch_bounds__(256) k_ml_list_all(uint32_t n, uint32_t* __restrict__ count, uint32_t* __restrict__ blocks)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0u) *count = n;
+    if (i < n) blocks[i] = i;
+}
+#else
+;
+#endif
+// partials in the wavefront VM's form (12 x 12 words x 2^384 per Fq12, the reference's flat order) -> n x 576 canonical big-endian bytes
+__global__ void __launch_bounds__(256) k_ml_partials_to_bytes(const uint32_t* __restrict__ partials, uint32_t nvalues, uint32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvalues) return;
+    uint32_t x[12], y[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) x[j] = partials[(size_t)i * 12 + j];
+    r28::to_raw(y, r28::from_vm(x));
+#pragma unroll
+    for (int j = 0; j < 12; j++) out[(size_t)i * 12 + j] = bswap32(y[11 - j]);
+}
+#else
+;
+#endif
+
 // ---- stages B / merge / Horner: six lanes per accumulator -----------------------------------------------------------
 struct Team {
     uint32_t c;            // the lane's coefficient: power of w

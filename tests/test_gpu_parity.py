@@ -145,8 +145,14 @@ def test_degenerate_pairs_inside_large_batches(engine, golden, seeded_pairs, ora
         engine.set_mp_threshold(4096)
 
 
-def test_miller_loop_batch_is_the_reference_value(engine, golden, seeded_pairs, oracle):
-    """blsgpu_miller_loop_batch == fq_miller_loop bit for bit (not up to the final exponentiation)"""
+@pytest.mark.parametrize("form", ["lane_kernels", "wavefront_vm_program"])
+def test_miller_loop_batch_is_the_reference_value(engine, golden, seeded_pairs, oracle, form):
+    """blsgpu_miller_loop_batch == fq_miller_loop bit for bit (not up to the final exponentiation): through the lane kernels
+    (k_ml_lines_exact + k_ml_small with groups of one, the default since round 5) and through the wavefront VM's reference-faithful
+    program k_miller_exact (BLSGPU_MILLER_EXACT_LANES=0)"""
+    if form == "wavefront_vm_program":
+        from conftest import engine_with_env
+        engine = engine_with_env({"BLSGPU_MILLER_EXACT_LANES": "0"})
     g = golden("pairing.json")
     assert engine.miller_loop_batch(bytes.fromhex(g["gen"]["g1"]), bytes.fromhex(g["gen"]["g2"]), 1).hex() == g["gen"]["miller"]
     v = g["small4"]
@@ -155,9 +161,9 @@ def test_miller_loop_batch_is_the_reference_value(engine, golden, seeded_pairs, 
         n = len(c["g1"])
         assert engine.miller_loop_batch(cat(c["g1"]), cat(c["g2"]), n, flags(c)).hex() == "".join(c["miller"]), name
     g1, g2 = seeded_pairs
-    n = 70
+    n = 333                                                             # (ragged last wavefronts of both lane kernels)
     out = engine.miller_loop_batch(g1[:96 * n], g2[:192 * n], n)
-    for i in (0, 1, 33, 69):
+    for i in (0, 1, 33, 69, 331, 332):
         assert out[576 * i:576 * (i + 1)] == oracle.miller_loop(g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)])
     assert engine.miller_loop_batch(b"", b"", 0) == b""
 
