@@ -24,6 +24,9 @@ def main():
     os.environ["BLSGPU_MILLER_WIDE3_MAX"] = "0"        # (read at context creation) the wide Miller loop on two wavefronts at every size
     eng2 = _native.Engine(0)
     del os.environ["BLSGPU_MILLER_WIDE3_MAX"]
+    os.environ["BLSGPU_MILLER_EXACT_LANES"] = "0"      # blsgpu_miller_loop_batch on the wavefront VM's reference-faithful program
+    eng_vm_exact = _native.Engine(0)
+    del os.environ["BLSGPU_MILLER_EXACT_LANES"]
     gold = os.path.join(ROOT, "tests", "golden")
     g1 = open(os.path.join(gold, "pairs_seed1_g1.bin"), "rb").read()
     g2 = open(os.path.join(gold, "pairs_seed1_g2.bin"), "rb").read()
@@ -71,8 +74,13 @@ def main():
         return b"".join(a), b"".join(b), bytes(f)
 
     for t in range(trials):
-        mode = t % 3
-        if mode == 0:                                   # one multi-pairing, one pair per wavefront / workgroup: k_miller (VM), k_miller_wide<3>, <2>
+        mode = 3 if t % 7 == 6 else t % 3
+        if mode == 3:                                   # blsgpu_miller_loop_batch: the reference's Miller value of every pair (lane kernels; the VM's program)
+            n = rng.choice([1, 2, 31, 32, 33, 70, 129])
+            a, b, f = pick(n, True)
+            got = rng.choice([eng, eng_vm_exact]).miller_loop_batch(a, b, n, f)
+            ok = all(got[576 * i:576 * (i + 1)] == O.miller_loop(a[96 * i:96 * (i + 1)], b[192 * i:192 * (i + 1)], bool(f[2 * i + 1])) for i in range(n))
+        elif mode == 0:                                   # one multi-pairing, one pair per wavefront / workgroup: k_miller (VM), k_miller_wide<3>, <2>
             n = rng.choice([1, 2, 3, 5, 63, 64, 65, 127, 200, 257, 600])
             a, b, f = pick(n, t % 2 == 1)
             e = rng.choice([eng, eng2])
