@@ -32,17 +32,20 @@ class AggregationInfo:
         return not self.tree
 
     # ---- ordering: lexicographic on (message hash, pk, exponent) triples
-    def _triples(self):
-        return [(mh, pk, self.tree[(mh, pk)]) for mh, pk in zip(self.message_hashes, self.public_keys)]
+    def _order_key(self):
+        """the triples with the key in its serialised form: PublicKey orders by its 48 bytes (keys.py:69), so comparing these tuples
+        IS the lexicographic comparison of the triples, the shorter list first on a tie -- kept on the object (sorting n infos
+        compared n log n lists built from scratch: 30 ms of a 1024-signature secure aggregation) and rebuilt when the map or the
+        lists were replaced (Signature.divide_by)"""
+        stamp = (len(self.tree), id(self.message_hashes), id(self.public_keys))
+        k = self.__dict__.get("_okey")
+        if k is None or k[0] != stamp:
+            k = (stamp, tuple((mh, pk.serialize(), self.tree[(mh, pk)]) for mh, pk in zip(self.message_hashes, self.public_keys)))
+            self.__dict__["_okey"] = k
+        return k[1]
 
     def __lt__(self, other):
-        a, b = self._triples(), other._triples()
-        for x, y in zip(a, b):
-            if x < y:
-                return True
-            if y < x:
-                return False
-        return len(a) < len(b)
+        return self._order_key() < other._order_key()
 
     def __eq__(self, other):
         return not self.__lt__(other) and not other.__lt__(self)
