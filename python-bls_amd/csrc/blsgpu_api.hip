@@ -102,9 +102,12 @@ struct blsgpu_ctx {
     void* d_lsp[2] = {nullptr, nullptr};   // dense partial products (ping-pong over the merge levels)
     size_t lsp_cap[2] = {0, 0};        // bytes
     void* d_bad = nullptr;             // one byte per pair: left to the slow program
+    void* d_exflags = nullptr;         // blsgpu_miller_loop_batch's fast form: the caller's flags with "py = 0" marked (2 bytes per pair)
+    size_t exflags_cap = 0;
     size_t bad_cap = 0;
     bool vm_exact_lanes = true;        // degenerate blocks of the VM kernels through the lane kernels (k_ml_lines_exact / k_ml_small) instead of k_miller_slow
     bool miller_exact_lanes = true;    // blsgpu_miller_loop_batch (one exact Fq12 per pair) on the lane kernels (k_ml_lines_exact + k_ml_small, round 5) instead of the VM's k_miller_exact
+    bool miller_exact_fast = true;     // ... from the FAST lines: the line-stream kernels + one Fq2 factor per pair (k_ml_exact_fixup) instead of the reference's 73 affine slopes per pair; false: k_ml_lines_exact for every pair
     size_t ls_merge_wide_max = 16384;  // merge levels with at most this many outputs run one wavefront per output
     size_t ls_wide_max = 5120;         // calls of at most this many pairs run the point chains sixteen lanes per pair with the values in LDS (k_ml_lines_wide, blsgpu_lsw.hip); 0: never
     size_t ls_quad_max = 20480;        // calls of at most this many pairs run the point chains on lane QUADS (k_ml_lines4: 0.6 of the depth while lane pairs leave SIMDs empty)
@@ -660,6 +663,7 @@ BLSGPU_EXPORT int blsgpu_ctx_create(int device, blsgpu_ctx** out) {
     if (const char* e = getenv("BLSGPU_MSM_SORT_THRESHOLD")) c->msm_sort_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MSM_SORT2_THRESHOLD")) c->msm_sort2_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_MILLER_EXACT_LANES")) c->miller_exact_lanes = atoi(e) != 0;
+    if (const char* e = getenv("BLSGPU_MILLER_EXACT_FAST")) c->miller_exact_fast = atoi(e) != 0;
     if (const char* e = getenv("BLSGPU_MSM_PLAIN_THRESHOLD")) c->msm_plain_threshold = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_SMUL_MIN_GROUPS")) c->smul_min_groups = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("BLSGPU_SMUL_MAX_K")) c->smul_max_k = (size_t)strtoull(e, nullptr, 10);
@@ -778,6 +782,7 @@ BLSGPU_EXPORT void blsgpu_ctx_destroy(blsgpu_ctx* c) {
     for (int i = 0; i < 2; i++)
         if (c->d_lsp[i]) (void)hipFree(c->d_lsp[i]);
     if (c->d_bad) (void)hipFree(c->d_bad);
+    if (c->d_exflags) (void)hipFree(c->d_exflags);
     if (c->d_fexp_ws) (void)hipFree(c->d_fexp_ws);
     if (c->d_h2c_ws) (void)hipFree(c->d_h2c_ws);
     for (void* q : c->retired) (void)hipFree(q);
@@ -1379,6 +1384,26 @@ BLSGPU_EXPORT int blsgpu_miller_loop_batch_dev(blsgpu_ctx* c, const void* d_g1, 
         const hipStream_t st = (hipStream_t)stream;
         const size_t slice = 262144;
         const size_t m0 = n < slice ? n : slice;
+        if (c->miller_exact_fast && grow_buffer(c, &c->d_exflags, &c->exflags_cap, 2 * m0) == 0 && ensure_workspace(c, 2 * m0) == 0) {
+            // the ordinary line-stream kernels with one accumulator per pair, then one Fq2 factor per pair turns the fast value into the
+            // reference's (k_ml_exact_fixup: 73 dependent inversions per pair become one); a pair the fast formulas are not valid for
+            // -- or whose py is 0, which the factor divides by -- takes the reference's own lines inside the same launches
+            bool ok = true;
+            for (size_t lo = 0; lo < n && ok; lo += slice) {
+                const size_t m = n - lo < slice ? n - lo : slice;
+                const uint32_t* p1 = (const uint32_t*)d_g1 + lo * 24;
+                const uint32_t* p2 = (const uint32_t*)d_g2 + lo * 48;
+                hipLaunchKernelGGL(ml::k_ml_exact_flags, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, p1, d_inf ? (const uint8_t*)d_inf + 2 * lo : nullptr,
+                                   (uint32_t)m, (uint8_t*)c->d_exflags);
+                const int rc_ = launch_miller_ls(c, p1, p2, c->d_exflags, 1, m, c->d_part[0], st);
+                if (rc_ == -ENOMEM && lo == 0) { ok = false; break; }          // no room for the line records: the forms below
+                if (rc_) return rc_;
+                hipLaunchKernelGGL(ml::k_ml_exact_fixup, dim3((unsigned)((2 * m + 255) / 256)), dim3(256), 0, st, p1, (const int32_t*)c->d_lines,
+                                   (const uint8_t*)c->d_bad, c->d_part[0], (uint32_t)m, (uint32_t*)d_out + lo * 144);
+                HIP_TRY(hipGetLastError());
+            }
+            if (ok) return 0;
+        }
         if (grow_buffer(c, &c->d_lines, &c->lines_cap, m0 * ml::LINES * ml::LINE_DW * 4) == 0 && grow_buffer(c, &c->d_bad, &c->bad_cap, m0) == 0 &&
             grow_elems(c, &c->d_degen, &c->degen_cap, m0 + 2) == 0 && ensure_workspace(c, 2 * m0) == 0) {
             for (size_t lo = 0; lo < n; lo += slice) {

@@ -31,6 +31,7 @@
 // reference's own line values (affine formulas, 0^-1 := 0, the chord step's branches), which k_ml_accum multiplies in
 // like any other line -- their product is the reference's Miller value of that pair itself.
 #pragma once
+#include "mlx_consts_gfx950.h"
 
 namespace blsgpu {
 namespace ml {
@@ -510,7 +511,7 @@ __global__ void __launch_bounds__(64) k_ml_lines_exact(const uint32_t* __restric
         }
         const uint32_t* s1 = g1 + (size_t)p * 24;
         const uint32_t* s2 = g2 + (size_t)p * 48 + part * 12;
-        const bool qinf = q_flagged(dg, p);
+        const bool qinf = dg.inf != nullptr && (dg.inf[2 * (size_t)p + 1] & 1u) != 0;   // (bit 1: listed without being flagged -- blsgpu_miller_loop_batch's pairs with py = 0)
         const fe px = load_coord(s1), py = load_coord(s1 + 12);
         const fe hnpx = r28::mul(r28::neg(px), half);                 // -px / 2
         const h qx = load_part(s2), qy = load_part(s2 + 24);
@@ -592,6 +593,20 @@ __global__ void __launch_bounds__(256) k_ml_list_all(uint32_t n, uint32_t* __res
 #else
 ;
 #endif
+// flags for blsgpu_miller_loop_batch's fast form: the caller's (P, Q) flags with bit 1 of Q's set where py = 0 mod q -- the lane
+// kernels send any non-zero flag through the reference's own lines (k_ml_exact_fixup divides by py)
+__global__ void __launch_bounds__(256) k_ml_exact_flags(const uint32_t* __restrict__ g1, const uint8_t* __restrict__ inf, uint32_t n, uint8_t* __restrict__ flags)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const fe py = load_coord(g1 + (size_t)p * 24 + 12);
+    flags[2 * (size_t)p] = inf ? inf[2 * (size_t)p] : 0;
+    flags[2 * (size_t)p + 1] = (uint8_t)((inf ? (inf[2 * (size_t)p + 1] & 1u) : 0u) | (r28::is_zero(py) ? 2u : 0u));
+}
+#else
+;
+#endif
 // partials in the wavefront VM's form (12 x 12 words x 2^384 per Fq12, the reference's flat order) -> n x 576 canonical big-endian bytes
 __global__ void __launch_bounds__(256) k_ml_partials_to_bytes(const uint32_t* __restrict__ partials, uint32_t nvalues, uint32_t* __restrict__ out)
 #if BLSGPU_EMIT(BLSGPU_TU_ML)
@@ -604,6 +619,84 @@ __global__ void __launch_bounds__(256) k_ml_partials_to_bytes(const uint32_t* __
     r28::to_raw(y, r28::from_vm(x));
 #pragma unroll
     for (int j = 0; j < 12; j++) out[(size_t)i * 12 + j] = bswap32(y[11 - j]);
+}
+#else
+;
+#endif
+
+// blsgpu_miller_loop_batch from the FAST lines (round 5): one Fq2 factor per pair instead of 73 inversions.  The fast lines are the
+// exact ones times an Fq2 factor and w^3 --  l_fast = c w^3 l_exact  with  c = 2YZ (tangent), 3 (X - xq Z) (chord), and the third
+// coefficient of l_fast is  c py  -- so with S = sum over the lines of 2^(squarings after the line) (odd) and
+// L3 = prod (third coefficient)^(2^(squarings after)):   f_exact = w^-3 D f_fast,   D = py^S / (L3 xi^((S - 1) / 2))
+// (vmgen/gen_mlx.py: derivation, constants, the identity on the integer model -- tests/test_mlx_model.py).  One pair per lane pair:
+// reads the pair's 68 line records (third coefficients), its partial (the wavefront VM's form, flat order) and py; writes the
+// reference's 576 bytes.  A pair whose flag byte is set went through the reference's own lines: its partial IS the value.
+__global__ void __launch_bounds__(256, 2) k_ml_exact_fixup(const uint32_t* __restrict__ g1, const int32_t* __restrict__ lines, const uint8_t* __restrict__ bad,
+                                                          const uint32_t* __restrict__ partials, uint32_t n, uint32_t* __restrict__ out)
+#if BLSGPU_EMIT(BLSGPU_TU_ML)
+{
+    using namespace sp;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pr = t >> 1, part = t & 1u;
+    const uint32_t p = pr < n ? pr : n - 1u;                          // the last wavefront's spare lane pairs repeat the last pair
+    h f[6];                                                           // flat Fq2 index i = power (0, 2, 4, 1, 3, 5)[i] of w: this lane's parts
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        uint32_t x[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) x[j] = partials[(size_t)p * 144 + (2 * i + part) * 12 + j];
+        const fe v = r28::from_vm(x);
+#pragma unroll
+        for (int j = 0; j < NL; j++) f[i].v[j] = v.v[j];
+    }
+    if (bad[p] == 0) {
+        const size_t lstride = (size_t)n * LINE_DW;
+        const int32_t* rec = lines + (size_t)p * LINE_DW + (2 * 2 + part) * NL;
+        h L3;
+#pragma unroll
+        for (int j = 0; j < NL; j++) L3.v[j] = rec[j];
+#pragma unroll 1
+        for (uint32_t L = 1; L < (uint32_t)LINES; L++) {
+            rec += lstride;
+            h l;
+#pragma unroll
+            for (int j = 0; j < NL; j++) l.v[j] = rec[j];
+            const bool chord = L < 64u && ((MLX_CHORD_MASK_LO >> L) & 1ull) != 0ull;        // (every chord is among the first 64 lines)
+            if (!chord) L3 = sqr(L3);
+            L3 = mul(left(L3), right(l));
+        }
+        const fe py = load_coord(g1 + (size_t)p * 24 + 12);
+        fe ps = py;                                                   // py^S, from the top bit of S down
+#pragma unroll 1
+        for (int b = 62; b >= 0; b--) {
+            ps = r28::sqr(ps);
+            if ((MLX_S >> b) & 1ull) ps = r28::mul(ps, py);
+        }
+        const int32_t kr[NL] = MLX_KAPPA_RE, ki[NL] = MLX_KAPPA_IM, halfc[NL] = BLS28_HALF;
+        h kap;
+        fe half;
+#pragma unroll
+        for (int j = 0; j < NL; j++) { kap.v[j] = part ? ki[j] : kr[j]; half.v[j] = halfc[j]; }
+        const h D = mulf(inv2(mul(left(L3), right(kap))), ps);
+        const Rop<1> rD = right(D);
+        // power k of w: k < 3 takes D f[k + 3], k >= 3 takes xi^-1 D f[k - 3]; flat index of power k: (0, 3, 1, 4, 2, 5)[k]
+        const h g0 = mul(left(f[4]), rD), g1v = mul(left(f[2]), rD), g2v = mul(left(f[5]), rD);                 // powers 0, 1, 2 <- 3, 4, 5
+        const h g3 = mulf(xisum(mul(left(f[0]), rD)), half), g4 = mulf(xisum(mul(left(f[3]), rD)), half),      // powers 3, 4, 5 <- xi^-1 x 0, 1, 2
+                g5 = mulf(xisum(mul(left(f[1]), rD)), half);
+        f[0] = g0; f[3] = g1v; f[1] = g2v; f[4] = g3; f[2] = g4; f[5] = g5;
+    }
+    if (pr < n) {
+#pragma unroll 1
+        for (int i = 0; i < 6; i++) {
+            fe v;
+#pragma unroll
+            for (int j = 0; j < NL; j++) v.v[j] = f[i].v[j];
+            uint32_t y[12];
+            r28::to_raw(y, v);
+#pragma unroll
+            for (int j = 0; j < 12; j++) out[(size_t)p * 144 + (2 * i + part) * 12 + j] = bswap32(y[11 - j]);
+        }
+    }
 }
 #else
 ;

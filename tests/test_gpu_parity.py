@@ -145,14 +145,18 @@ def test_degenerate_pairs_inside_large_batches(engine, golden, seeded_pairs, ora
         engine.set_mp_threshold(4096)
 
 
-@pytest.mark.parametrize("form", ["lane_kernels", "wavefront_vm_program"])
+@pytest.mark.parametrize("form", ["fast_lines_and_one_factor_per_pair", "reference_lines_for_every_pair", "wavefront_vm_program"])
 def test_miller_loop_batch_is_the_reference_value(engine, golden, seeded_pairs, oracle, form):
-    """blsgpu_miller_loop_batch == fq_miller_loop bit for bit (not up to the final exponentiation): through the lane kernels
-    (k_ml_lines_exact + k_ml_small with groups of one, the default since round 5) and through the wavefront VM's reference-faithful
-    program k_miller_exact (BLSGPU_MILLER_EXACT_LANES=0)"""
+    """blsgpu_miller_loop_batch == fq_miller_loop bit for bit (not up to the final exponentiation): from the line-stream stage's
+    fast lines with one Fq2 factor per pair (k_ml_exact_fixup, the default since round 5; degenerate pairs and py = 0 take the
+    reference's own lines inside the same launches), with the reference's lines for every pair (k_ml_lines_exact + k_ml_small,
+    BLSGPU_MILLER_EXACT_FAST=0), and through the wavefront VM's reference-faithful program k_miller_exact
+    (BLSGPU_MILLER_EXACT_LANES=0)"""
+    from conftest import engine_with_env
     if form == "wavefront_vm_program":
-        from conftest import engine_with_env
         engine = engine_with_env({"BLSGPU_MILLER_EXACT_LANES": "0"})
+    elif form == "reference_lines_for_every_pair":
+        engine = engine_with_env({"BLSGPU_MILLER_EXACT_FAST": "0"})
     g = golden("pairing.json")
     assert engine.miller_loop_batch(bytes.fromhex(g["gen"]["g1"]), bytes.fromhex(g["gen"]["g2"]), 1).hex() == g["gen"]["miller"]
     v = g["small4"]
@@ -165,6 +169,13 @@ def test_miller_loop_batch_is_the_reference_value(engine, golden, seeded_pairs, 
     out = engine.miller_loop_batch(g1[:96 * n], g2[:192 * n], n)
     for i in (0, 1, 33, 69, 331, 332):
         assert out[576 * i:576 * (i + 1)] == oracle.miller_loop(g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)])
+    # py = 0 (not a point of G1, but the reference's loop is a total function of the coordinates): the factor would divide by it
+    g1z = bytearray(g1[:96 * 5])
+    g1z[96 * 1 + 48:96 * 2] = bytes(48)
+    g1z[96 * 3:96 * 4] = bytes(96)
+    out = engine.miller_loop_batch(bytes(g1z), g2[:192 * 5], 5)
+    for i in range(5):
+        assert out[576 * i:576 * (i + 1)] == oracle.miller_loop(bytes(g1z[96 * i:96 * (i + 1)]), g2[192 * i:192 * (i + 1)]), i
     assert engine.miller_loop_batch(b"", b"", 0) == b""
 
 

@@ -27,6 +27,9 @@ def main():
     os.environ["BLSGPU_MILLER_EXACT_LANES"] = "0"      # blsgpu_miller_loop_batch on the wavefront VM's reference-faithful program
     eng_vm_exact = _native.Engine(0)
     del os.environ["BLSGPU_MILLER_EXACT_LANES"]
+    os.environ["BLSGPU_MILLER_EXACT_FAST"] = "0"       # ... on k_ml_lines_exact for every pair (the default: fast lines + one factor per pair)
+    eng_ref_lines = _native.Engine(0)
+    del os.environ["BLSGPU_MILLER_EXACT_FAST"]
     gold = os.path.join(ROOT, "tests", "golden")
     g1 = open(os.path.join(gold, "pairs_seed1_g1.bin"), "rb").read()
     g2 = open(os.path.join(gold, "pairs_seed1_g2.bin"), "rb").read()
@@ -47,7 +50,7 @@ def main():
             i = rng.randrange(1025)
             p, q, fl = g1[96 * i:96 * (i + 1)], g2[192 * i:192 * (i + 1)], (0, 0)
             if degenerate and rng.random() < 0.08:
-                kind = rng.randrange(10)
+                kind = rng.randrange(11)
                 if kind == 0:
                     p = bytes(96)                       # P = (0, 0)
                 elif kind == 1:
@@ -66,6 +69,8 @@ def main():
                     fl = (rng.randrange(2), 1)          # flagged valid Q
                 elif kind == 8:
                     q, fl = rng.choice(low), (0, 1)
+                elif kind == 10:
+                    p = fq() + bytes(48)                # P.y = 0
                 else:
                     p = bytes(48) + fq()                # P.x = 0
             a.append(p)
@@ -78,7 +83,7 @@ def main():
         if mode == 3:                                   # blsgpu_miller_loop_batch: the reference's Miller value of every pair (lane kernels; the VM's program)
             n = rng.choice([1, 2, 31, 32, 33, 70, 129])
             a, b, f = pick(n, True)
-            got = rng.choice([eng, eng_vm_exact]).miller_loop_batch(a, b, n, f)
+            got = rng.choice([eng, eng, eng_ref_lines, eng_vm_exact]).miller_loop_batch(a, b, n, f)
             ok = all(got[576 * i:576 * (i + 1)] == O.miller_loop(a[96 * i:96 * (i + 1)], b[192 * i:192 * (i + 1)], bool(f[2 * i + 1])) for i in range(n))
         elif mode == 0:                                   # one multi-pairing, one pair per wavefront / workgroup: k_miller (VM), k_miller_wide<3>, <2>
             n = rng.choice([1, 2, 3, 5, 63, 64, 65, 127, 200, 257, 600])
