@@ -726,7 +726,67 @@ def secondary(env, args, eng, gen1, gen2):
     out["verify_pipeline"] = run_verify_pipeline(env, eng)
     out["verify_single_signature"] = run_verify_single(env, eng)
     out["g2_sum"] = run_g2_sum(env, eng, gen2)
+    out["other_shapes"] = run_other_shapes(env, eng, gen1, gen2)
     return out
+
+
+def run_other_shapes(env, eng, gen1, gen2, n=65536):
+    """The entry points in the call shapes BASELINE.json does not name (tools/shape_sweep.py): a batch of scalar
+    multiplications (groups x 1 point: key generation, signing), ONE plain sum of the results (aggregate_pub_keys / aggregate_sigs
+    without exponents), and the reference's own fq_miller_loop value per pair (blsgpu_miller_loop_batch).  Device-resident, each
+    with a check that does not go through the kernel it checks."""
+    torch = env.torch
+    from bls_py import _native
+    old = {k: os.environ.get(k) for k in ("BLSGPU_MSM_SORT_THRESHOLD", "BLSGPU_MSM_SORT2_THRESHOLD", "BLSGPU_MSM_PLAIN_THRESHOLD", "BLSGPU_SMUL_MIN_GROUPS")}
+    for k in old:
+        os.environ[k] = str(1 << 40)
+    try:
+        vm = _native.Engine(env.local_dev)                       # the wavefront VM's / fixed-window kernels: the independent side of the checks
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    a = [prf_scalar(b"blsgpu/shapes/a", 0, i) for i in range(n)]
+    sc = env.up(b"".join(x.to_bytes(32, "big") for x in a))
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    pts = {}
+    for deg, gen, fn in ((1, gen1, "blsgpu_g1_msm_dev"), (2, gen2, "blsgpu_g2_msm_dev")):
+        sz = 96 * deg
+        dp, do, fl = env.up(gen * n), torch.zeros(sz * n, dtype=torch.uint8, device=env.dev), torch.zeros(n, dtype=torch.uint8, device=env.dev)
+        f = getattr(eng.lib, fn)
+        dt = device_timed(env, lambda: f(eng.h, dp.data_ptr(), sc.data_ptr(), 1, n, do.data_ptr(), fl.data_ptr(), st), 2)
+        got = bytes(do.cpu().numpy())
+        probe = [0, 1, n // 2, n - 1]
+        want = (vm.g1_msm if deg == 1 else vm.g2_msm)(gen * len(probe), [a[i] for i in probe], 1, len(probe))[0]
+        if b"".join(got[sz * i:sz * (i + 1)] for i in probe) != want:
+            raise SystemExit("other_shapes: a scalar multiplication of the batch differs from the fixed-window kernels' -- bench invalid")
+        res["scalar_multiplications_g%d" % deg] = {"value": n / dt, "unit": "points/s", "ms": dt * 1e3, "batch": n}
+        pts[deg] = do
+        # one plain sum of the n results: sum a_i G == (sum a_i) G
+        out1, inf1 = torch.zeros(sz, dtype=torch.uint8, device=env.dev), torch.zeros(1, dtype=torch.uint8, device=env.dev)
+        dt = device_timed(env, lambda: f(eng.h, do.data_ptr(), None, n, 1, out1.data_ptr(), inf1.data_ptr(), st), 3)
+        want = (vm.g1_msm if deg == 1 else vm.g2_msm)(gen, [sum(a) % N_ORDER], 1, 1)[0]
+        if bytes(out1.cpu().numpy()) != want:
+            raise SystemExit("other_shapes: sum a_i G != (sum a_i) G -- bench invalid")
+        res["plain_sum_g%d" % deg] = {"value": n / dt, "unit": "points/s", "ms": dt * 1e3, "points": n}
+    # the reference's Miller value of every pair (a_i G1, a_i G2); check: its final exponentiation is the pairing of the pair
+    om = torch.zeros(576 * n, dtype=torch.uint8, device=env.dev)
+    dt = device_timed(env, lambda: eng.miller_loop_batch_dev(pts[1].data_ptr(), pts[2].data_ptr(), n, om.data_ptr(), st), 2)
+    dt1 = device_timed(env, lambda: eng.miller_loop_batch_dev(pts[1].data_ptr(), pts[2].data_ptr(), 1, om.data_ptr(), st), 3)
+    eng.miller_loop_batch_dev(pts[1].data_ptr(), pts[2].data_ptr(), n, om.data_ptr(), st)
+    torch.cuda.synchronize()
+    g1b, g2b, mb = bytes(pts[1][:96 * 3].cpu().numpy()), bytes(pts[2][:192 * 3].cpu().numpy()), bytes(om[:576 * 3].cpu().numpy())
+    for i in range(3):
+        if eng.final_exp(mb[576 * i:576 * (i + 1)]) != eng.pairing_multi(g1b[96 * i:96 * (i + 1)], g2b[192 * i:192 * (i + 1)], 1):
+            raise SystemExit("other_shapes: final_exp(miller_loop_batch value) != pairing -- bench invalid")
+    res["miller_loop_batch"] = {"value": n / dt, "unit": "pairs/s", "ms": dt * 1e3, "pairs": n, "one_pair_ms": dt1 * 1e3}
+    res["check"] = ("scalar multiplications: four of the batch against the fixed-window kernels; plain sums: sum a_i G == (sum a_i) G from those "
+                    "kernels; Miller values: their final exponentiation == the pairing of the pair (tests/test_gpu_parity.py holds them to the "
+                    "reference's golden fq_miller_loop values)")
+    return res
 
 
 def run_g2_sum(env, eng, gen2, n=16384):
