@@ -448,17 +448,29 @@ static int msm_plain(blsgpu_ctx* c, const void* d_pts, size_t n, void* d_out, vo
 template <int DEG>
 static int msm_small_groups(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, size_t groups, void* d_out, void* d_out_inf, hipStream_t st) {
     typedef blsgpu::SrtG<DEG> G;
-    const size_t n = k * groups, upw = 64 / G::LP, units = (groups + upw - 1) / upw * upw;          // whole wavefronts of units
+    // slices of groups whose tables (16 projective multiples per point) stay below 2 GB: 2^20 groups of eight G2 points would ask for 45 GB
+    const size_t upw = 64 / G::LP, per_group = k * blsgpu::SMUL_T * G::PJ * 4;
+    size_t slice = ((size_t)2 << 30) / per_group / upw * upw;
+    if (slice < upw) slice = upw;
+    if (slice > groups) slice = groups;
+    const size_t units0 = (slice + upw - 1) / upw * upw, n0 = k * slice;
     size_t off = 0;
     auto take = [&](size_t words) { size_t o = off; off += (words + 3) & ~(size_t)3; return o; };
-    const size_t o_prep = take(n * blsgpu::L28_AFF * DEG), o_live = take((n + 3) / 4), o_tab = take(units * k * blsgpu::SMUL_T * G::PJ);
-    if (int rc_ = grow_elems(c, &c->d_buckets, &c->bucket_cap, off)) return rc_;
+    const size_t o_prep = take(n0 * blsgpu::L28_AFF * DEG), o_live = take((n0 + 3) / 4), o_tab = take(units0 * k * blsgpu::SMUL_T * G::PJ);
+    if (grow_elems(c, &c->d_buckets, &c->bucket_cap, off)) {
+        (void)hipGetLastError();
+        return 1;                                              // no room: the caller's other kernels
+    }
     uint32_t* W = c->d_buckets;
     uint8_t* live = (uint8_t*)(W + o_live);
-    hipLaunchKernelGGL(blsgpu::k_lane_prep<DEG>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts, (uint32_t)n, W + o_prep, live);
-    hipLaunchKernelGGL(blsgpu::k_smul<DEG>, dim3((unsigned)(units * G::LP / 64)), dim3(64), 0, st, W + o_prep, live, (const uint32_t*)d_scalars, (uint32_t)k,
-                       (uint32_t)groups, W + o_tab, (uint32_t*)d_out, (uint8_t*)d_out_inf);
-    HIP_TRY(hipGetLastError());
+    for (size_t lo = 0; lo < groups; lo += slice) {
+        const size_t m = groups - lo < slice ? groups - lo : slice, n = k * m, units = (m + upw - 1) / upw * upw;
+        hipLaunchKernelGGL(blsgpu::k_lane_prep<DEG>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_pts + lo * k * 24 * DEG, (uint32_t)n,
+                           W + o_prep, live);
+        hipLaunchKernelGGL(blsgpu::k_smul<DEG>, dim3((unsigned)(units * G::LP / 64)), dim3(64), 0, st, W + o_prep, live, (const uint32_t*)d_scalars + lo * k * 8,
+                           (uint32_t)k, (uint32_t)m, W + o_tab, (uint32_t*)d_out + lo * 24 * DEG, d_out_inf ? (uint8_t*)d_out_inf + lo : nullptr);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -475,7 +487,10 @@ int msm_dev(blsgpu_ctx* c, const void* d_pts, const void* d_scalars, size_t k, s
     }
     if (k > 0x7FFFFFFFull || groups > 0x7FFFFFFFull || k * groups > 0xFFFFFFF0ull) return fail(-EINVAL, "msm too large");
     if (groups == 1 && !d_scalars && k >= c->msm_plain_threshold) return msm_plain<DEG>(c, d_pts, k, d_out, d_out_inf, st);
-    if (d_scalars && groups >= c->smul_min_groups && k <= c->smul_max_k) return msm_small_groups<DEG>(c, d_pts, d_scalars, k, groups, d_out, d_out_inf, st);
+    if (d_scalars && groups >= c->smul_min_groups && k <= c->smul_max_k) {
+        const int rc_ = msm_small_groups<DEG>(c, d_pts, d_scalars, k, groups, d_out, d_out_inf, st);
+        if (rc_ != 1) return rc_;
+    }
     if (groups == 1 && d_scalars && k >= (DEG == 1 ? c->msm_sort_threshold : c->msm_sort2_threshold)) {
         const int rc_ = msm_sorted<DEG>(c, d_pts, d_scalars, k, d_out, d_out_inf, st);
         if (rc_ != 1) return rc_;

@@ -653,3 +653,16 @@ def test_batches_of_small_sums_with_scalars(smul_engine, engine, fixed_window_en
         want, _ = om(pts[sz * k * g:sz * k * (g + 1)], sc[k * g:k * (g + 1)], k)
         assert got[sz * g:sz * (g + 1)] == want and inf[g] == (want == bytes(sz)), g
 
+
+def test_batches_of_small_sums_in_slices(engine, fixed_window_engine, seeded_pairs):
+    """more groups than one 2 GB table holds (50 100 groups of eight G2 points: 16 multiples of 336 bytes per point): the batch runs
+    in slices of groups; every group against the wavefront VM's double-and-add"""
+    _, g2 = seeded_pairs
+    k, groups = 8, 50100
+    n = k * groups
+    npts = len(g2) // 192
+    rnd = random.Random(50100)
+    pts = b"".join(g2[192 * j:192 * (j + 1)] for j in (rnd.randrange(npts) for _ in range(n)))
+    sc = [rnd.randrange(1 << 256) for _ in range(n)]
+    assert engine.g2_msm(pts, sc, k, groups) == fixed_window_engine.g2_msm(pts, sc, k, groups)
+
